@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""Headline benchmark: NEWT forward throughput (audio samples/s, x real-time) on 4 s @ 16 kHz clips.
+
+    python bench.py [--gpus N --steps K --warmup W] [--batch 64] [--frames 500] [--exact]
+
+Contract: a step = one NeuralWaveshaping.forward over a batch of `--batch` synthetic
+utterances per GPU (torch.rand F0/control exactly like the reference's scripts/time_forward_pass.py:27-40,
+vn checkpoint, FastNEWT LUT), inputs resident in HBM, the two RNG draws of forward() made on the device
+inside the step; with N>1 the rendered waveforms are all-gathered over RCCL (overlapped with the next
+step's kernels).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work of the dominant kernel (exciter_newt_kernel) per utterance of T=500 frames, SURVEY.md §8(d):
+#   harmonic mixer 2*64*101 flop/sample + 101 sin/sample (1 flop each) + FiLM lerp/FiLM/LUT/mix ~ 24 flop per (sample, shaper)
+FLOP_PER_SAMPLE_EXCITER_NEWT = 2 * 64 * 101 + 101 * 5 + 64 * 24
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU (weak scaling: fixed per-GPU work)")
+    ap.add_argument("--frames", type=int, default=500, help="control frames per utterance (500 = 4 s @ 16 kHz)")
+    ap.add_argument("--exact", action="store_true", help="exact sin-MLP shapers instead of the FastNEWT LUT")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=60)
+    ap.add_argument("--batch1-iters", type=int, default=200)
+    return ap.parse_args()
+
+
+def cpu_baseline(weights_path, iters, T):
+    """The oracle (op-for-op torch-CPU restatement of the reference forward, python LUT loop included) timed on
+    the host cores, protocol of scripts/time_forward_pass.py: B=1, torch.rand inputs, FastNEWT."""
+    from oracle.newt_oracle import OracleNEWT, load_weights_npz
+
+    w = {k: v for k, v in load_weights_npz(weights_path).items() if not k.startswith("__")}
+    o = OracleNEWT(w, fast=True, lut_python_loop=True)
+    torch.manual_seed(0)
+    f0, control = torch.rand(1, 1, T), torch.rand(1, 2, T)
+    for _ in range(3):
+        o(f0, control)
+    ts = []
+    t_end = time.time() + 25.0
+    for _ in range(iters):
+        t0 = time.time()
+        o(f0, control)
+        ts.append(time.time() - t0)
+        if time.time() > t_end:
+            break
+    mean = float(np.mean(ts))
+    return {"value": 128 * T / mean, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(ts)} forwards of B=1, T={T} (4 s) FastNEWT, torch.rand inputs, oracle/newt_oracle.py "
+                      f"(torch {torch.__version__} CPU, {os.cpu_count()} logical cpus)",
+            "ms_per_utterance": mean * 1e3, "x_realtime": (128 * T / 16000.0) / mean}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    nws = importlib.import_module("neural-waveshaping-synthesis_amd")
+    _lib = importlib.import_module("neural-waveshaping-synthesis_amd._lib")
+    par = importlib.import_module("neural-waveshaping-synthesis_amd.parallel")
+    nws.ensure_default_config()
+    wpath = os.path.join(ROOT, "tests", "golden", "weights_vn.npz")
+    model = nws.NeuralWaveshaping.load_from_checkpoint(wpath).to(dev).eval()
+    if not a.exact:
+        model.newt = nws.FastNEWT(model.newt)
+
+    B, T = a.batch, a.frames
+    N = 128 * T
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    f0 = torch.rand(B, 1, T, device=dev, generator=g)         # time_forward_pass.py:34-40
+    control = torch.rand(B, 2, T, device=dev, generator=g)    # time_forward_pass.py:27-33
+    full = [torch.empty((B * world, N), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
+
+    def step(i, pending):
+        if world > 1:
+            pu, nz = par.shared_draws(101, N - 1, dev)       # identical draws on all ranks
+            y = model(f0, control, phase_u=pu, noise=nz)
+            if pending is not None:
+                pending.wait()
+            return dist.all_gather_into_tensor(full[i & 1], y, async_op=True)
+        model(f0, control)
+        return None
+
+    with torch.no_grad():
+        pending = None
+        for i in range(a.warmup):
+            pending = step(i, pending)
+        if pending is not None:
+            pending.wait()
+        torch.cuda.synchronize()
+        # live HIP-event timing of the dominant kernel on its launch stream, inside the timed region
+        _lib.check(_lib.lib().nws_profile_begin(a.steps, 1 << 3))
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pending = None
+        for i in range(a.steps):
+            pending = step(i, pending)
+        if pending is not None:
+            pending.wait()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        ms = (C.c_float * (a.steps * 6))()
+        n = C.c_int(0)
+        _lib.check(_lib.lib().nws_profile_collect(ms, C.byref(n)))
+        k_ms = float(np.mean([ms[i * 6 + 3] for i in range(n.value)])) if n.value else float("nan")
+
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+
+        extra = {}
+        if rank == 0:
+            # per-stage breakdown (diagnostic, outside the timed region)
+            _lib.check(_lib.lib().nws_profile_begin(10, 0x3F))
+            for _ in range(10):
+                model(f0, control)
+            torch.cuda.synchronize()
+            ms2 = (C.c_float * 60)()
+            _lib.check(_lib.lib().nws_profile_collect(ms2, C.byref(n)))
+            extra["stage_ms"] = {nm: round(float(np.mean([ms2[i * 6 + s] for i in range(n.value)])), 4)
+                                 for s, nm in enumerate(_lib.STAGE_NAMES)}
+            _lib.lib().nws_profile_end()
+            if world == 1:
+                # config "batch=1, single MI355X, FastNEWT": latency / x real-time per utterance
+                f1, c1 = f0[:1].contiguous(), control[:1].contiguous()
+                for _ in range(10):
+                    model(f1, c1)
+                torch.cuda.synchronize()
+                lat = []
+                for _ in range(a.batch1_iters):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    model(f1, c1)
+                    e1.record()
+                    e1.synchronize()
+                    lat.append(e0.elapsed_time(e1))
+                lat = np.array(lat)
+                dur_ms = N / 16000.0 * 1e3
+                extra["batch1"] = {"p50_ms": round(float(np.percentile(lat, 50)), 4), "p90_ms": round(float(np.percentile(lat, 90)), 4),
+                                   "x_realtime_p50": round(dur_ms / float(np.percentile(lat, 50)), 1),
+                                   "rtf_mean": float(np.mean(lat) / dur_ms)}
+
+    if rank == 0:
+        total_samples = B * world * N * a.steps
+        value = total_samples / elapsed
+        ms_per_step = elapsed / a.steps * 1e3
+        flops = FLOP_PER_SAMPLE_EXCITER_NEWT * B * N
+        achieved = flops / (k_ms * 1e-3) / 1e12
+        out = {
+            "metric": "audio_samples_per_sec", "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"NEWT forward, vn checkpoint, {'exact sin-MLP shapers' if a.exact else 'FastNEWT LUT'}, "
+                                   f"batch {B}/GPU x {T} frames (4 s @ 16 kHz), torch.rand F0/control, "
+                                   f"RNG draws on device{', RCCL all-gather of waveforms' if world > 1 else ''}",
+                       "batch_per_gpu": B, "frames": T, "samples_per_utterance": N, "parallelism": f"batch-shard x{world}"},
+            "x_realtime_aggregate": value / 16000.0,
+            "rtf_per_utterance": (ms_per_step * 1e-3) / (N / 16000.0) / B,
+            "roofline": {"bound": "mfma", "kernel": "exciter_newt_kernel", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel_ms": k_ms, "flop_per_launch": flops},
+        }
+        out.update(extra)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wpath, a.cpu_iters, T)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

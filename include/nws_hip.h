@@ -1,0 +1,216 @@
+/*
+ * nws_hip.h — C-ABI of the MI355X (gfx950) NEWT synthesis engine.
+ *
+ * The reference (ben-hayes/neural-waveshaping-synthesis) has no FFI: its hot path sits behind
+ * a Python nn.Module.  This header is the drop-in boundary *below* that
+ * surface: every entry point replaces one block of ATen calls made by the reference's
+ * forward().  Citations are relative to /root/reference/neural_waveshaping_synthesis/.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers to contiguous fp32 unless
+ *     stated otherwise; `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - every launcher returns 0 on success, a positive hipError_t if the HIP runtime failed, or
+ *     one of the negative NWS_ERR_* codes below.  Nothing is synchronised: work is enqueued on
+ *     `stream` exactly like the ATen ops it replaces.
+ *   - kernels are specialised for the architecture of gin/models/newt.gin (the only one the
+ *     reference ships): 101 harmonics, 64 waveshapers, hidden/embedding 128, shaper MLP width 8
+ *     depth 4, control hop 128, FIR length 256.  Other sizes return NWS_ERR_UNSUPPORTED.
+ *   - B = batch, T = control frames, N = 128*T samples.
+ */
+#ifndef NWS_HIP_H
+#define NWS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NWS_ABI_VERSION 1
+
+#define NWS_N_HARMONICS 101
+#define NWS_N_SHAPERS 64
+#define NWS_HIDDEN 128
+#define NWS_HOP 128
+#define NWS_FIR_LEN 256
+#define NWS_N_BANDS 129      /* FIR_LEN/2 + 1 */
+#define NWS_SHAPER_WIDTH 8
+#define NWS_FILM_CH 256      /* 4 * N_SHAPERS */
+
+enum {
+  NWS_OK = 0,
+  NWS_ERR_UNSUPPORTED = -1, /* sizes outside the compiled specialisation */
+  NWS_ERR_BAD_ARG = -2,     /* NULL / non-positive / misaligned argument */
+  NWS_ERR_WORKSPACE = -3    /* workspace too small */
+};
+
+/* Device pointers to the parameters, in the reference's own state_dict layouts. */
+typedef struct NwsWeights {
+  /* embedding = ControlModule (models/neural_waveshaping.py:17-26) */
+  const float* gru_w_ih;  /* (384, 2)   rows [r; z; n] */
+  const float* gru_w_hh;  /* (384, 128) */
+  const float* gru_b_ih;  /* (384) */
+  const float* gru_b_hh;  /* (384) */
+  const float* proj_w;    /* (128, 128) Conv1d k=1 */
+  const float* proj_b;    /* (128) */
+  /* harmonic_mixer = Conv1d(101, 64, 1) (models/neural_waveshaping.py:54) */
+  const float* mixer_w;   /* (64, 101) */
+  const float* mixer_b;   /* (64) */
+  /* newt.mlp = TimeDistributedMLP(128,128,256,depth=4) (models/modules/shaping.py:53-55) */
+  const float* newt_mlp_w[4]; /* (128,128) x3, (256,128) */
+  const float* newt_mlp_b[4];
+  const float* newt_ln_g[3];  /* LayerNorm weight (128) */
+  const float* newt_ln_b[3];
+  /* h_generator = TimeDistributedMLP(128,128,129,depth=4) (models/neural_waveshaping.py:58-59) */
+  const float* hgen_w[4];     /* (128,128) x3, (129,128) */
+  const float* hgen_b[4];
+  const float* hgen_ln_g[3];
+  const float* hgen_ln_b[3];
+  /* newt.shaping_fn = TrainableNonlinearity(64, 8, depth=4) (models/modules/shaping.py:15-37) */
+  const float* shaper_in_scale; /* (64) */
+  const float* shaper_w0; /* (512)    net.0.weight (512,1,1) */
+  const float* shaper_b0; /* (512) */
+  const float* shaper_w2; /* (512, 8) net.2.weight */
+  const float* shaper_b2; /* (512) */
+  const float* shaper_w4; /* (512, 8) net.4.weight */
+  const float* shaper_b4; /* (512) */
+  const float* shaper_w6; /* (64, 8)  net.6.weight */
+  const float* shaper_b6; /* (64) */
+  /* FastNEWT.lookup_table (models/modules/shaping.py:103-105); NULL selects the exact shapers */
+  const float* lut;       /* (64, lut_size) */
+  int32_t lut_size;       /* 4096 */
+  float lut_min;          /* -3 */
+  float lut_max;          /* +3 */
+  /* newt.mixer = Conv1d(64, 1, 1) (models/modules/shaping.py:63-65) */
+  const float* newt_out_w; /* (64) */
+  const float* newt_out_b; /* (1) */
+  /* noise_synth.window (models/modules/generators.py:20), periodic Hann(256) */
+  const float* noise_window; /* (256) */
+} NwsWeights;
+
+int nws_abi_version(void);
+const char* nws_error_string(int code);
+
+/* ---- hardware self-test: MFMA fragment layout the kernels rely on (returns #mismatches in *bad) ---- */
+int nws_selftest_mfma(int32_t* bad_out /* device int32[1] */, void* stream);
+
+/* ---- accurate sinf used by the oscillator / shapers, exposed for testing: y[i] = sin(x[i]) ---- */
+int nws_sin(const float* x, float* y, int64_t n, void* stream);
+
+/*
+ * Exciter phase carries.  Replaces the double-accumulated torch.cumsum of
+ * models/modules/generators.py:59 at 32-sample granularity:
+ *   carry[b][c] = sum_{n < 32c} f0_up[b][n]   (float64, exclusive)
+ * f0 (B,T) Hz frames are linearly upsampled x128 on the fly exactly like
+ * F.upsample(mode="linear") (models/neural_waveshaping.py:75); if f0_up != NULL the (B,N)
+ * already-upsampled F0 is used instead (public render_exciter(), :64-67).
+ */
+int nws_phase_carry(const float* f0, const float* f0_up, int B, int T, double* carry /* (B, N/32) */, void* stream);
+
+/*
+ * Fused harmonic exciter + waveshaper bank:
+ *   HarmonicOscillator.forward (models/modules/generators.py:58-66)
+ *   harmonic_mixer Conv1d 101->64 (models/neural_waveshaping.py:66)
+ *   NEWT.forward / FastNEWT.shaping_fn: FiLM -> shaper (LUT or sin-MLP) -> FiLM -> Conv1d 64->1
+ *   (models/modules/shaping.py:67-79, :136-151)
+ * film: (B, T, 256) frame-major FiLM parameters [g_idx | b_idx | g_norm | b_norm] (output of
+ *       nws_frame_mlps), linearly upsampled on the fly (shaping.py:69).
+ * phase_u: (101) the U[0,1) draws of generators.py:55; rand_phase: (101) the osc.rand_phase buffer (= tau);
+ *          the kernel forms shift = fl(fl(u * rand_phase) - pi) exactly like _create_phase_shift.
+ * exciter_out: optional (B, 64, N) materialised exciter (render_exciter()); newt_out: optional (B, N).
+ */
+int nws_exciter_newt(const NwsWeights* w, const float* f0, const float* f0_up, const double* carry,
+                     const float* phase_u, const float* rand_phase, const float* film, int B, int T,
+                     float sample_rate, float* exciter_out, float* newt_out, void* stream);
+
+/*
+ * Control encoder: GRU(2->128, h0=0) over T frames of control[:, 0:2]
+ * (models/neural_waveshaping.py:69-72, :24-25).  control: (B, C, T) with C >= 2.
+ * gru_out: (B, T, 128).
+ */
+int nws_control_gru(const NwsWeights* w, const float* control, int B, int C, int T, float* gru_out, void* stream);
+
+/*
+ * Frame-rate MLPs on the GRU output (one kernel):
+ *   emb  = proj(gru_out)                         models/neural_waveshaping.py:26
+ *   film = newt.mlp(emb)                         models/modules/shaping.py:68, dynamic.py:20-40
+ *   H    = h_generator(emb)                      models/neural_waveshaping.py:82
+ *   fir  = window * roll(irfft(H), 128)          models/modules/generators.py:22-27 (zero-phase FIR design)
+ * emb_out (B,128,T) [optional], film_out (B,T,256), H_out (B,T,129) [optional], fir_out (B,T,256).
+ * fir_design: (256, 132) constant matrix from nws_fir_design_matrix().
+ */
+int nws_frame_mlps(const NwsWeights* w, const float* gru_out, const float* fir_design, int B, int T,
+                   float* emb_out, float* film_out, float* H_out, float* fir_out, void* stream);
+
+/* D[n][k]: fir[n] = sum_k D[n][k] H[k]  (irfft + roll(128) + window folded), (256, 132) fp32, cols 129..131 = 0. */
+int nws_fir_design_matrix(const float* window /* (256) */, float* D_out, void* stream);
+
+/*
+ * Time-varying FIR noise (models/modules/generators.py:30-35): rectangular-window STFT of the
+ * shared noise vector (N-1 samples, reflect-padded by 128), per-frame 256-point CIRCULAR
+ * convolution with fir[b][t], overlap-add / overlap count.   out = add_in + noise_branch
+ * (the cat+sum of models/neural_waveshaping.py:85-86); add_in may be NULL.
+ */
+int nws_fir_noise(const float* fir /* (B,T,256) */, const float* noise /* (N-1) */, const float* add_in /* (B,N) */,
+                  int B, int T, float* out /* (B,N) */, void* stream);
+
+/* ---- learned reverb (models/modules/shaping.py:161-173): y = x + circconv_L(x, [0, ir])[:N], L = max(N, ir_len+1) ---- */
+typedef struct NwsReverbPlan {
+  int32_t L;   /* circular length */
+  int32_t N1;  /* column-DFT size  (L = N1 * N2) */
+  int32_t N2;  /* row-FFT size, power of two */
+  int32_t reserved;
+} NwsReverbPlan;
+
+int nws_reverb_plan(int N, int ir_len_plus1, NwsReverbPlan* plan /* host */);
+/* bytes of the constant tables (DFT matrices + twiddles) and of the IR spectrum for a plan */
+size_t nws_reverb_table_bytes(const NwsReverbPlan* plan);
+size_t nws_reverb_spectrum_bytes(const NwsReverbPlan* plan);
+size_t nws_reverb_workspace_bytes(const NwsReverbPlan* plan, int B);
+int nws_reverb_build_tables(const NwsReverbPlan* plan, void* tables, void* stream);
+/* spectrum of ir_ = [0, ir] zero-padded to L, in the engine's own (k1,k2) order */
+int nws_reverb_ir_spectrum(const NwsReverbPlan* plan, const void* tables, const float* ir, int ir_len,
+                           void* spectrum, void* workspace, size_t workspace_bytes, void* stream);
+int nws_reverb(const NwsReverbPlan* plan, const void* tables, const void* spectrum, const float* x /* (B,N) */,
+               int B, int N, float* y /* (B,N) */, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- FastNEWT table (models/modules/shaping.py:107-119): table[s][i] = shaper_s(linspace(min,max,size)[i]) ---- */
+int nws_shaper_table(const NwsWeights* w, int table_size, float table_min, float table_max, float* table_out, void* stream);
+
+/* exact shapers on an arbitrary (B,64,N) tensor (TrainableNonlinearity.forward, shaping.py:36-37) / LUT lookup (:136-151) */
+int nws_shaper_apply(const NwsWeights* w, const float* x, int64_t B, int64_t N, float* y, void* stream);
+
+/*
+ * Whole forward (models/neural_waveshaping.py:74-90) as one enqueue: phase carries -> GRU -> frame MLPs ->
+ * fused exciter+NEWT -> FIR noise (+sum) -> reverb.  All scratch lives in `workspace`
+ * (nws_forward_workspace_bytes).  phase_u (101) and noise (N-1) are the two RNG draws of forward().
+ */
+typedef struct NwsForwardAux {
+  const float* fir_design;       /* (256,132) */
+  const NwsReverbPlan* plan;     /* host */
+  const void* reverb_tables;
+  const void* reverb_spectrum;
+  const float* reverb_ir_unused; /* reserved */
+} NwsForwardAux;
+
+size_t nws_forward_workspace_bytes(const NwsReverbPlan* plan, int B, int T);
+int nws_forward(const NwsWeights* w, const NwsForwardAux* aux, const float* f0 /* (B,T) */, const float* control /* (B,C,T) */,
+                int B, int C, int T, float sample_rate, const float* phase_u, const float* rand_phase,
+                const float* noise, float* out /* (B,N) */, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Live profiling of nws_forward (bench.py's roofline leg): hipEvents are recorded on the launch stream around
+ * the stages selected by stage_mask (bit 0 phase carries, 1 GRU, 2 frame MLPs, 3 exciter+NEWT, 4 FIR noise,
+ * 5 reverb) for the next `slots` calls.  nws_profile_collect synchronises the events and writes
+ * ms_out[call][6] (-1 for unselected stages).
+ */
+#define NWS_N_STAGES 6
+int nws_profile_begin(int slots, unsigned stage_mask);
+int nws_profile_collect(float* ms_out /* host, slots*6 */, int* n_out /* host */);
+int nws_profile_end(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NWS_HIP_H */

@@ -1,0 +1,125 @@
+"""ctypes binding of libnws_hip.so (the C-ABI declared in include/nws_hip.h).
+
+There is NO fallback: if the library cannot be loaded every entry point raises, so a GPU run can
+never silently execute anything but the hand-written HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnws_hip.so")
+
+N_HARMONICS = 101
+N_SHAPERS = 64
+HIDDEN = 128
+HOP = 128
+FIR_LEN = 256
+N_BANDS = 129
+FILM_CH = 256
+FIR_DESIGN_COLS = 132
+
+_fp = C.c_void_p  # device pointers travel as integers
+
+
+class NwsWeights(C.Structure):
+    _fields_ = [
+        ("gru_w_ih", _fp), ("gru_w_hh", _fp), ("gru_b_ih", _fp), ("gru_b_hh", _fp),
+        ("proj_w", _fp), ("proj_b", _fp),
+        ("mixer_w", _fp), ("mixer_b", _fp),
+        ("newt_mlp_w", _fp * 4), ("newt_mlp_b", _fp * 4), ("newt_ln_g", _fp * 3), ("newt_ln_b", _fp * 3),
+        ("hgen_w", _fp * 4), ("hgen_b", _fp * 4), ("hgen_ln_g", _fp * 3), ("hgen_ln_b", _fp * 3),
+        ("shaper_in_scale", _fp),
+        ("shaper_w0", _fp), ("shaper_b0", _fp), ("shaper_w2", _fp), ("shaper_b2", _fp),
+        ("shaper_w4", _fp), ("shaper_b4", _fp), ("shaper_w6", _fp), ("shaper_b6", _fp),
+        ("lut", _fp), ("lut_size", C.c_int32), ("lut_min", C.c_float), ("lut_max", C.c_float),
+        ("newt_out_w", _fp), ("newt_out_b", _fp),
+        ("noise_window", _fp),
+    ]
+
+
+class NwsReverbPlan(C.Structure):
+    _fields_ = [("L", C.c_int32), ("N1", C.c_int32), ("N2", C.c_int32), ("reserved", C.c_int32)]
+
+
+class NwsForwardAux(C.Structure):
+    _fields_ = [("fir_design", _fp), ("plan", C.POINTER(NwsReverbPlan)), ("reverb_tables", _fp),
+                ("reverb_spectrum", _fp), ("reverb_ir_unused", _fp)]
+
+
+_PROTOTYPES = {
+    "nws_abi_version": (C.c_int, []),
+    "nws_error_string": (C.c_char_p, [C.c_int]),
+    "nws_selftest_mfma": (C.c_int, [_fp, _fp]),
+    "nws_sin": (C.c_int, [_fp, _fp, C.c_int64, _fp]),
+    "nws_phase_carry": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp, _fp]),
+    "nws_exciter_newt": (C.c_int, [C.POINTER(NwsWeights), _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_float,
+                                   _fp, _fp, _fp]),
+    "nws_control_gru": (C.c_int, [C.POINTER(NwsWeights), _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "nws_frame_mlps": (C.c_int, [C.POINTER(NwsWeights), _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp]),
+    "nws_fir_design_matrix": (C.c_int, [_fp, _fp, _fp]),
+    "nws_fir_noise": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp]),
+    "nws_reverb_plan": (C.c_int, [C.c_int, C.c_int, C.POINTER(NwsReverbPlan)]),
+    "nws_reverb_table_bytes": (C.c_size_t, [C.POINTER(NwsReverbPlan)]),
+    "nws_reverb_spectrum_bytes": (C.c_size_t, [C.POINTER(NwsReverbPlan)]),
+    "nws_reverb_workspace_bytes": (C.c_size_t, [C.POINTER(NwsReverbPlan), C.c_int]),
+    "nws_reverb_build_tables": (C.c_int, [C.POINTER(NwsReverbPlan), _fp, _fp]),
+    "nws_reverb_ir_spectrum": (C.c_int, [C.POINTER(NwsReverbPlan), _fp, _fp, C.c_int, _fp, _fp, C.c_size_t, _fp]),
+    "nws_reverb": (C.c_int, [C.POINTER(NwsReverbPlan), _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, C.c_size_t, _fp]),
+    "nws_shaper_table": (C.c_int, [C.POINTER(NwsWeights), C.c_int, C.c_float, C.c_float, _fp, _fp]),
+    "nws_shaper_apply": (C.c_int, [C.POINTER(NwsWeights), _fp, C.c_int64, C.c_int64, _fp, _fp]),
+    "nws_forward_workspace_bytes": (C.c_size_t, [C.POINTER(NwsReverbPlan), C.c_int, C.c_int]),
+    "nws_forward": (C.c_int, [C.POINTER(NwsWeights), C.POINTER(NwsForwardAux), _fp, _fp, C.c_int, C.c_int, C.c_int,
+                              C.c_float, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
+    "nws_profile_begin": (C.c_int, [C.c_int, C.c_uint]),
+    "nws_profile_collect": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "nws_profile_end": (C.c_int, []),
+}
+
+STAGE_NAMES = ("phase_carry", "control_gru", "frame_mlps", "exciter_newt", "fir_noise", "reverb")
+
+EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
+
+_lib = None
+
+
+class NwsError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it is missing - never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NwsError(
+                f"{LIB_PATH} not found: build the HIP kernels first "
+                "(python __graft_entry__.py build, or python neural-waveshaping-synthesis_amd/build.py). "
+                "There is no CPU/PyTorch fallback for the NEWT forward path.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().nws_error_string(rc)
+        raise NwsError(f"{what or 'nws call'} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32 (or fp64) CUDA tensor; None -> NULL."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,125 @@
+// Time-varying FIR filtered noise (FIRNoiseSynth.forward, models/modules/generators.py:30-35).
+//
+// The reference multiplies a rectangular-window STFT (n_fft 256, hop 128, center/reflect) of one
+// shared U[0,1) noise vector by the per-frame filter spectrum and inverts with istft(center=False):
+// per frame that is a 256-point CIRCULAR convolution of the noise frame with the frame's FIR
+// (SURVEY.md App. A.6), overlap-added and divided by the overlap count (1 for n < 128, else 2).
+//
+// Design: one wave produces one 128-sample output hop of one utterance.  Lanes
+// 0-31 compute the first half of frame t's circular convolution (4 outputs each), lanes 32-63 the
+// second half of frame t-1's; the two contributions meet with one half-swap.  Taps and noise are
+// staged in LDS per workgroup (4 consecutive hops share 5 frames).  Each lane keeps a sliding
+// 8-tap register window, so one ds_read_b128 of taps + one broadcast ds_read_b128 of noise feed
+// 16 FMAs.  The NEWT branch is added here (cat + sum(1), models/neural_waveshaping.py:85-86).
+#include "nws_common.h"
+
+namespace {
+
+constexpr int kL = NWS_FIR_LEN;  // 256
+constexpr int kHop = NWS_HOP;    // 128
+constexpr int kHopsPerBlock = 4;
+
+struct NoiseLds {
+  float taps[kHopsPerBlock + 1][kL];          // fir of frames t0-1 .. t0+3
+  float sig[(kHopsPerBlock + 1) * kHop + kHop];  // padded noise [128(t0-1), 128(t0+3)+256)
+};
+
+// reflect-padded noise (torch.stft center=True, pad_mode="reflect", pad 128 each side); len = N-1
+__device__ __forceinline__ float padded_noise(const float* __restrict__ noise, int len, int i) {
+  int s = i - kL / 2;
+  if (s < 0) s = -s;
+  if (s > len - 1) s = 2 * (len - 1) - s;
+  s = s < 0 ? 0 : s;
+  return noise[s];
+}
+
+__global__ __launch_bounds__(256) void fir_noise_kernel(const float* __restrict__ fir, const float* __restrict__ noise,
+                                                        const float* __restrict__ add_in, int T,
+                                                        float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) NoiseLds L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, q = lane & 31;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * kHopsPerBlock;
+  const int N = T * kHop;
+  const int len = N - 1;
+
+  for (int e = tid; e < (kHopsPerBlock + 1) * kL; e += 256) {
+    const int fr = e >> 8, k = e & 255;
+    const int t = t0 - 1 + fr;
+    L.taps[fr][k] = (t >= 0 && t < T) ? fir[((size_t)b * T + t) * kL + k] : 0.0f;
+  }
+  for (int e = tid; e < (kHopsPerBlock + 1) * kHop + kHop; e += 256) {
+    const int i = (t0 - 1) * kHop + e;  // index into the padded noise, valid range [0, N+255)
+    L.sig[e] = (i >= 0 && i < N + kL - 1) ? padded_noise(noise, len, i) : 0.0f;
+  }
+  __syncthreads();
+
+  const int t = t0 + wave;  // output hop
+  if (t >= T) return;
+  // half 0: frame t, outputs y_t[4q .. 4q+3];  half 1: frame t-1, outputs y_{t-1}[128+4q .. ]
+  const int slot = wave + 1 - half;            // frame slot in LDS (frame t0-1+slot)
+  const int nb = half * kHop + 4 * q;          // first output index inside the frame
+  const float* f = &L.sig[slot * kHop];        // frame samples f[0..255]
+  const float* h = L.taps[slot];
+
+  float y0 = 0.0f, y1 = 0.0f, y2 = 0.0f, y3 = 0.0f;
+  // y[nb+i] = sum_m f[m] h[(nb+i-m) & 255];  m = m0+k, window hi = h[nb-m0 .. +3], lo = h[nb-m0-4 .. -1]
+  float4 hi = *reinterpret_cast<const float4*>(&h[nb & 255]);
+#pragma unroll 4
+  for (int m0 = 0; m0 < kL; m0 += 4) {
+    const float4 lo = *reinterpret_cast<const float4*>(&h[(nb - m0 - 4) & 255]);
+    const float4 fv = *reinterpret_cast<const float4*>(&f[m0]);
+    // k = 0: h[nb+i-m0]
+    y0 = fmaf(fv.x, hi.x, y0);
+    y1 = fmaf(fv.x, hi.y, y1);
+    y2 = fmaf(fv.x, hi.z, y2);
+    y3 = fmaf(fv.x, hi.w, y3);
+    // k = 1: h[nb+i-m0-1]
+    y0 = fmaf(fv.y, lo.w, y0);
+    y1 = fmaf(fv.y, hi.x, y1);
+    y2 = fmaf(fv.y, hi.y, y2);
+    y3 = fmaf(fv.y, hi.z, y3);
+    // k = 2
+    y0 = fmaf(fv.z, lo.z, y0);
+    y1 = fmaf(fv.z, lo.w, y1);
+    y2 = fmaf(fv.z, hi.x, y2);
+    y3 = fmaf(fv.z, hi.y, y3);
+    // k = 3
+    y0 = fmaf(fv.w, lo.y, y0);
+    y1 = fmaf(fv.w, lo.z, y1);
+    y2 = fmaf(fv.w, lo.w, y2);
+    y3 = fmaf(fv.w, hi.x, y3);
+    hi = lo;
+  }
+  // overlap-add of the two frames covering this hop, divided by the overlap count
+  const float o0 = y0 + nws_swap_halves(y0);
+  const float o1 = y1 + nws_swap_halves(y1);
+  const float o2 = y2 + nws_swap_halves(y2);
+  const float o3 = y3 + nws_swap_halves(y3);
+  if (half == 0) {
+    const float inv = t == 0 ? 1.0f : 0.5f;
+    const size_t o = (size_t)b * N + (size_t)t * kHop + 4 * q;
+    float4 r = make_float4(o0 * inv, o1 * inv, o2 * inv, o3 * inv);
+    if (add_in != nullptr) {
+      const float4 a = *reinterpret_cast<const float4*>(&add_in[o]);
+      r.x = a.x + r.x;
+      r.y = a.y + r.y;
+      r.z = a.z + r.z;
+      r.w = a.w + r.w;
+    }
+    *reinterpret_cast<float4*>(&out[o]) = r;
+  }
+}
+
+}  // namespace
+
+extern "C" int nws_fir_noise(const float* fir, const float* noise, const float* add_in, int B, int T, float* out,
+                             void* stream) {
+  if (!fir || !noise || !out || B <= 0 || T <= 0) return NWS_ERR_BAD_ARG;
+  if (B > 65535) return NWS_ERR_UNSUPPORTED;
+  const dim3 grid((T + kHopsPerBlock - 1) / kHopsPerBlock, B);
+  fir_noise_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(fir, noise, add_in, T, out);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}

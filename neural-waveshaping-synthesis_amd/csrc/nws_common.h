@@ -1,0 +1,90 @@
+// Shared device helpers for the gfx950 NEWT kernels.
+//
+// The library is compiled with -ffp-contract=off: every a*b+c written as plain arithmetic is two
+// IEEE roundings (the reference's CPU chains for the oscillator phase and the LUT index must be
+// reproduced rounding for rounding); fused multiply-adds are spelled
+// fmaf() wherever they are wanted.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nws_hip.h"
+
+#define NWS_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define NWS_CHECK_LAUNCH()                      \
+  do {                                          \
+    hipError_t e__ = hipGetLastError();         \
+    if (e__ != hipSuccess) return (int)e__;     \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// F.upsample(x, T*128, mode="linear") of the reference (align_corners=False), bit-exact with
+// ATen's CPU kernel as probed in the build container:  out = fmaf(1-l, x[i0], fl(l*x[i1])).
+// (models/neural_waveshaping.py:75, models/modules/shaping.py:69.)
+// ---------------------------------------------------------------------------------------------
+struct NwsLerp {
+  int i0, i1;
+  float w0, w1;
+};
+
+__device__ __forceinline__ NwsLerp nws_lerp_coeff(int n, int T) {
+  // scale = T/N = 1/128 exactly; (n + 0.5)/128 - 0.5 is exact in fp32 for n < 2^23
+  float src = ((float)n + 0.5f) * (1.0f / (float)NWS_HOP) - 0.5f;
+  src = src < 0.0f ? 0.0f : src;
+  const int i0 = (int)src;  // src >= 0: trunc == floor
+  NwsLerp c;
+  c.i0 = i0;
+  c.i1 = i0 + 1 < T ? i0 + 1 : T - 1;
+  c.w1 = src - (float)i0;
+  c.w0 = 1.0f - c.w1;
+  return c;
+}
+
+__device__ __forceinline__ float nws_lerp(float a, float b, float w0, float w1) { return fmaf(w0, a, w1 * b); }
+
+// ---------------------------------------------------------------------------------------------
+// sinf with full-range argument reduction.  |error| <~ 1.5e-7 absolute for |x| <= 6e6 (two-constant
+// Cody-Waite in fp32 with FMA: the product q*P1 is exact inside the fma), fp64 reduction above.
+// The reference's torch.sin (Sleef u10) is itself within 1 ulp of the true value; the oscillator
+// needs ~1e-6 (SURVEY.md §7 hard part 2).  Fast intrinsics (__sinf / v_sin_f32) are NOT used.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float nws_sin_poly(float r) {
+  const float z = r * r;
+  float p = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+  p = fmaf(p, z, -1.6666654611e-1f);
+  return fmaf(p * z, r, r);
+}
+
+__device__ __forceinline__ float nws_cos_poly(float r) {
+  const float z = r * r;
+  float p = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+  p = fmaf(p, z, 4.166664568298827e-2f);
+  return fmaf(p, z * z, fmaf(-0.5f, z, 1.0f));
+}
+
+__device__ __noinline__ float nws_sinf_huge(float x) {
+  // rare path: |x| > 6e6 (sine arguments this large are already phase-quantised in fp32)
+  return (float)sin((double)x);
+}
+
+__device__ __forceinline__ float nws_sinf(float x) {
+  if (__builtin_expect(fabsf(x) > 6.0e6f, 0)) return nws_sinf_huge(x);
+  const float fq = rintf(x * 0.6366197723675814f);
+  float r = fmaf(fq, -1.5707963705062866f, x);
+  r = fmaf(fq, 4.371138828673793e-08f, r);
+  const int q = (int)fq;
+  const float s = nws_sin_poly(r);
+  const float c = nws_cos_poly(r);
+  float v = (q & 1) ? c : s;
+  return (q & 2) ? -v : v;
+}
+
+// 32-lane-half exchange (lane l <-> lane l^32)
+__device__ __forceinline__ float nws_swap_halves(float v) { return __shfl_xor(v, 32, 64); }
+
+__device__ __forceinline__ float nws_leaky_relu(float x) { return x > 0.0f ? x : 0.01f * x; }

@@ -1,0 +1,353 @@
+// Learned reverb: y = x + circconv_L(x, [0, ir])[:N],  L = max(N, len(ir)+1)
+// (Reverb.forward, models/modules/shaping.py:161-173; circular, NOT zero-padded to 2N: SURVEY App. D.4).
+//
+// Design: a hand-written four-step FFT of length L = N1 * N2 (N2 = largest power of
+// two dividing L, <= 1024; L = 64000 -> 125 x 512, L = 32000 -> 125 x 256):
+//   (1) column DFT over n1 (size N1, any integer) as a dense fp32 MFMA contraction against a cached
+//       DFT matrix  -- exact-fp32 v_mfma_f32_32x32x2_f32, the complex product written as a real
+//       [2N1 x 2N1] matrix so that one MFMA step consumes (re, im) of one input row;
+//   (2) twiddle + radix-2 Stockham row FFT of size N2 in LDS, pointwise product with the cached IR
+//       spectrum, inverse row FFT, conjugate twiddle, 1/L  -- one workgroup per row, one kernel;
+//   (3) inverse column DFT (same MFMA kernel, conjugate matrix) + dry signal, only for rows < N/N2.
+// Two utterances are packed into one complex transform (z = x_a + i x_b; the IR is real, so
+// Re/Im of the circular convolution are the two results): no Hermitian untangling anywhere.
+// The spectrum is kept in the transform's own (k1,k2) order, which a pointwise product does not care about.
+#include "nws_common.h"
+
+namespace {
+
+__device__ __forceinline__ int frag_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+struct PlanDev {
+  int L, N1, N2, NP, M2;
+};
+
+__host__ __device__ inline int round_up32(int v) { return (v + 31) & ~31; }
+
+inline PlanDev plan_dev(const NwsReverbPlan* p) {
+  PlanDev d;
+  d.L = p->L;
+  d.N1 = p->N1;
+  d.N2 = p->N2;
+  d.NP = round_up32(p->N1);
+  d.M2 = 2 * d.NP;
+  return d;
+}
+
+// table offsets (in floats)
+inline size_t off_afwd(const PlanDev&) { return 0; }
+inline size_t off_ainv(const PlanDev& d) { return (size_t)d.N1 * 2 * d.M2; }
+inline size_t off_tw(const PlanDev& d) { return 2 * (size_t)d.N1 * 2 * d.M2; }
+inline size_t off_rowtw(const PlanDev& d) { return off_tw(d) + 2 * (size_t)d.L; }
+inline size_t table_floats(const PlanDev& d) { return off_rowtw(d) + (size_t)d.N2; }
+
+// A[(step*2 + h)*M2 + row]: the real form of the (inverse) DFT matrix, see header comment.
+//   forward  F = cos - i sin :  real row k1: [cos, +sin]   imag row k1: [-sin, cos]
+//   inverse  F = cos + i sin :  real row n1: [cos, -sin]   imag row n1: [+sin, cos]
+__global__ void build_dft_matrix_kernel(float* __restrict__ A, int N1, int NP, int M2, int inverse) {
+  const size_t total = (size_t)N1 * 2 * M2;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(e % M2);
+    const int h = (int)((e / M2) & 1);
+    const int step = (int)(e / (2 * (size_t)M2));
+    const int is_im = row >= NP;
+    const int idx = is_im ? row - NP : row;
+    float v = 0.0f;
+    if (idx < N1) {
+      const long long m = ((long long)idx * step) % N1;
+      double s, c;
+      sincospi(2.0 * (double)m / (double)N1, &s, &c);
+      if (inverse) s = -s;
+      // forward: real row [c, s], imag row [-s, c]
+      v = (float)(is_im ? (h == 0 ? -s : c) : (h == 0 ? c : s));
+    }
+    A[e] = v;
+  }
+}
+
+__global__ void build_twiddle_kernel(float2* __restrict__ tw, float2* __restrict__ rowtw, int L, int N1, int N2) {
+  const size_t total = (size_t)L + N2 / 2;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    double s, c;
+    if (e < (size_t)L) {
+      const int k1 = (int)(e / N2), n2 = (int)(e % N2);
+      const long long m = ((long long)k1 * n2) % L;
+      sincospi(2.0 * (double)m / (double)L, &s, &c);
+      tw[e] = make_float2((float)c, (float)-s);
+    } else {
+      const int m = (int)(e - L);
+      sincospi(2.0 * (double)m / (double)N2, &s, &c);
+      rowtw[m] = make_float2((float)c, (float)-s);
+    }
+  }
+}
+
+// ---- column DFT (forward): real utterances -> planar U[p][k1][n2] ----
+__global__ __launch_bounds__(256) void col_fwd_kernel(const float* __restrict__ A, PlanDev d, const float* __restrict__ x,
+                                                      int B, int N, long long x_stride, float* __restrict__ Ure,
+                                                      float* __restrict__ Uim) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int mt = blockIdx.y * 4 + wave;
+  if (mt >= d.M2 / 32) return;
+  const int p = blockIdx.z;
+  const int c = blockIdx.x * 32 + col;
+  const int utt = 2 * p + half;
+  const float* xs = utt < B ? x + (size_t)utt * x_stride : nullptr;
+  const int rows_in = (N + d.N2 - 1) / d.N2 < d.N1 ? (N + d.N2 - 1) / d.N2 : d.N1;
+  const float* a_ptr = A + (size_t)half * d.M2 + 32 * mt + col;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll 4
+  for (int n1 = 0; n1 < rows_in; ++n1) {
+    const long long n = (long long)d.N2 * n1 + c;
+    const float bv = (xs != nullptr && n < N) ? xs[n] : 0.0f;
+    const float av = a_ptr[(size_t)n1 * 2 * d.M2];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = 32 * mt + frag_row(r, half);
+    const int is_im = row >= d.NP;
+    const int k1 = is_im ? row - d.NP : row;
+    if (k1 < d.N1) {
+      float* dst = is_im ? Uim : Ure;
+      dst[((size_t)p * d.N1 + k1) * d.N2 + c] = acc[r];
+    }
+  }
+}
+
+// ---- inverse column DFT + dry signal: planar U'[p][k1][n2] -> y (B,N) ----
+__global__ __launch_bounds__(256) void col_inv_kernel(const float* __restrict__ A, PlanDev d,
+                                                      const float* __restrict__ Ure, const float* __restrict__ Uim,
+                                                      const float* __restrict__ x, int B, int N, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int rows_out = (N + d.N2 - 1) / d.N2;
+  const int nt = (rows_out + 31) / 32;
+  const int idx = blockIdx.y * 4 + wave;
+  if (idx >= 2 * nt) return;
+  const int mt = idx < nt ? idx : d.NP / 32 + (idx - nt);
+  const int p = blockIdx.z;
+  const int c = blockIdx.x * 32 + col;
+  const float* src = (half == 0 ? Ure : Uim) + (size_t)p * d.N1 * d.N2 + c;
+  const float* a_ptr = A + (size_t)half * d.M2 + 32 * mt + col;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll 4
+  for (int k1 = 0; k1 < d.N1; ++k1) {
+    const float bv = src[(size_t)k1 * d.N2];
+    const float av = a_ptr[(size_t)k1 * 2 * d.M2];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = 32 * mt + frag_row(r, half);
+    const int is_im = row >= d.NP;
+    const int n1 = is_im ? row - d.NP : row;
+    const int utt = 2 * p + is_im;
+    const long long n = (long long)d.N2 * n1 + c;
+    if (n1 < d.N1 && utt < B && n < N) {
+      const size_t o = (size_t)utt * N + n;
+      y[o] = x[o] + acc[r];
+    }
+  }
+}
+
+// ---- row pass: twiddle, FFT_N2, x IR spectrum, IFFT_N2, conj twiddle, 1/L (in place on planar U) ----
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
+
+template <bool INVERSE>
+__device__ __forceinline__ float2* stockham(float2* x, float2* y, const float2* __restrict__ rowtw, int N2, int tid,
+                                            int nthreads) {
+  const int t = N2 >> 1;
+  for (int p = 1; p < N2; p <<= 1) {
+    const int tw_step = t / p;  // N2 / (2p)
+    for (int i = tid; i < t; i += nthreads) {
+      const int k = i & (p - 1);
+      const int j = ((i - k) << 1) + k;
+      float2 w = rowtw[k * tw_step];
+      if (INVERSE) w.y = -w.y;
+      const float2 u0 = x[i];
+      const float2 u1 = cmul(w, x[i + t]);
+      y[j] = make_float2(u0.x + u1.x, u0.y + u1.y);
+      y[j + p] = make_float2(u0.x - u1.x, u0.y - u1.y);
+    }
+    __syncthreads();
+    float2* tmp = x;
+    x = y;
+    y = tmp;
+  }
+  return x;
+}
+
+template <bool SPECTRUM_ONLY>
+__global__ __launch_bounds__(256) void row_kernel(PlanDev d, float* __restrict__ Ure, float* __restrict__ Uim,
+                                                  const float2* __restrict__ tw, const float2* __restrict__ rowtw_g,
+                                                  const float* __restrict__ Hre, const float* __restrict__ Him,
+                                                  float* __restrict__ Sre, float* __restrict__ Sim) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float2* buf0 = reinterpret_cast<float2*>(smem_raw);
+  float2* buf1 = buf0 + d.N2;
+  float2* rowtw = buf1 + d.N2;  // N2/2 entries
+  const int tid = threadIdx.x;
+  const int k1 = blockIdx.x;
+  const int p = blockIdx.y;
+  const size_t base = ((size_t)p * d.N1 + k1) * d.N2;
+  const size_t hbase = (size_t)k1 * d.N2;
+  for (int i = tid; i < d.N2 / 2; i += 256) rowtw[i] = rowtw_g[i];
+  for (int i = tid; i < d.N2; i += 256) {
+    const float2 z = make_float2(Ure[base + i], Uim[base + i]);
+    buf0[i] = cmul(z, tw[hbase + i]);
+  }
+  __syncthreads();
+  float2* cur = stockham<false>(buf0, buf1, rowtw, d.N2, tid, 256);
+  if (SPECTRUM_ONLY) {
+    for (int i = tid; i < d.N2; i += 256) {
+      Sre[hbase + i] = cur[i].x;
+      Sim[hbase + i] = cur[i].y;
+    }
+    return;
+  }
+  float2* other = cur == buf0 ? buf1 : buf0;
+  for (int i = tid; i < d.N2; i += 256) cur[i] = cmul(cur[i], make_float2(Hre[hbase + i], Him[hbase + i]));
+  __syncthreads();
+  cur = stockham<true>(cur, other, rowtw, d.N2, tid, 256);
+  const float inv_l = 1.0f / (float)d.L;
+  for (int i = tid; i < d.N2; i += 256) {
+    float2 t = tw[hbase + i];
+    t.y = -t.y;
+    const float2 z = cmul(cur[i], t);
+    Ure[base + i] = z.x * inv_l;
+    Uim[base + i] = z.y * inv_l;
+  }
+}
+
+// ir_ = [0, ir] (models/modules/shaping.py:162)
+__global__ void build_ir_kernel(const float* __restrict__ ir, int ir_len, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= ir_len) out[i] = i == 0 ? 0.0f : ir[i - 1];
+}
+
+bool plan_ok(const NwsReverbPlan* p) {
+  return p && p->L > 0 && p->N1 > 0 && p->N2 >= 32 && p->N2 <= 1024 && (p->N2 & (p->N2 - 1)) == 0 &&
+         (long long)p->N1 * p->N2 == p->L;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nws_reverb_plan(int N, int ir_len_plus1, NwsReverbPlan* plan) {
+  if (!plan || N <= 0 || ir_len_plus1 <= 0) return NWS_ERR_BAD_ARG;
+  const int L = N > ir_len_plus1 ? N : ir_len_plus1;
+  int n2 = 1;
+  while ((L % (n2 * 2)) == 0 && n2 < 1024) n2 *= 2;
+  if (n2 < 32) return NWS_ERR_UNSUPPORTED;
+  const int n1 = L / n2;
+  if (n1 > 8192) return NWS_ERR_UNSUPPORTED;
+  plan->L = L;
+  plan->N1 = n1;
+  plan->N2 = n2;
+  plan->reserved = 0;
+  return NWS_OK;
+}
+
+size_t nws_reverb_table_bytes(const NwsReverbPlan* plan) {
+  if (!plan_ok(plan)) return 0;
+  return table_floats(plan_dev(plan)) * sizeof(float);
+}
+
+size_t nws_reverb_spectrum_bytes(const NwsReverbPlan* plan) {
+  if (!plan_ok(plan)) return 0;
+  return 2 * (size_t)plan->L * sizeof(float);
+}
+
+size_t nws_reverb_workspace_bytes(const NwsReverbPlan* plan, int B) {
+  if (!plan_ok(plan) || B <= 0) return 0;
+  const size_t pairs = (size_t)(B + 1) / 2;
+  // planar U (2 * pairs * L) ; the IR-spectrum build needs 3 L (ir_, Ure, Uim)
+  const size_t f = 2 * pairs * (size_t)plan->L;
+  const size_t g = 3 * (size_t)plan->L;
+  return (f > g ? f : g) * sizeof(float);
+}
+
+int nws_reverb_build_tables(const NwsReverbPlan* plan, void* tables, void* stream) {
+  if (!plan_ok(plan) || !tables) return NWS_ERR_BAD_ARG;
+  const PlanDev d = plan_dev(plan);
+  float* t = static_cast<float*>(tables);
+  hipStream_t st = (hipStream_t)stream;
+  build_dft_matrix_kernel<<<1024, 256, 0, st>>>(t + off_afwd(d), d.N1, d.NP, d.M2, 0);
+  NWS_CHECK_LAUNCH();
+  build_dft_matrix_kernel<<<1024, 256, 0, st>>>(t + off_ainv(d), d.N1, d.NP, d.M2, 1);
+  NWS_CHECK_LAUNCH();
+  build_twiddle_kernel<<<512, 256, 0, st>>>(reinterpret_cast<float2*>(t + off_tw(d)),
+                                            reinterpret_cast<float2*>(t + off_rowtw(d)), d.L, d.N1, d.N2);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+static size_t row_lds_bytes(const PlanDev& d) { return (size_t)(2 * d.N2 + d.N2 / 2) * sizeof(float2); }
+
+int nws_reverb_ir_spectrum(const NwsReverbPlan* plan, const void* tables, const float* ir, int ir_len, void* spectrum,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  if (!plan_ok(plan) || !tables || !ir || !spectrum || !workspace || ir_len <= 0) return NWS_ERR_BAD_ARG;
+  if (ir_len + 1 > plan->L) return NWS_ERR_BAD_ARG;
+  if (workspace_bytes < nws_reverb_workspace_bytes(plan, 1)) return NWS_ERR_WORKSPACE;
+  const PlanDev d = plan_dev(plan);
+  const float* t = static_cast<const float*>(tables);
+  hipStream_t st = (hipStream_t)stream;
+  float* irp = static_cast<float*>(workspace);
+  float* Ure = irp + d.L;
+  float* Uim = Ure + d.L;
+  float* Sre = static_cast<float*>(spectrum);
+  float* Sim = Sre + d.L;
+  build_ir_kernel<<<(ir_len + 1 + 255) / 256, 256, 0, st>>>(ir, ir_len, irp);
+  NWS_CHECK_LAUNCH();
+  const dim3 g1(d.N2 / 32, (d.M2 / 32 + 3) / 4, 1);
+  col_fwd_kernel<<<g1, 256, 0, st>>>(t + off_afwd(d), d, irp, 1, ir_len + 1, 0, Ure, Uim);
+  NWS_CHECK_LAUNCH();
+  const dim3 g2(d.N1, 1);
+  row_kernel<true><<<g2, 256, row_lds_bytes(d), st>>>(d, Ure, Uim, reinterpret_cast<const float2*>(t + off_tw(d)),
+                                                      reinterpret_cast<const float2*>(t + off_rowtw(d)), nullptr,
+                                                      nullptr, Sre, Sim);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+int nws_reverb(const NwsReverbPlan* plan, const void* tables, const void* spectrum, const float* x, int B, int N,
+               float* y, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!plan_ok(plan) || !tables || !spectrum || !x || !y || !workspace || B <= 0 || N <= 0) return NWS_ERR_BAD_ARG;
+  if (N > plan->L) return NWS_ERR_BAD_ARG;
+  if (workspace_bytes < nws_reverb_workspace_bytes(plan, B)) return NWS_ERR_WORKSPACE;
+  const PlanDev d = plan_dev(plan);
+  const int pairs = (B + 1) / 2;
+  if (pairs > 65535) return NWS_ERR_UNSUPPORTED;
+  const float* t = static_cast<const float*>(tables);
+  hipStream_t st = (hipStream_t)stream;
+  float* Ure = static_cast<float*>(workspace);
+  float* Uim = Ure + (size_t)pairs * d.L;
+  const float* Sre = static_cast<const float*>(spectrum);
+  const float* Sim = Sre + d.L;
+
+  const dim3 g1(d.N2 / 32, (d.M2 / 32 + 3) / 4, pairs);
+  col_fwd_kernel<<<g1, 256, 0, st>>>(t + off_afwd(d), d, x, B, N, (long long)N, Ure, Uim);
+  NWS_CHECK_LAUNCH();
+  const dim3 g2(d.N1, pairs);
+  row_kernel<false><<<g2, 256, row_lds_bytes(d), st>>>(d, Ure, Uim, reinterpret_cast<const float2*>(t + off_tw(d)),
+                                                       reinterpret_cast<const float2*>(t + off_rowtw(d)), Sre, Sim,
+                                                       nullptr, nullptr);
+  NWS_CHECK_LAUNCH();
+  const int rows_out = (N + d.N2 - 1) / d.N2;
+  const int nt = (rows_out + 31) / 32;
+  const dim3 g3(d.N2 / 32, (2 * nt + 3) / 4, pairs);
+  col_inv_kernel<<<g3, 256, 0, st>>>(t + off_ainv(d), d, Ure, Uim, x, B, N, y);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+}  // extern "C"

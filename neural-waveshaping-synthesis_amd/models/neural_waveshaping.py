@@ -1,0 +1,158 @@
+"""``NeuralWaveshaping`` - the drop-in module surface of the MI355X NEWT engine.
+
+Mirrors the reference's ``NeuralWaveshaping`` (models/neural_waveshaping.py:29-90): same constructor
+(gin-configurable), sub-module / attribute names, state-dict keys, ``forward(f0, control)``,
+``render_exciter`` and ``get_embedding``.  ``forward`` is ONE call into the C-ABI (``nws_forward``),
+which enqueues the hand-written HIP kernels on torch's current stream.  Training hooks of the
+reference (:92-165) are out of scope.
+
+Hidden inputs, exactly like the reference: every forward draws ``rand_like(osc.rand_phase)`` and then
+``rand(control_hop*T - 1)`` from the default generator of the module's device, in that order
+(generators.py:55, :30).  For parity testing the two draws can be injected with the keyword-only
+arguments ``phase_u`` and ``noise``.
+"""
+import contextlib
+import os
+import sys
+import types
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .. import ginlite as gin
+from ..engine import Engine, _req
+from .modules.dynamic import TimeDistributedMLP
+from .modules.generators import FIRNoiseSynth, HarmonicOscillator
+from .modules.shaping import NEWT, Reverb
+from .modules._fused import fused_only
+
+gin.external_configurable(nn.GRU, module="torch.nn")
+gin.external_configurable(nn.Conv1d, module="torch.nn")
+
+_DEFAULT_GIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gin", "models", "newt.gin")
+
+
+@gin.configurable
+class ControlModule(nn.Module):
+    """GRU(control_size -> hidden) + Conv1d(hidden -> embedding, 1) (reference :17-26)."""
+
+    def __init__(self, control_size: int, hidden_size: int, embedding_size: int):
+        super().__init__()
+        self.gru = nn.GRU(control_size, hidden_size, batch_first=True)
+        self.proj = nn.Conv1d(hidden_size, embedding_size, 1)
+
+    def forward(self, x):
+        raise fused_only("ControlModule", "NeuralWaveshaping.get_embedding / forward (control_gru_kernel)")
+
+
+@gin.configurable
+class NeuralWaveshaping(nn.Module):
+    def __init__(self, n_waveshapers: int, control_hop: int, sample_rate: float = 16000,
+                 learning_rate: float = 1e-3, lr_decay: float = 0.9, lr_decay_interval: int = 10000,
+                 log_audio: bool = False):
+        super().__init__()
+        self.hparams = dict(n_waveshapers=n_waveshapers, control_hop=control_hop, sample_rate=sample_rate,
+                            learning_rate=learning_rate, lr_decay=lr_decay, lr_decay_interval=lr_decay_interval,
+                            log_audio=log_audio)
+        self.learning_rate = learning_rate
+        self.lr_decay = lr_decay
+        self.lr_decay_interval = lr_decay_interval
+        self.control_hop = control_hop
+        self.log_audio = log_audio
+        self.sample_rate = sample_rate
+
+        self.embedding = ControlModule()
+        self.osc = HarmonicOscillator()
+        self.harmonic_mixer = nn.Conv1d(self.osc.n_harmonics, n_waveshapers, 1)
+        self.newt = NEWT()
+        with gin.config_scope("noise_synth"):
+            self.h_generator = TimeDistributedMLP()
+            self.noise_synth = FIRNoiseSynth()
+        self.reverb = Reverb()
+        if control_hop != _lib.HOP:
+            raise RuntimeError("kernels are specialised for control_hop = 128 (gin/models/newt.gin)")
+        object.__setattr__(self, "_engine", Engine(self))
+
+    # ---- cache hygiene: any re-homing / re-loading of parameters drops the pointer cache ----------
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._engine.invalidate()
+        return out
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self._engine.invalidate()
+        return out
+
+    def __setattr__(self, name, value):
+        super().__setattr__(name, value)
+        if name == "newt" and "_engine" in self.__dict__:
+            self._engine.invalidate()
+
+    def invalidate_cache(self):
+        """Call after mutating parameters in place (the engine caches raw device pointers)."""
+        self._engine.invalidate()
+
+    # ---- public surface ----------------------------------------------------------------------------
+    def render_exciter(self, f0):
+        """(B, 1, N) upsampled F0 in Hz -> (B, n_waveshapers, N) exciter (reference :64-67)."""
+        f0 = _req(f0, "f0")
+        if f0.dim() != 3 or f0.shape[1] != 1 or f0.shape[-1] % _lib.HOP:
+            raise RuntimeError(f"expected (B, 1, 128*T), got {tuple(f0.shape)}")
+        eng = self._engine
+        f0_up = f0[:, 0]
+        u = torch.rand_like(self.osc.rand_phase).reshape(-1)
+        carry = eng.phase_carry(f0_up=f0_up)
+        exc, _ = eng.exciter_newt(None, f0_up, carry, u, None, want_exciter=True, want_newt=False)
+        return exc
+
+    def get_embedding(self, control):
+        """(B, C>=2, T) normalised control -> (B, 128, T) embedding (reference :69-72)."""
+        control = _req(control, "control")
+        gru = self._engine.control_gru(control)
+        emb, _, _, _ = self._engine.frame_mlps(gru, want_emb=True)
+        return emb
+
+    def forward(self, f0, control, *, phase_u=None, noise=None):
+        f0 = _req(f0, "f0")
+        control = _req(control, "control")
+        if f0.dim() != 3 or f0.shape[1] != 1:
+            raise RuntimeError(f"f0: expected (B, 1, T), got {tuple(f0.shape)}")
+        if control.dim() != 3 or control.shape[1] < 2:
+            raise RuntimeError(f"control: expected (B, C>=2, T), got {tuple(control.shape)}")
+        B, _, T = f0.shape
+        if control.shape[0] != B or control.shape[2] != T:
+            raise RuntimeError(f"f0 {tuple(f0.shape)} and control {tuple(control.shape)} disagree on batch / frames")
+        if T < 2:
+            raise RuntimeError("need at least 2 control frames (reflect padding of the noise STFT, generators.py:31)")
+        dev = f0.device
+        if phase_u is None:
+            phase_u = torch.rand_like(self.osc.rand_phase)          # RNG draw #1 (generators.py:55)
+        phase_u = _req(phase_u.reshape(-1), "phase_u", _lib.N_HARMONICS)
+        if noise is None:
+            noise = torch.rand(self.control_hop * T - 1, device=dev)  # RNG draw #2 (generators.py:30)
+        noise = _req(noise, "noise", self.control_hop * T - 1)
+        return self._engine.forward(f0, control, phase_u, noise)
+
+    # ---- checkpoints (Lightning .ckpt as shipped by the reference, or flat .npz fixtures) -------------
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None, strict=True, **kwargs):
+        from ..checkpoint import read_checkpoint
+
+        ensure_default_config()
+        state, hparams = read_checkpoint(checkpoint_path)
+        hparams.update(kwargs)
+        model = cls(**hparams)
+        model.load_state_dict({k: torch.as_tensor(v) for k, v in state.items()}, strict=strict)
+        if map_location is not None:
+            model = model.to(map_location)
+        return model
+
+
+def ensure_default_config():
+    """Parse the packaged newt.gin if the caller has not parsed a model gin file yet."""
+    try:
+        gin.query_parameter("NeuralWaveshaping.control_hop")
+    except ValueError:
+        gin.parse_config_file(_DEFAULT_GIN)

@@ -1,0 +1,67 @@
+"""Multi-GPU rendering: a batch of independent utterances sharded over ranks (one process per GPU,
+torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests).
+
+The reference has no collective code; forward() is independent across the batch
+dimension except that the two RNG draws are shared by all rows (generators.py:30,55), so
+  * rank r renders rows [r*B/W, (r+1)*B/W) with the SAME phase_u / noise on every rank
+    (drawn once on rank 0 and broadcast: 101 + N-1 floats), and
+  * the rendered waveforms are all-gathered (the one exchange step BASELINE.json's north_star names).
+`render_fn(f0, control, phase_u, noise) -> (b, N)` is the single-device forward; it is a parameter so the
+CPU tests can drive this file with the oracle instead of the HIP engine.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(batch: int, world: int, rank: int):
+    """Contiguous, balanced split: the first (batch % world) ranks get one extra row."""
+    base, extra = divmod(batch, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shared_draws(n_harmonics: int, n_noise: int, device, group=None, src: int = 0):
+    """The two hidden draws of forward(), identical on every rank (drawn on `src`, broadcast)."""
+    buf = torch.empty(n_harmonics + n_noise, dtype=torch.float32, device=device)
+    if not dist.is_initialized() or dist.get_rank(group) == src:
+        buf[:n_harmonics] = torch.rand(n_harmonics, device=device)   # draw #1 (generators.py:55)
+        buf[n_harmonics:] = torch.rand(n_noise, device=device)       # draw #2 (generators.py:30)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(buf, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+    return buf[:n_harmonics], buf[n_harmonics:]
+
+
+def render_sharded(render_fn, f0, control, group=None, phase_u=None, noise=None, gather: bool = True,
+                   out: torch.Tensor | None = None, async_op: bool = False):
+    """f0 (B,1,T), control (B,C,T) are the FULL batch on every rank (or pre-sharded with gather-only use).
+
+    Returns the full (B, N) result on every rank (gather=True) or the local shard.  With
+    ``async_op=True`` returns (out, work) so the all-gather of this step overlaps the next render.
+    Equal shards use one all_gather_into_tensor; ragged shards fall back to all_gather of padded rows.
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    B, _, T = f0.shape
+    hop_n = None
+    lo, hi = shard_bounds(B, world, rank)
+    if phase_u is None or noise is None:
+        raise ValueError("render_sharded needs the shared draws (see shared_draws())")
+    local = render_fn(f0[lo:hi].contiguous(), control[lo:hi].contiguous(), phase_u, noise)
+    if not gather or world == 1:
+        return (local, None) if async_op else local
+    N = local.shape[-1]
+    if B % world == 0:
+        if out is None:
+            out = torch.empty((B, N), dtype=local.dtype, device=local.device)
+        work = dist.all_gather_into_tensor(out, local.contiguous(), group=group, async_op=async_op)
+        return (out, work) if async_op else out
+    rows = -(-B // world)
+    pad = torch.zeros((rows, N), dtype=local.dtype, device=local.device)
+    pad[: hi - lo] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    full = torch.cat([parts[r][: shard_bounds(B, world, r)[1] - shard_bounds(B, world, r)[0]] for r in range(world)], 0)
+    del hop_n
+    return (full, None) if async_op else full

@@ -1,0 +1,11 @@
+"""Importable alias of the package directory `neural-waveshaping-synthesis_amd` (hyphens cannot be
+written in an import statement):  ``import nws_amd as nws``."""
+import importlib
+import os
+import sys
+
+_root = os.path.dirname(os.path.abspath(__file__))
+if _root not in sys.path:
+    sys.path.insert(0, _root)
+_pkg = importlib.import_module("neural-waveshaping-synthesis_amd")
+sys.modules[__name__] = _pkg
