@@ -79,6 +79,7 @@ typedef struct NwsWeights {
   const float* shaper_b6; /* (64) */
   /* FastNEWT.lookup_table (models/modules/shaping.py:103-105); NULL selects the exact shapers */
   const float* lut;       /* (64, lut_size) */
+  const float* lut_pairs; /* optional (64, lut_size, 2) from nws_lut_pairs(): {T[i], T[i+1]-T[i]}; NULL -> two gathers */
   int32_t lut_size;       /* 4096 */
   float lut_min;          /* -3 */
   float lut_max;          /* +3 */
@@ -178,6 +179,9 @@ int nws_reverb(const NwsReverbPlan* plan, const void* tables, const void* spectr
 /* ---- FastNEWT table (models/modules/shaping.py:107-119): table[s][i] = shaper_s(linspace(min,max,size)[i]) ---- */
 int nws_shaper_table(const NwsWeights* w, int table_size, float table_min, float table_max, float* table_out, void* stream);
 
+/* derived gather-friendly form of a FastNEWT table: pairs[s][i] = {table[s][i], fl(table[s][min(i+1,size-1)] - table[s][i])} */
+int nws_lut_pairs(const float* table /* (64, size) */, int table_size, float* pairs_out /* (64, size, 2) */, void* stream);
+
 /* exact shapers on an arbitrary (B,64,N) tensor (TrainableNonlinearity.forward, shaping.py:36-37) / LUT lookup (:136-151) */
 int nws_shaper_apply(const NwsWeights* w, const float* x, int64_t B, int64_t N, float* y, void* stream);
 
@@ -198,6 +202,16 @@ size_t nws_forward_workspace_bytes(const NwsReverbPlan* plan, int B, int T);
 int nws_forward(const NwsWeights* w, const NwsForwardAux* aux, const float* f0 /* (B,T) */, const float* control /* (B,C,T) */,
                 int B, int C, int T, float sample_rate, const float* phase_u, const float* rand_phase,
                 const float* noise, float* out /* (B,N) */, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Diagnostics only: ablation variants of the fused kernel for timing (1 no sin, 2 no LUT gather, 3 no shaper tail,
+ * 4 no MFMA; 0 = product kernel).  Outputs of variants != 0 are meaningless. */
+int nws_debug_exciter_newt(int variant, const NwsWeights* w, const float* f0, const double* carry, const float* phase_u,
+                           const float* rand_phase, const float* film, int B, int T, float sample_rate,
+                           float* newt_out, void* stream);
+
+/* Diagnostics only: candidate sine implementations (0 = nws_sinf as shipped, 1 = v_sin_f32 after an exact-product
+ * reduction to turns, 2 = single odd polynomial after the same reduction); y[i] = sum of `reps` sines (reps = 1: sin(x[i])). */
+int nws_debug_sin(int mode, const float* x, float* y, int64_t n, int reps, void* stream);
 
 /*
  * Live profiling of nws_forward (bench.py's roofline leg): hipEvents are recorded on the launch stream around

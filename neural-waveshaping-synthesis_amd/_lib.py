@@ -33,7 +33,7 @@ class NwsWeights(C.Structure):
         ("shaper_in_scale", _fp),
         ("shaper_w0", _fp), ("shaper_b0", _fp), ("shaper_w2", _fp), ("shaper_b2", _fp),
         ("shaper_w4", _fp), ("shaper_b4", _fp), ("shaper_w6", _fp), ("shaper_b6", _fp),
-        ("lut", _fp), ("lut_size", C.c_int32), ("lut_min", C.c_float), ("lut_max", C.c_float),
+        ("lut", _fp), ("lut_pairs", _fp), ("lut_size", C.c_int32), ("lut_min", C.c_float), ("lut_max", C.c_float),
         ("newt_out_w", _fp), ("newt_out_b", _fp),
         ("noise_window", _fp),
     ]
@@ -68,10 +68,14 @@ _PROTOTYPES = {
     "nws_reverb_ir_spectrum": (C.c_int, [C.POINTER(NwsReverbPlan), _fp, _fp, C.c_int, _fp, _fp, C.c_size_t, _fp]),
     "nws_reverb": (C.c_int, [C.POINTER(NwsReverbPlan), _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, C.c_size_t, _fp]),
     "nws_shaper_table": (C.c_int, [C.POINTER(NwsWeights), C.c_int, C.c_float, C.c_float, _fp, _fp]),
+    "nws_lut_pairs": (C.c_int, [_fp, C.c_int, _fp, _fp]),
     "nws_shaper_apply": (C.c_int, [C.POINTER(NwsWeights), _fp, C.c_int64, C.c_int64, _fp, _fp]),
     "nws_forward_workspace_bytes": (C.c_size_t, [C.POINTER(NwsReverbPlan), C.c_int, C.c_int]),
     "nws_forward": (C.c_int, [C.POINTER(NwsWeights), C.POINTER(NwsForwardAux), _fp, _fp, C.c_int, C.c_int, C.c_int,
                               C.c_float, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
+    "nws_debug_exciter_newt": (C.c_int, [C.c_int, C.POINTER(NwsWeights), _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_float,
+                                         _fp, _fp]),
+    "nws_debug_sin": (C.c_int, [C.c_int, _fp, _fp, C.c_int64, C.c_int, _fp]),
     "nws_profile_begin": (C.c_int, [C.c_int, C.c_uint]),
     "nws_profile_collect": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "nws_profile_end": (C.c_int, []),

@@ -7,19 +7,43 @@
 //
 // Design: the recurrence is strictly sequential, so one workgroup owns one
 // utterance for all T steps and W_hh (384x128 fp32 = 192 KB, more than the 160 KB LDS) lives in
-// VGPRs: wave w holds the 32-column slice [32w, 32w+32) of all 384 rows, 6 rows per lane =
-// 192 VGPRs.  Per step every wave reads only its 32 h values (8 broadcast ds_read_b128), does
-// 192 FMAs per lane, and the four K-slices of each row are reduced through a conflict-free LDS
-// exchange by the 128 gate lanes.  Two workgroup barriers per step, no global traffic on the
-// critical path except the (prefetched) 2 control values and the 512 B h_t store.
+// VGPRs.  Wave w owns hidden units [32w, 32w+32); lane (j = l&31, kh = l>>5) holds the three gate
+// rows of unit 32w+j restricted to columns [64kh, 64kh+64): 192 weights per lane.  Per step a lane
+// reads its 64 h values (16 broadcast ds_read_b128), does 96 packed FMAs (v_pk_fma_f32), meets its
+// other K-half with one v_permlane32_swap per gate, evaluates the gates with v_exp/v_rcp (1 ulp) and
+// writes h' into the other half of a ping-pong LDS buffer: ONE workgroup barrier per step that waits
+// on LDS only (raw s_barrier + lgkmcnt(0); the 512 B h_t global store is never drained on the critical
+// path), control values staged in LDS 1024 frames at a time.
 #include "nws_common.h"
 
 namespace {
 
 constexpr int kH = NWS_HIDDEN;  // 128
-constexpr int kG = 3 * kH;      // 384 gate rows
+constexpr int kXChunk = 1024;   // control frames staged in LDS at a time
 
-__device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+// cross-half (lane l <-> l^32) sum on the VALU (v_permlane32_swap), no LDS round trip
+__device__ __forceinline__ float sum_halves(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// workgroup barrier that orders LDS traffic only: the h_t global stores (and nothing else in this loop)
+// need not be drained before the next step may start, which __syncthreads() would force (vmcnt(0))
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// sigmoid / tanh from the hardware exp2 + reciprocal (each ~1 ulp): same error class as the
+// libm forms inside torch's CPU GRU, a fraction of their latency on the sequential critical path
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+  // tanh(x) = 1 - 2 / (exp(2x) + 1); saturates correctly for |x| large (exp2 -> inf or 0)
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
 
 __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const float* __restrict__ control, int C,
                                                              int T, float* __restrict__ gru_out) {
@@ -27,101 +51,80 @@ __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  const int kh = lane >> 5;
+  const int unit = 32 * wave + (lane & 31);
 
-  __shared__ __attribute__((aligned(16))) float h_lds[kH];
-  __shared__ __attribute__((aligned(16))) float part[4][kG];
+  __shared__ __attribute__((aligned(16))) float h_lds[2][kH];
+  __shared__ float x_lds[2][kXChunk];  // control[:, 0:2] of the current chunk of frames
 
-  // W_hh slice in registers: wreg[i][c] = W_hh[lane + 64 i][32 wave + c]
-  float wreg[6][32];
+  // wreg[g][c] = W_hh[g*128 + unit][64 kh + c]
+  f32x2 wreg[3][32];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const float4* src = reinterpret_cast<const float4*>(w.gru_w_hh + (size_t)(lane + 64 * i) * kH + 32 * wave);
+  for (int g = 0; g < 3; ++g) {
+    const float4* src = reinterpret_cast<const float4*>(w.gru_w_hh + (size_t)(g * kH + unit) * kH + 64 * kh);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < 16; ++q) {
       const float4 v = src[q];
-      wreg[i][4 * q + 0] = v.x;
-      wreg[i][4 * q + 1] = v.y;
-      wreg[i][4 * q + 2] = v.z;
-      wreg[i][4 * q + 3] = v.w;
+      wreg[g][2 * q + 0] = f32x2{v.x, v.y};
+      wreg[g][2 * q + 1] = f32x2{v.z, v.w};
     }
   }
+  const float wi_r0 = w.gru_w_ih[unit * 2 + 0], wi_r1 = w.gru_w_ih[unit * 2 + 1];
+  const float wi_z0 = w.gru_w_ih[(kH + unit) * 2 + 0], wi_z1 = w.gru_w_ih[(kH + unit) * 2 + 1];
+  const float wi_n0 = w.gru_w_ih[(2 * kH + unit) * 2 + 0], wi_n1 = w.gru_w_ih[(2 * kH + unit) * 2 + 1];
+  const float bi_r = w.gru_b_ih[unit], bi_z = w.gru_b_ih[kH + unit], bi_n = w.gru_b_ih[2 * kH + unit];
+  const float bh_r = w.gru_b_hh[unit], bh_z = w.gru_b_hh[kH + unit], bh_n = w.gru_b_hh[2 * kH + unit];
 
-  // gate lanes (tid < 128 -> hidden unit j = tid) keep their input weights / biases in registers
-  float wi_r0 = 0, wi_r1 = 0, wi_z0 = 0, wi_z1 = 0, wi_n0 = 0, wi_n1 = 0;
-  float bi_r = 0, bi_z = 0, bi_n = 0, bh_r = 0, bh_z = 0, bh_n = 0;
-  float h_prev = 0.0f;
-  if (tid < kH) {
-    wi_r0 = w.gru_w_ih[(tid)*2 + 0];
-    wi_r1 = w.gru_w_ih[(tid)*2 + 1];
-    wi_z0 = w.gru_w_ih[(kH + tid) * 2 + 0];
-    wi_z1 = w.gru_w_ih[(kH + tid) * 2 + 1];
-    wi_n0 = w.gru_w_ih[(2 * kH + tid) * 2 + 0];
-    wi_n1 = w.gru_w_ih[(2 * kH + tid) * 2 + 1];
-    bi_r = w.gru_b_ih[tid];
-    bi_z = w.gru_b_ih[kH + tid];
-    bi_n = w.gru_b_ih[2 * kH + tid];
-    bh_r = w.gru_b_hh[tid];
-    bh_z = w.gru_b_hh[kH + tid];
-    bh_n = w.gru_b_hh[2 * kH + tid];
-    h_lds[tid] = 0.0f;
-  }
+  if (tid < kH) h_lds[0][tid] = 0.0f;
   const float* x0p = control + ((size_t)b * C + 0) * T;
   const float* x1p = control + ((size_t)b * C + 1) * T;
-  float x0 = 0.0f, x1 = 0.0f;
-  if (tid < kH) {
-    x0 = x0p[0];
-    x1 = x1p[0];
-  }
-  __syncthreads();
+  float h_prev = 0.0f;
 
-  for (int t = 0; t < T; ++t) {
-    // prefetch next frame's controls (independent of h)
-    float nx0 = 0.0f, nx1 = 0.0f;
-    if (tid < kH && t + 1 < T) {
-      nx0 = x0p[t + 1];
-      nx1 = x1p[t + 1];
-    }
-    // this wave's 32 hidden values
-    float hc[32];
-    const float4* hp = reinterpret_cast<const float4*>(&h_lds[32 * wave]);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const float4 v = hp[q];
-      hc[4 * q + 0] = v.x;
-      hc[4 * q + 1] = v.y;
-      hc[4 * q + 2] = v.z;
-      hc[4 * q + 3] = v.w;
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-      for (int c = 0; c < 32; c += 2) {
-        a0 = fmaf(wreg[i][c], hc[c], a0);
-        a1 = fmaf(wreg[i][c + 1], hc[c + 1], a1);
-      }
-      part[wave][lane + 64 * i] = a0 + a1;
+  for (int t0 = 0; t0 < T; t0 += kXChunk) {
+    const int nt = T - t0 < kXChunk ? T - t0 : kXChunk;
+    __syncthreads();  // previous chunk fully consumed (and h_lds[0] initialised on the first pass)
+    for (int i = tid; i < nt; i += 256) {
+      x_lds[0][i] = x0p[t0 + i];
+      x_lds[1][i] = x1p[t0 + i];
     }
     __syncthreads();
-    if (tid < kH) {
-      const float hr = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) + bh_r;
-      const float hz = ((part[0][kH + tid] + part[1][kH + tid]) + (part[2][kH + tid] + part[3][kH + tid])) + bh_z;
-      const float hn =
-          ((part[0][2 * kH + tid] + part[1][2 * kH + tid]) + (part[2][2 * kH + tid] + part[3][2 * kH + tid])) + bh_n;
-      const float ir = fmaf(wi_r1, x1, fmaf(wi_r0, x0, bi_r));
-      const float iz = fmaf(wi_z1, x1, fmaf(wi_z0, x0, bi_z));
+    for (int tt = 0; tt < nt; ++tt) {
+      const int t = t0 + tt;
+      const int cur = t & 1;
+      const float x0 = x_lds[0][tt], x1 = x_lds[1][tt];
+      // input-side gate terms: independent of h, overlap the h reads
+      const float ir = fmaf(wi_r1, x1, fmaf(wi_r0, x0, bi_r)) + bh_r;
+      const float iz = fmaf(wi_z1, x1, fmaf(wi_z0, x0, bi_z)) + bh_z;
       const float in = fmaf(wi_n1, x1, fmaf(wi_n0, x0, bi_n));
-      const float r = sigmoidf_acc(ir + hr);
-      const float z = sigmoidf_acc(iz + hz);
-      const float nn = tanhf(in + r * hn);
+      const float4* hp = reinterpret_cast<const float4*>(&h_lds[cur][64 * kh]);
+      f32x2 ar = {0.0f, 0.0f}, az = {0.0f, 0.0f}, an = {0.0f, 0.0f};
+      f32x2 br = {0.0f, 0.0f}, bz = {0.0f, 0.0f}, bn = {0.0f, 0.0f};
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float4 hv = hp[q];
+        const f32x2 h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
+        ar = __builtin_elementwise_fma(wreg[0][2 * q], h01, ar);
+        az = __builtin_elementwise_fma(wreg[1][2 * q], h01, az);
+        an = __builtin_elementwise_fma(wreg[2][2 * q], h01, an);
+        br = __builtin_elementwise_fma(wreg[0][2 * q + 1], h23, br);
+        bz = __builtin_elementwise_fma(wreg[1][2 * q + 1], h23, bz);
+        bn = __builtin_elementwise_fma(wreg[2][2 * q + 1], h23, bn);
+      }
+      const float sr = sum_halves((ar.x + ar.y) + (br.x + br.y));
+      const float sz = sum_halves((az.x + az.y) + (bz.x + bz.y));
+      const float sn = sum_halves((an.x + an.y) + (bn.x + bn.y));
+      // both K-halves now hold the full sums; both evaluate the gates (no divergence), half 0 stores
+      const float r = fast_sigmoid(ir + sr);
+      const float z = fast_sigmoid(iz + sz);
+      const float nn = fast_tanh(in + r * (sn + bh_n));
       const float hnew = (h_prev - nn) * z + nn;
       h_prev = hnew;
-      h_lds[tid] = hnew;
-      gru_out[((size_t)b * T + t) * kH + tid] = hnew;
-      x0 = nx0;
-      x1 = nx1;
+      if (kh == 0) {
+        h_lds[cur ^ 1][unit] = hnew;
+        gru_out[((size_t)b * T + t) * kH + unit] = hnew;
+      }
+      lds_barrier();
     }
-    __syncthreads();
   }
 }
 

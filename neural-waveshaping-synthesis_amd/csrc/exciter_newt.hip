@@ -24,7 +24,10 @@ constexpr int kTile = 128;                  // samples per workgroup (= control 
 constexpr float kTau = 6.283185307179586f;  // fl32(math.tau)
 constexpr float kPi = 3.141592653589793f;   // fl32(math.pi)
 
-enum Mode { kModeLut = 0, kModeExact = 1, kModeExciterOnly = 2 };
+enum Mode { kModeLut = 0, kModeExact = 1, kModeExciterOnly = 2, kModeLutPairs = 3, kModeLutPairsDiv6 = 4 };
+__host__ __device__ constexpr bool is_lut(int mode) {
+  return mode == kModeLut || mode == kModeLutPairs || mode == kModeLutPairsDiv6;
+}
 
 // ---------------------------------------------------------------------------------------------
 // carry[b][c] = sum_{n<32c} f0_up[b][n] in float64 (torch's CPU cumsum accumulates in double and
@@ -146,29 +149,73 @@ __device__ __forceinline__ void load_shaper_lds(ShaperLds& L, const NwsWeights& 
 
 // FastNEWT.shaping_fn (models/modules/shaping.py:136-151), quirks kept: index scale size/(max-min)
 // against a linspace grid of step (max-min)/(size-1); fract taken against the CLAMPED lower index.
-__device__ __forceinline__ float lut_shaper(const float* __restrict__ row, int size, float tmin, float trange, float x) {
-  const float idx = __fdiv_rn((float)size * (x - tmin), trange);
+struct LutParams {
+  const float* table;
+  const float2* pairs;
+  int size;
+  float tmin, trange, rcp_range;
+};
+
+// DIV6: trange == 6 (the reference's default table range): t/6 == fma(fma(-q,6,t), 1/6, q) with q = t*(1/6) for
+// EVERY fp32 t (checked exhaustively over all mantissas), 3 instructions instead of the ~10 of an IEEE division.
+// Compile-time on purpose: a runtime-uniform test makes hipcc unswitch the whole unrolled tail and spill it.
+template <bool DIV6>
+__device__ __forceinline__ float lut_index(const LutParams& P, float x) {
+  const float t = (float)P.size * (x - P.tmin);
+  if (DIV6) {
+    const float q = t * P.rcp_range;
+    const float r = fmaf(-q, P.trange, t);
+    return fmaf(r, P.rcp_range, q);
+  }
+  return __fdiv_rn(t, P.trange);
+}
+
+// row_off = shaper * size (elements).  With the derived pair table {T[i], fl(T[min(i+1,size-1)] - T[i])}
+// (nws_lut_pairs) one ALIGNED 8-byte gather serves the lookup; fl(upper - lower) is the reference's own
+// intermediate, so the result stays bit-identical.  Without it: two 4-byte gathers.
+template <bool PAIRS, bool DIV6>
+__device__ __forceinline__ float lut_shaper(const LutParams& P, int row_off, float x) {
+  const float idx = lut_index<DIV6>(P, x);
   float fl = floorf(idx);
   fl = fmaxf(fl, 0.0f);
-  fl = fminf(fl, (float)(size - 1));
+  fl = fminf(fl, (float)(P.size - 1));
   const int lo = (int)fl;
-  const int up = lo + 1 < size ? lo + 1 : size - 1;
   const float fract = idx - fl;
-  const float lv = row[lo];
-  const float uv = row[up];
+  if (PAIRS) {  // compile-time: a runtime test here makes hipcc unswitch the whole unrolled tail and spill it
+    const float2 v = P.pairs[(unsigned)(row_off + lo)];
+    return v.y * fract + v.x;
+  }
+  const int up = lo + 1 < P.size ? lo + 1 : P.size - 1;
+  const float lv = P.table[(unsigned)(row_off + lo)];
+  const float uv = P.table[(unsigned)(row_off + up)];
   return (uv - lv) * fract + lv;
+}
+
+__device__ __forceinline__ LutParams make_lut_params(const NwsWeights& w) {
+  LutParams P;
+  P.table = w.lut;
+  P.pairs = reinterpret_cast<const float2*>(w.lut_pairs);
+  P.size = w.lut_size;
+  P.tmin = w.lut_min;
+  P.trange = w.lut_max - w.lut_min;
+  P.rcp_range = 1.0f / P.trange;
+  return P;
 }
 
 struct ExcLds {
   float wt[kKPad * kWtStride];  // wt[kk][s] = mixer_w[s][kk]
-  float mix_b[kS];
-  float out_w[kS];
+  float2 shp[kS];               // {harmonic_mixer.bias[s], newt.mixer.weight[s]}
   float shift[kKPad];
-  float film[3][NWS_FILM_CH];   // frames j-1, j, j+1 (clamped)
+  float pad_[2];
+  float4 film[3][kS];           // frames j-1, j, j+1 (clamped): {g_idx, b_idx, g_norm, b_norm} of shaper s
 };
 
-template <int MODE>
-__global__ __launch_bounds__(256) void exciter_newt_kernel(NwsWeights w, const float* __restrict__ f0,
+// DBG != 0 instantiations exist only for nws_debug_exciter_newt (ablation timing; results are wrong by design):
+//   1: sin() replaced by its argument   2: LUT gather skipped   3: whole FiLM/shaper tail skipped   4: MFMAs skipped
+// second launch-bound = minimum waves per SIMD: without it hipcc hoists all 32 LUT gathers of the tail, takes 256
+// VGPRs and drops the kernel to 1 wave/SIMD (measured 2x slower); 4 waves/SIMD = 128 VGPRs, LDS allows 5 blocks/CU
+template <int MODE, int DBG = 0>
+__global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_kernel(NwsWeights w, const float* __restrict__ f0,
                                                            const float* __restrict__ f0_up,
                                                            const double* __restrict__ carry,
                                                            const float* __restrict__ phase_u,
@@ -196,8 +243,7 @@ __global__ __launch_bounds__(256) void exciter_newt_kernel(NwsWeights w, const f
   }
   if (tid < kS) {
     L.wt[kK * kWtStride + tid] = 0.0f;  // padded harmonic 102
-    L.mix_b[tid] = w.mixer_b[tid];
-    if (MODE != kModeExciterOnly) L.out_w[tid] = w.newt_out_w[tid];
+    L.shp[tid] = make_float2(w.mixer_b[tid], MODE != kModeExciterOnly ? w.newt_out_w[tid] : 0.0f);
   }
   // _create_phase_shift (generators.py:54-56): fl(fl(u * rand_phase) - fl32(pi))
   if (tid < kKPad) L.shift[tid] = tid < kK ? phase_u[tid] * rand_phase[tid] - kPi : 0.0f;
@@ -206,7 +252,7 @@ __global__ __launch_bounds__(256) void exciter_newt_kernel(NwsWeights w, const f
       const int q = e >> 8, c = e & 255;
       int f = j - 1 + q;
       f = f < 0 ? 0 : (f > T - 1 ? T - 1 : f);
-      L.film[q][c] = film[((size_t)b * T + f) * NWS_FILM_CH + c];
+      reinterpret_cast<float*>(&L.film[q][c & 63])[c >> 6] = film[((size_t)b * T + f) * NWS_FILM_CH + c];
     }
   }
   if (MODE == kModeExact) load_shaper_lds(SH, w, tid, 256);
@@ -248,11 +294,16 @@ __global__ __launch_bounds__(256) void exciter_newt_kernel(NwsWeights w, const f
     const bool live = (f0n * kf) < nyquist;  // anti-alias mask on the upsampled F0 (generators.py:50-52)
     if (__all(!live)) break;                 // k*f0 only grows with k: everything above is masked too
     const float arg = kf * phase + L.shift[kk];
-    const float v = live ? nws_sinf(arg) : 0.0f;
+    const float v = live ? (DBG == 1 ? arg : nws_sinf_fast(arg)) : 0.0f;
     const float a0 = wt_lane[s * 2 * kWtStride];
     const float a1 = wt_lane[s * 2 * kWtStride + 32];
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, v, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, v, acc1, 0, 0, 0);
+    if (DBG == 4) {
+      acc0[s & 15] = fmaf(a0, v, acc0[s & 15]);
+      acc1[s & 15] = fmaf(a1, v, acc1[s & 15]);
+    } else {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, v, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, v, acc1, 0, 0, 0);
+    }
   }
 
   // accumulator element r of M-tile m: shaper 32m + (r&3) + 8(r>>2) + 4*half, sample `col`
@@ -260,36 +311,53 @@ __global__ __launch_bounds__(256) void exciter_newt_kernel(NwsWeights w, const f
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int s0 = (r & 3) + 8 * (r >> 2) + 4 * half;
-      exciter_out[((size_t)b * kS + s0) * N + n] = acc0[r] + L.mix_b[s0];
-      exciter_out[((size_t)b * kS + s0 + 32) * N + n] = acc1[r] + L.mix_b[s0 + 32];
+      exciter_out[((size_t)b * kS + s0) * N + n] = acc0[r] + L.shp[s0].x;
+      exciter_out[((size_t)b * kS + s0 + 32) * N + n] = acc1[r] + L.shp[s0 + 32].x;
     }
   }
   if (MODE == kModeExciterOnly) return;
+  if (DBG == 3) {
+    float t = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += acc0[r] + acc1[r];
+    t += nws_swap_halves(t);
+    if (half == 0) newt_out[(size_t)b * N + n] = t;
+    return;
+  }
 
   // ---- FiLM -> shaper -> FiLM -> 64->1 mix, all in registers ----
-  const float* p0 = L.film[lc.i0 - (j - 1)];
-  const float* p1 = L.film[lc.i1 - (j - 1)];
-  const float trange = w.lut_max - w.lut_min;
+  const float4* p0 = L.film[lc.i0 - (j - 1)];
+  const float4* p1 = L.film[lc.i1 - (j - 1)];
+  LutParams LP;
+  if (is_lut(MODE)) LP = make_lut_params(w);
+  const int lane_row_off = is_lut(MODE) ? 4 * half * w.lut_size : 0;
   float partial = 0.0f;
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int s0 = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float x = (m == 0 ? acc0[r] : acc1[r]) + L.mix_b[s0];
-      const float g_i = nws_lerp(p0[s0], p1[s0], lc.w0, lc.w1);
-      const float b_i = nws_lerp(p0[64 + s0], p1[64 + s0], lc.w0, lc.w1);
-      const float g_n = nws_lerp(p0[128 + s0], p1[128 + s0], lc.w0, lc.w1);
-      const float b_n = nws_lerp(p0[192 + s0], p1[192 + s0], lc.w0, lc.w1);
+      const int sb = 32 * m + (r & 3) + 8 * (r >> 2);  // compile-time part of the shaper index
+      const int s0 = sb + 4 * half;
+      const float2 sp = L.shp[s0];
+      const float x = (m == 0 ? acc0[r] : acc1[r]) + sp.x;
+      const float4 a = p0[s0], c = p1[s0];
+      const float g_i = nws_lerp(a.x, c.x, lc.w0, lc.w1);
+      const float b_i = nws_lerp(a.y, c.y, lc.w0, lc.w1);
+      const float g_n = nws_lerp(a.z, c.z, lc.w0, lc.w1);
+      const float b_n = nws_lerp(a.w, c.w, lc.w0, lc.w1);
       const float xi = g_i * x + b_i;  // FiLM (models/modules/dynamic.py:8)
       float sh;
-      if (MODE == kModeLut) {
-        sh = lut_shaper(w.lut + (size_t)s0 * w.lut_size, w.lut_size, w.lut_min, trange, xi);
+      if (DBG == 2) {
+        sh = xi;
+      } else if (is_lut(MODE)) {
+        sh = lut_shaper<MODE != kModeLut, MODE == kModeLutPairsDiv6>(LP, sb * LP.size + lane_row_off, xi);
       } else {
         sh = exact_shaper(SH, s0, xi);
       }
       const float y = g_n * sh + b_n;
-      partial = fmaf(L.out_w[s0], y, partial);
+      partial = fmaf(sp.y, y, partial);
+      // fence the scheduler every 8 pairs: at most 8 gathers (+ their FiLM operands) are live at once
+      if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
   }
   const float total = partial + nws_swap_halves(partial) + w.newt_out_b[0];
@@ -306,11 +374,11 @@ __global__ __launch_bounds__(256) void shaper_apply_kernel(NwsWeights w, const f
   __syncthreads();
   const int64_t row = blockIdx.y;  // b*64 + s
   const int s = (int)(row & 63);
-  const float trange = w.lut_max - w.lut_min;
+  LutParams LP;
+  if (MODE == kModeLut) LP = make_lut_params(w);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
     const float v = x[row * N + i];
-    y[row * N + i] = MODE == kModeLut ? lut_shaper(w.lut + (size_t)s * w.lut_size, w.lut_size, w.lut_min, trange, v)
-                                      : exact_shaper(SH, s, v);
+    y[row * N + i] = MODE == kModeLut ? lut_shaper<false, false>(LP, s * LP.size, v) : exact_shaper(SH, s, v);
   }
 }
 
@@ -329,6 +397,53 @@ __global__ __launch_bounds__(256) void shaper_table_kernel(NwsWeights w, int siz
   for (int i = blockIdx.x * 256 + threadIdx.x; i < size; i += gridDim.x * 256) {
     const float xv = i < halfway ? fmaf(step, (float)i, tmin) : fmaf(-step, (float)(size - 1 - i), tmax);
     table[(size_t)s * size + i] = exact_shaper(SH, s, xv);
+  }
+}
+
+// Candidate cheaper sines, measured on hardware through nws_debug_sin before any of them may replace nws_sinf.
+//  exact-product reduction to turns: p = x*C_hi, e = fma(x, C_hi, -p) (the product's rounding error),
+//  t = (p - rint(p)) + (e + x*C_lo)  in [-0.53, 0.53] turns, good to ~3e-8 turns for |x| <= 6e6.
+__device__ __forceinline__ float turns_reduce(float x) {
+  const float c_hi = 0.15915493667125702f;     // fl32(1/(2 pi))
+  const float c_lo = 6.4206382432985265e-09f;   // 1/(2 pi) - c_hi
+  const float p = x * c_hi;
+  const float e = fmaf(x, c_hi, -p);
+  return (p - rintf(p)) + fmaf(x, c_lo, e);
+}
+__device__ __forceinline__ float sin_hw_turns(float x) { return __builtin_amdgcn_sinf(turns_reduce(x)); }
+__device__ __forceinline__ float sin_poly_turns(float x) {
+  float t = turns_reduce(x);
+  t = t - rintf(t);                                   // [-0.5, 0.5]
+  const float f = copysignf(0.5f, t) - t;             // sin(pi - a) = sin(a)
+  t = fabsf(t) > 0.25f ? f : t;                       // [-0.25, 0.25] turns
+  const float a = t * 6.283185307179586f;             // [-pi/2, pi/2]
+  const float z = a * a;
+  float q = fmaf(-2.4080531346726275e-08f, z, 2.753648004727438e-06f);  // odd degree-11 fit, |err| < 2e-8 on [-pi/2, pi/2]
+  q = fmaf(q, z, -0.00019841086759697646f);
+  q = fmaf(q, z, 0.00833333283662796f);
+  q = fmaf(q, z, -0.1666666716337204f);
+  return fmaf(a * z, q, a);
+}
+
+template <int MODE>
+__global__ void sin_variant_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int reps) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    float acc = 0.0f;
+    for (int r = 0; r < reps; ++r) {
+      const float a = v + (float)r * 1.0e-3f * acc;
+      acc += MODE == 0 ? nws_sinf(a) : MODE == 1 ? sin_hw_turns(a) : sin_poly_turns(a);
+    }
+    y[i] = acc;
+  }
+}
+
+__global__ void lut_pairs_kernel(const float* __restrict__ table, int size, float2* __restrict__ pairs) {
+  const int s = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < size; i += gridDim.x * blockDim.x) {
+    const float lv = table[(size_t)s * size + i];
+    const float uv = table[(size_t)s * size + (i + 1 < size ? i + 1 : size - 1)];
+    pairs[(size_t)s * size + i] = make_float2(lv, uv - lv);
   }
 }
 
@@ -397,6 +512,26 @@ int nws_sin(const float* x, float* y, int64_t n, void* stream) {
   return NWS_OK;
 }
 
+int nws_lut_pairs(const float* table, int table_size, float* pairs_out, void* stream) {
+  if (!table || !pairs_out || table_size < 2) return NWS_ERR_BAD_ARG;
+  const dim3 grid((table_size + 255) / 256, NWS_N_SHAPERS);
+  lut_pairs_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(table, table_size, reinterpret_cast<float2*>(pairs_out));
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+int nws_debug_sin(int mode, const float* x, float* y, int64_t n, int reps, void* stream) {
+  if (!x || !y || n <= 0 || reps < 1) return NWS_ERR_BAD_ARG;
+  const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 0) sin_variant_kernel<0><<<blocks, 256, 0, st>>>(x, y, n, reps);
+  else if (mode == 1) sin_variant_kernel<1><<<blocks, 256, 0, st>>>(x, y, n, reps);
+  else if (mode == 2) sin_variant_kernel<2><<<blocks, 256, 0, st>>>(x, y, n, reps);
+  else return NWS_ERR_BAD_ARG;
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
 int nws_phase_carry(const float* f0, const float* f0_up, int B, int T, double* carry, void* stream) {
   if ((!f0 && !f0_up) || !carry || B <= 0 || T <= 0) return NWS_ERR_BAD_ARG;
   phase_carry_kernel<<<B, 1024, 0, (hipStream_t)stream>>>(f0, f0_up, T, carry);
@@ -420,14 +555,46 @@ int nws_exciter_newt(const NwsWeights* w, const float* f0, const float* f0_up, c
     if (!film || !w->newt_out_w || !w->newt_out_b) return NWS_ERR_BAD_ARG;
     if (w->lut != nullptr) {
       if (w->lut_size < 2 || !(w->lut_max > w->lut_min)) return NWS_ERR_BAD_ARG;
-      exciter_newt_kernel<kModeLut><<<grid, 256, base, st>>>(*w, f0, f0_up, carry, phase_u, rand_phase, film, T,
-                                                             sample_rate, exciter_out, newt_out);
+      if (w->lut_pairs != nullptr && w->lut_max - w->lut_min == 6.0f)
+        exciter_newt_kernel<kModeLutPairsDiv6><<<grid, 256, base, st>>>(*w, f0, f0_up, carry, phase_u, rand_phase,
+                                                                        film, T, sample_rate, exciter_out, newt_out);
+      else if (w->lut_pairs != nullptr)
+        exciter_newt_kernel<kModeLutPairs><<<grid, 256, base, st>>>(*w, f0, f0_up, carry, phase_u, rand_phase, film,
+                                                                    T, sample_rate, exciter_out, newt_out);
+      else
+        exciter_newt_kernel<kModeLut><<<grid, 256, base, st>>>(*w, f0, f0_up, carry, phase_u, rand_phase, film, T,
+                                                               sample_rate, exciter_out, newt_out);
     } else {
       if (!w->shaper_w0 || !w->shaper_w2 || !w->shaper_w4 || !w->shaper_w6) return NWS_ERR_BAD_ARG;
       exciter_newt_kernel<kModeExact><<<grid, 256, base + sizeof(ShaperLds), st>>>(
           *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out);
     }
   }
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+int nws_debug_exciter_newt(int variant, const NwsWeights* w, const float* f0, const double* carry, const float* phase_u,
+                           const float* rand_phase, const float* film, int B, int T, float sample_rate,
+                           float* newt_out, void* stream) {
+  if (!weights_ok(w) || !f0 || !carry || !phase_u || !rand_phase || !film || !newt_out || !w->lut || !w->lut_pairs)
+    return NWS_ERR_BAD_ARG;
+  if (w->lut_max - w->lut_min != 6.0f) return NWS_ERR_UNSUPPORTED;
+  const dim3 grid(T, B);
+  const size_t base = (sizeof(ExcLds) + 15) & ~size_t(15);
+  hipStream_t st = (hipStream_t)stream;
+#define NWS_DBG_LAUNCH(V)                                                                                         \
+  exciter_newt_kernel<kModeLutPairsDiv6, V><<<grid, 256, base, st>>>(*w, f0, nullptr, carry, phase_u, rand_phase, film, T, \
+                                                            sample_rate, nullptr, newt_out)
+  switch (variant) {
+    case 0: NWS_DBG_LAUNCH(0); break;
+    case 1: NWS_DBG_LAUNCH(1); break;
+    case 2: NWS_DBG_LAUNCH(2); break;
+    case 3: NWS_DBG_LAUNCH(3); break;
+    case 4: NWS_DBG_LAUNCH(4); break;
+    default: return NWS_ERR_BAD_ARG;
+  }
+#undef NWS_DBG_LAUNCH
   NWS_CHECK_LAUNCH();
   return NWS_OK;
 }

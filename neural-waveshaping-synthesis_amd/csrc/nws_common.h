@@ -77,11 +77,35 @@ __device__ __forceinline__ float nws_sinf(float x) {
   const float fq = rintf(x * 0.6366197723675814f);
   float r = fmaf(fq, -1.5707963705062866f, x);
   r = fmaf(fq, 4.371138828673793e-08f, r);
-  const int q = (int)fq;
+  int q = (int)fq;
+  if (fabsf(x) > 32768.0f) {
+    // the fp32 quotient estimate is only good to ~1e-7*|x|: r may sit up to ~0.5 outside [-pi/4, pi/4];
+    // one more (exact) reduction step by -1/0/+1 quadrants brings it back
+    const float fq2 = rintf(r * 0.6366197723675814f);
+    r = fmaf(fq2, -1.5707963705062866f, r);
+    r = fmaf(fq2, 4.371138828673793e-08f, r);
+    q += (int)fq2;
+  }
   const float s = nws_sin_poly(r);
   const float c = nws_cos_poly(r);
   float v = (q & 1) ? c : s;
   return (q & 2) ? -v : v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast sine for the 6.5 M oscillator evaluations per utterance: the hardware v_sin_f32 (argument in turns)
+// behind an exact-product reduction  p = x*C_hi, e = fma(x, C_hi, -p) (the rounding error of p, exact),
+// t = (p - rint(p)) + (e + x*C_lo).  Measured on MI355X against float64 (tools/measure_sin.py): max abs
+// error 2.4e-7 for |x| <= 5e6 (rms 4.6e-8), 2.2x the throughput of nws_sinf.  The oscillator needs ~1e-6.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float nws_sinf_fast(float x) {
+  if (__builtin_expect(fabsf(x) > 6.0e6f, 0)) return nws_sinf_huge(x);
+  const float c_hi = 0.15915493667125702f;     // fl32(1/(2 pi))
+  const float c_lo = 6.4206382432985265e-09f;   // 1/(2 pi) - c_hi
+  const float p = x * c_hi;
+  const float e = fmaf(x, c_hi, -p);
+  const float t = (p - rintf(p)) + fmaf(x, c_lo, e);
+  return __builtin_amdgcn_sinf(t);
 }
 
 // 32-lane-half exchange (lane l <-> lane l^32)

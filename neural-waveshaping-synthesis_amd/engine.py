@@ -117,11 +117,16 @@ class Engine:
         if table is not None:
             size = int(m.newt.table_size)
             w.lut = P(table, "newt.lookup_table", 64 * size)
+            pairs = torch.empty((64, size, 2), dtype=torch.float32, device=table.device)
+            check(_lib.lib().nws_lut_pairs(w.lut, size, ptr(pairs), stream_ptr()), "nws_lut_pairs")
+            keep.append(pairs)
+            w.lut_pairs = pairs.data_ptr()
             w.lut_size = size
             w.lut_min = float(m.newt.table_min)
             w.lut_max = float(m.newt.table_max)
         else:
             w.lut = None
+            w.lut_pairs = None
             w.lut_size, w.lut_min, w.lut_max = 0, 0.0, 0.0
         w.newt_out_w = P(m.newt.mixer[0].weight, "newt.mixer.0.weight", 64)
         w.newt_out_b = P(m.newt.mixer[0].bias, "newt.mixer.0.bias", 1)

