@@ -27,7 +27,7 @@ class NwsWeights(C.Structure):
     _fields_ = [
         ("gru_w_ih", _fp), ("gru_w_hh", _fp), ("gru_b_ih", _fp), ("gru_b_hh", _fp),
         ("proj_w", _fp), ("proj_b", _fp),
-        ("mixer_w", _fp), ("mixer_b", _fp),
+        ("mixer_w", _fp), ("mixer_b", _fp), ("mixer_frags", _fp),
         ("newt_mlp_w", _fp * 4), ("newt_mlp_b", _fp * 4), ("newt_ln_g", _fp * 3), ("newt_ln_b", _fp * 3),
         ("hgen_w", _fp * 4), ("hgen_b", _fp * 4), ("hgen_ln_g", _fp * 3), ("hgen_ln_b", _fp * 3),
         ("shaper_in_scale", _fp),
@@ -68,6 +68,7 @@ _PROTOTYPES = {
     "nws_reverb_ir_spectrum": (C.c_int, [C.POINTER(NwsReverbPlan), _fp, _fp, C.c_int, _fp, _fp, C.c_size_t, _fp]),
     "nws_reverb": (C.c_int, [C.POINTER(NwsReverbPlan), _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, C.c_size_t, _fp]),
     "nws_shaper_table": (C.c_int, [C.POINTER(NwsWeights), C.c_int, C.c_float, C.c_float, _fp, _fp]),
+    "nws_mixer_frags": (C.c_int, [_fp, _fp, _fp]),
     "nws_lut_pairs": (C.c_int, [_fp, C.c_int, _fp, _fp]),
     "nws_shaper_apply": (C.c_int, [C.POINTER(NwsWeights), _fp, C.c_int64, C.c_int64, _fp, _fp]),
     "nws_forward_workspace_bytes": (C.c_size_t, [C.POINTER(NwsReverbPlan), C.c_int, C.c_int]),

@@ -7,19 +7,24 @@
 //   NEWT.forward / FastNEWT.shaping_fn  models/modules/shaping.py:67-79, :136-151
 //
 // Design: the (B,101,N) oscillator bank and the (B,64,N) exciter of the
-// reference never exist in HBM.  Each lane evaluates one sin() per MFMA step directly in the
-// B-operand layout of v_mfma_f32_32x32x2_f32 (lane l -> harmonic 2s+(l>>5), sample l&31); the
-// 101->64 mixer weights are the A operand, staged once per workgroup in LDS (transposed, row
-// stride 65 -> conflict-free).  The 64x32 accumulator tile then goes straight through
+// reference never exist in HBM.  Each lane evaluates 8 sines per MFMA K-step directly in the
+// B-fragment layout of v_mfma_f32_32x32x16_f16 (lane l -> harmonics 16ks + 8(l>>5) + 1..8 of sample
+// l&31).  The 101->64 mixer runs on the fp16 matrix pipe with BOTH operands split into two fp16
+// terms (W = W_hi + W_lo staged once per workgroup in LDS in A-fragment order, v = v_hi + v_lo):
+// W_hi v_hi + W_hi v_lo + W_lo v_hi keeps 22 bits per product with fp32 accumulation -- measured
+// indistinguishable from the exact-fp32 MFMA it replaced, at 1/5 of its matrix-pipe time, and unlike
+// the fp32 MFMA it overlaps with the VALU work.  The 64x32 accumulator tile then goes straight through
 // FiLM -> LUT (or sin-MLP) -> FiLM -> 64->1 mix in registers; one coalesced 128 B store per wave.
 #include "nws_common.h"
 
 namespace {
 
 constexpr int kK = NWS_N_HARMONICS;         // 101
-constexpr int kKPad = 102;                  // 51 MFMA steps of 2 harmonics
+constexpr int kKSteps = 7;                  // MFMA K-steps of 16 harmonics
+constexpr int kKPad = 16 * kKSteps;         // 112
 constexpr int kS = NWS_N_SHAPERS;           // 64
-constexpr int kWtStride = 65;               // LDS row stride of the transposed mixer
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 constexpr int kTile = 128;                  // samples per workgroup (= control hop)
 constexpr float kTau = 6.283185307179586f;  // fl32(math.tau)
 constexpr float kPi = 3.141592653589793f;   // fl32(math.pi)
@@ -202,13 +207,21 @@ __device__ __forceinline__ LutParams make_lut_params(const NwsWeights& w) {
   return P;
 }
 
+// Mixer weights as two fp16 terms, W = W_hi + W_lo (22+ significant bits), in MFMA A-fragment order:
+// fragment (ks, m, h, i) = 8 halfs = W[32m + i][16ks + 8h .. +7]; lane (i, h) reads it with one ds_read_b128.
 struct ExcLds {
-  float wt[kKPad * kWtStride];  // wt[kk][s] = mixer_w[s][kk]
+  f16x8 whi[kKSteps * 2 * 2 * 32];
+  f16x8 wlo[kKSteps * 2 * 2 * 32];
+  float4 film[3][kS];           // frames j-1, j, j+1 (clamped): {g_idx, b_idx, g_norm, b_norm} of shaper s
   float2 shp[kS];               // {harmonic_mixer.bias[s], newt.mixer.weight[s]}
   float shift[kKPad];
-  float pad_[2];
-  float4 film[3][kS];           // frames j-1, j, j+1 (clamped): {g_idx, b_idx, g_norm, b_norm} of shaper s
 };
+
+// v = hi + lo with hi, lo fp16 (lo exact residual rounded to fp16: ~2^-22 relative)
+__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)v;
+  lo = (_Float16)(v - (float)hi);
+}
 
 // DBG != 0 instantiations exist only for nws_debug_exciter_newt (ablation timing; results are wrong by design):
 //   1: sin() replaced by its argument   2: LUT gather skipped   3: whole FiLM/shaper tail skipped   4: MFMAs skipped
@@ -237,16 +250,26 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
   const int N = T * NWS_HOP;
 
   // ---- stage the workgroup constants in LDS ----
-  for (int e = tid; e < kS * kK; e += 256) {
-    const int s = e / kK, kk = e - s * kK;
-    L.wt[kk * kWtStride + s] = w.mixer_w[e];
+  if (w.mixer_frags != nullptr) {
+    // pre-split fragment table (nws_mixer_frags): straight 28 KB copy, 16 B per lane per load
+    const float4* src = reinterpret_cast<const float4*>(w.mixer_frags);
+    float4* dst = reinterpret_cast<float4*>(L.whi);  // whi and wlo are contiguous
+    for (int e = tid; e < 2 * kKSteps * 2 * 2 * 32; e += 256) dst[e] = src[e];
+  } else {
+    _Float16* whi = reinterpret_cast<_Float16*>(L.whi);
+    _Float16* wlo = reinterpret_cast<_Float16*>(L.wlo);
+    for (int e = tid; e < kS * kKPad; e += 256) {
+      const int s = e / kKPad, kk = e - s * kKPad;
+      const float wv = kk < kK ? w.mixer_w[s * kK + kk] : 0.0f;  // harmonics 102..112 are padding
+      const int frag = (((kk >> 4) * 2 + (s >> 5)) * 2 + ((kk >> 3) & 1)) * 32 + (s & 31);
+      split_f16(wv, whi[frag * 8 + (kk & 7)], wlo[frag * 8 + (kk & 7)]);
+    }
   }
   if (tid < kS) {
-    L.wt[kK * kWtStride + tid] = 0.0f;  // padded harmonic 102
     L.shp[tid] = make_float2(w.mixer_b[tid], MODE != kModeExciterOnly ? w.newt_out_w[tid] : 0.0f);
   }
   // _create_phase_shift (generators.py:54-56): fl(fl(u * rand_phase) - fl32(pi))
-  if (tid < kKPad) L.shift[tid] = tid < kK ? phase_u[tid] * rand_phase[tid] - kPi : 0.0f;
+  if (tid < kKPad) L.shift[tid] = tid < kK ? phase_u[tid] * rand_phase[tid] - kPi : 0.0f;  // kKPad = 112 <= 256
   if (MODE != kModeExciterOnly) {
     for (int e = tid; e < 3 * NWS_FILM_CH; e += 256) {
       const int q = e >> 8, c = e & 255;
@@ -280,29 +303,61 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
 
   __syncthreads();
 
-  // ---- 101 harmonics -> 64 shapers on the matrix cores ----
+  // ---- 101 harmonics -> 64 shapers on the matrix cores (fp16 two-term split, fp32 accumulate) ----
+  // K-step ks covers harmonics 16ks+1 .. 16ks+16; lane (col, half) evaluates the 8 sines of harmonics
+  // 16ks + 8half + 1..8 for its sample: exactly the B fragment of v_mfma_f32_32x32x16_f16.
   f32x16 acc0, acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     acc0[r] = 0.0f;
     acc1[r] = 0.0f;
   }
-  const float* wt_lane = &L.wt[half * kWtStride + col];
-  for (int s = 0; s < kKPad / 2; ++s) {
-    const int kk = 2 * s + half;
-    const float kf = (float)(kk + 1);
-    const bool live = (f0n * kf) < nyquist;  // anti-alias mask on the upsampled F0 (generators.py:50-52)
-    if (__all(!live)) break;                 // k*f0 only grows with k: everything above is masked too
-    const float arg = kf * phase + L.shift[kk];
-    const float v = live ? (DBG == 1 ? arg : nws_sinf_fast(arg)) : 0.0f;
-    const float a0 = wt_lane[s * 2 * kWtStride];
-    const float a1 = wt_lane[s * 2 * kWtStride + 32];
-    if (DBG == 4) {
-      acc0[s & 15] = fmaf(a0, v, acc0[s & 15]);
-      acc1[s & 15] = fmaf(a1, v, acc1[s & 15]);
-    } else {
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, v, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, v, acc1, 0, 0, 0);
+  // no sine argument of this wave can exceed the fast reduction's range -> drop the per-sine range test
+  const bool small_args = __all(fabsf(phase) * (float)kKPad + 4.0f < 6.0e6f);
+  const int frag_lane = half * 32 + col;
+  for (int ks = 0; ks < kKSteps; ++ks) {
+    const int kk0 = 16 * ks + 8 * half;
+    bool live[8];
+    bool any = false;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      // anti-alias mask on the upsampled F0 (generators.py:50-52); padding harmonics are dead
+      live[e] = (f0n * (float)(kk0 + e + 1)) < nyquist && (kk0 + e) < kK;
+      any |= live[e];
+    }
+    if (!__any(any)) break;  // k*f0 only grows with k: everything above is masked too
+    const float4 sh0 = *reinterpret_cast<const float4*>(&L.shift[kk0]);
+    const float4 sh1 = *reinterpret_cast<const float4*>(&L.shift[kk0 + 4]);
+    const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
+    f16x8 vhi, vlo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float kf = (float)(kk0 + e + 1);
+      const float arg = kf * phase + sh[e];  // fl(fl(k*phase) + shift): the reference's own rounding chain
+      float v;
+      if (DBG == 1) v = arg;
+      else v = small_args ? nws_sin_turns(arg) : nws_sinf_fast(arg);
+      v = live[e] ? v : 0.0f;
+      _Float16 h, l;
+      split_f16(v, h, l);
+      vhi[e] = h;
+      vlo[e] = l;
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const f16x8 ahi = L.whi[(ks * 2 + m) * 64 + frag_lane];
+      const f16x8 alo = L.wlo[(ks * 2 + m) * 64 + frag_lane];
+      if (DBG == 4) {
+        (m == 0 ? acc0 : acc1)[ks] += (float)ahi[0] * (float)vhi[0] + (float)alo[1] * (float)vlo[1];
+      } else if (m == 0) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, vhi, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, vlo, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, vhi, acc0, 0, 0, 0);
+      } else {
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, vhi, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, vlo, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, vhi, acc1, 0, 0, 0);
+      }
     }
   }
 
@@ -438,6 +493,19 @@ __global__ void sin_variant_kernel(const float* __restrict__ x, float* __restric
   }
 }
 
+// mixer_w (64,101) fp32 -> [whi fragments | wlo fragments] exactly as ExcLds holds them
+__global__ void mixer_frags_kernel(const float* __restrict__ mixer_w, _Float16* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= kS * kKPad) return;
+  const int s = e / kKPad, kk = e - s * kKPad;
+  const float wv = kk < kK ? mixer_w[s * kK + kk] : 0.0f;
+  const int frag = (((kk >> 4) * 2 + (s >> 5)) * 2 + ((kk >> 3) & 1)) * 32 + (s & 31);
+  _Float16 h, l;
+  split_f16(wv, h, l);
+  out[frag * 8 + (kk & 7)] = h;
+  out[kKSteps * 2 * 2 * 32 * 8 + frag * 8 + (kk & 7)] = l;
+}
+
 __global__ void lut_pairs_kernel(const float* __restrict__ table, int size, float2* __restrict__ pairs) {
   const int s = blockIdx.y;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < size; i += gridDim.x * blockDim.x) {
@@ -474,6 +542,23 @@ __global__ void selftest_mfma_kernel(int32_t* bad) {
     const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
     if (acc[r] != 100.0f * (float)i + (float)col) ++nbad;
   }
+  // same check for the 32x32x16 f16 form with the fragment convention used above: lane (i|j = l&31, h = l>>5),
+  // element e <-> k = 8h + e for BOTH operands.  A[i][k] = (i % 16 == k), B[k][j] = 100k + j  ->  D[i][j] = B[i%16][j]
+  f16x8 a16, b16;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 8 * half + e;
+    a16[e] = (_Float16)((col % 16) == k ? 1.0f : 0.0f);
+    b16[e] = (_Float16)(100.0f * (float)k + (float)col);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a16, b16, acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (acc[r] != 100.0f * (float)(i % 16) + (float)col) ++nbad;
+  }
   if (nbad) atomicAdd(bad, nbad);
 }
 
@@ -508,6 +593,13 @@ int nws_sin(const float* x, float* y, int64_t n, void* stream) {
   if (n == 0) return NWS_OK;
   const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   sin_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(x, y, n);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+int nws_mixer_frags(const float* mixer_w, void* frags_out, void* stream) {
+  if (!mixer_w || !frags_out) return NWS_ERR_BAD_ARG;
+  mixer_frags_kernel<<<(kS * kKPad + 255) / 256, 256, 0, (hipStream_t)stream>>>(mixer_w, static_cast<_Float16*>(frags_out));
   NWS_CHECK_LAUNCH();
   return NWS_OK;
 }

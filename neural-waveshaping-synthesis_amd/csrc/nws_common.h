@@ -98,14 +98,18 @@ __device__ __forceinline__ float nws_sinf(float x) {
 // t = (p - rint(p)) + (e + x*C_lo).  Measured on MI355X against float64 (tools/measure_sin.py): max abs
 // error 2.4e-7 for |x| <= 5e6 (rms 4.6e-8), 2.2x the throughput of nws_sinf.  The oscillator needs ~1e-6.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float nws_sinf_fast(float x) {
-  if (__builtin_expect(fabsf(x) > 6.0e6f, 0)) return nws_sinf_huge(x);
+__device__ __forceinline__ float nws_sin_turns(float x) {  // caller guarantees |x| <= 6e6
   const float c_hi = 0.15915493667125702f;     // fl32(1/(2 pi))
   const float c_lo = 6.4206382432985265e-09f;   // 1/(2 pi) - c_hi
   const float p = x * c_hi;
   const float e = fmaf(x, c_hi, -p);
   const float t = (p - rintf(p)) + fmaf(x, c_lo, e);
   return __builtin_amdgcn_sinf(t);
+}
+
+__device__ __forceinline__ float nws_sinf_fast(float x) {
+  if (__builtin_expect(fabsf(x) > 6.0e6f, 0)) return nws_sinf_huge(x);
+  return nws_sin_turns(x);
 }
 
 // 32-lane-half exchange (lane l <-> lane l^32)

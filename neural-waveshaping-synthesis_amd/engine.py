@@ -88,6 +88,10 @@ class Engine:
         w.proj_b = P(m.embedding.proj.bias, "embedding.proj.bias", 128)
         w.mixer_w = P(m.harmonic_mixer.weight, "harmonic_mixer.weight", 64 * 101)
         w.mixer_b = P(m.harmonic_mixer.bias, "harmonic_mixer.bias", 64)
+        frags = torch.empty(28672, dtype=torch.uint8, device=keep[-1].device)
+        check(_lib.lib().nws_mixer_frags(w.mixer_w, ptr(frags), stream_ptr()), "nws_mixer_frags")
+        keep.append(frags)
+        w.mixer_frags = frags.data_ptr()
         for name, mlp, out_rows, wf, bf, gf, lf in (
                 ("newt.mlp", m.newt.mlp, 256, w.newt_mlp_w, w.newt_mlp_b, w.newt_ln_g, w.newt_ln_b),
                 ("h_generator", m.h_generator, 129, w.hgen_w, w.hgen_b, w.hgen_ln_g, w.hgen_ln_b)):
