@@ -151,7 +151,7 @@ def main():
             extra["stage_ms"] = {nm: round(float(np.mean([ms2[i * 6 + s] for i in range(n.value)])), 4)
                                  for s, nm in enumerate(_lib.STAGE_NAMES)}
             _lib.lib().nws_profile_end()
-            if world == 1:
+            if world == 1 and a.batch1_iters > 0:
                 # config "batch=1, single MI355X, FastNEWT": latency / x real-time per utterance
                 f1, c1 = f0[:1].contiguous(), control[:1].contiguous()
                 for _ in range(10):

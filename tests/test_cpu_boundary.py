@@ -1,0 +1,167 @@
+"""CPU tests of the boundary: the C-ABI library loads and exports every symbol include/nws_hip.h declares,
+host-side planning functions, the gin reader, checkpoint loading, the module surface, loud failure without a GPU."""
+import ctypes as C
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+nws = importlib.import_module("neural-waveshaping-synthesis_amd")
+_lib = importlib.import_module("neural-waveshaping-synthesis_amd._lib")
+REF_GIN = "/root/reference/gin/models/newt.gin"
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "nws_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nws_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    handle = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in include/nws_hip.h but not exported"
+    # and the ctypes table binds exactly the declared set
+    assert sorted(_lib.EXPORTED_SYMBOLS) == declared
+
+
+def test_abi_version_and_error_strings():
+    L = _lib.lib()
+    assert L.nws_abi_version() == 1
+    assert b"unsupported" in L.nws_error_string(-1)
+    assert b"bad argument" in L.nws_error_string(-2)
+    assert L.nws_error_string(0) == b"ok"
+
+
+def test_struct_layouts_match_header_sizes():
+    # 8-byte pointers, 4-byte ints/floats; the C side static-sizes are implied by field order
+    assert C.sizeof(_lib.NwsReverbPlan) == 16
+    n_ptr = sum(1 for _, t in _lib.NwsWeights._fields_ if t is _lib._fp) + 4 * 4 + 3 * 4
+    assert C.sizeof(_lib.NwsWeights) == 8 * n_ptr + 16  # + lut_size, lut_min, lut_max (+4 pad)
+
+
+@pytest.mark.parametrize("N,L,N1,N2", [(64000, 64000, 125, 512), (256, 32000, 125, 256), (32000, 32000, 125, 256),
+                                       (128 * 501, 64128, 501, 128), (128 * 512, 65536, 64, 1024)])
+def test_reverb_plan_is_host_only(N, L, N1, N2):
+    plan = _lib.NwsReverbPlan()
+    assert _lib.lib().nws_reverb_plan(N, 32000, C.byref(plan)) == 0
+    assert (plan.L, plan.N1, plan.N2) == (L, N1, N2)
+    assert _lib.lib().nws_reverb_workspace_bytes(C.byref(plan), 3) == max(2 * 2 * L, 3 * L) * 4
+    assert _lib.lib().nws_reverb_spectrum_bytes(C.byref(plan)) == 2 * L * 4
+
+
+def test_reverb_plan_rejects_unsupported_lengths():
+    plan = _lib.NwsReverbPlan()
+    assert _lib.lib().nws_reverb_plan(100, 88200, C.byref(plan)) == -1   # 88200 = 2^3 * 11025: no power-of-two row FFT
+    assert _lib.lib().nws_reverb_plan(0, 32000, C.byref(plan)) == -2
+
+
+def test_bad_arguments_return_codes_without_touching_the_gpu():
+    L = _lib.lib()
+    assert L.nws_phase_carry(None, None, 1, 4, None, None) == -2
+    assert L.nws_control_gru(None, None, 1, 2, 4, None, None) == -2
+    assert L.nws_fir_noise(None, None, None, 1, 4, None, None) == -2
+    assert L.nws_forward_workspace_bytes(None, 1, 4) == 0
+
+
+def test_gin_reader_parses_reference_and_packaged_config():
+    gin = nws.gin
+    for path in ([REF_GIN] if os.path.exists(REF_GIN) else []) + [nws.DEFAULT_GIN]:
+        gin.clear_config()
+        gin.parse_config_file(path)
+        assert gin.query_parameter("%sample_rate") == 16000
+        assert gin.query_parameter("HarmonicOscillator.n_harmonics") == 101
+        assert gin.query_parameter("NEWT.shaping_fn_size") == 8
+        assert gin.query_parameter("noise_synth/TimeDistributedMLP.out_size") == 129
+        assert gin.query_parameter("Reverb.length_in_seconds") == 2
+
+
+def test_gin_scopes_macros_and_references():
+    gin = nws.gin
+
+    @gin.configurable
+    class Thing:
+        def __init__(self, a, b=1, c=None):
+            self.a, self.b, self.c = a, b, c
+
+    @gin.configurable("helper_fn")
+    def helper(x=0):
+        return x * 2
+
+    gin.parse_config("""
+        base = 7
+        Thing.a = %base
+        Thing.b = [1, 2.5, 'x']   # trailing comment
+        inner/Thing.a = -3
+        helper_fn.x = 21
+        Thing.c = @helper_fn()
+    """)
+    t = Thing()
+    assert (t.a, t.b, t.c) == (7, [1, 2.5, "x"], 42)
+    with gin.config_scope("inner"):
+        assert Thing().a == -3 and Thing().b == [1, 2.5, "x"]
+    assert Thing(a=5).a == 5          # explicit arguments win
+    with pytest.raises(TypeError):
+        gin.parse_config("Thing.nope = 1")
+        Thing()
+
+
+def test_module_surface_and_state_dict_keys(weights):
+    nws.gin.clear_config()
+    nws.ensure_default_config()
+    m = nws.NeuralWaveshaping()
+    sd = m.state_dict()
+    assert set(sd) == set(weights), set(sd) ^ set(weights)
+    for k, v in weights.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+        assert sd[k].dtype == torch.from_numpy(np.asarray(v)).dtype, k
+    assert sum(p.numel() for p in m.parameters()) == 266945
+    assert (m.sample_rate, m.control_hop) == (16000, 128)
+    for attr in ("embedding", "osc", "harmonic_mixer", "newt", "h_generator", "noise_synth", "reverb"):
+        assert hasattr(m, attr)
+    with pytest.raises(AssertionError):
+        nws.TimeDistributedMLP(8, 8, 8, depth=2)
+
+
+def test_checkpoint_loading_npz_and_lightning_ckpt(weights):
+    m = nws.NeuralWaveshaping.load_from_checkpoint(os.path.join(ROOT, "tests", "golden", "weights_vn.npz"))
+    for k, v in weights.items():
+        assert np.array_equal(m.state_dict()[k].numpy(), v), k
+    ck = "/root/reference/checkpoints/nws/vn/last.ckpt"
+    if os.path.exists(ck):   # build container only; the GPU box has no reference tree
+        m2 = nws.NeuralWaveshaping.load_from_checkpoint(ck)
+        for k, v in weights.items():
+            assert np.array_equal(m2.state_dict()[k].numpy(), v), k
+        assert m2.hparams["n_waveshapers"] == 64
+
+
+def test_no_cpu_fallback_anywhere():
+    m = nws.NeuralWaveshaping.load_from_checkpoint(os.path.join(ROOT, "tests", "golden", "weights_vn.npz"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 1, 4), torch.zeros(1, 2, 4))
+    with pytest.raises(RuntimeError):
+        m.render_exciter(torch.zeros(1, 1, 512))
+    with pytest.raises(RuntimeError):
+        m.get_embedding(torch.zeros(1, 2, 4))
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            nws.FastNEWT(m.newt)
+    for sub in (m.embedding, m.osc, m.newt, m.h_generator, m.noise_synth):
+        with pytest.raises(NotImplementedError):
+            sub(torch.zeros(1, 2, 4), torch.zeros(1, 2, 4)) if sub is m.newt else sub(torch.zeros(1, 2, 4))
+
+
+def test_product_path_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "neural-waveshaping-synthesis_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("oracle's", "").lower() or f in ("parallel.py",), (dirpath, f)

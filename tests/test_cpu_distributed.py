@@ -1,0 +1,67 @@
+"""world_size-2 gloo tests of the sharded render path (parallel.py): the shards of a batch rendered on two
+ranks and all-gathered equal the un-sharded render, with the two RNG draws shared across ranks.
+The single-device render function is injected (the oracle here, the HIP engine in production)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_npz
+
+par = importlib.import_module("neural-waveshaping-synthesis_amd.parallel")
+
+
+def test_shard_bounds_cover_batch_exactly():
+    for B in (1, 2, 5, 64, 512, 513):
+        for W in (1, 2, 3, 8):
+            spans = [par.shard_bounds(B, W, r) for r in range(W)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, B, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.newt_oracle import OracleNEWT
+        w = {k: v for k, v in load_npz("weights_vn.npz").items() if not k.startswith("__")}
+        oracle = OracleNEWT(w, fast=True, lut_python_loop=False)
+        T = 6
+        g = torch.Generator().manual_seed(5)          # same full batch on every rank
+        f0 = 150 + 500 * torch.rand(B, 1, T, generator=g)
+        control = torch.randn(B, 3, T, generator=g)
+        torch.manual_seed(100 + rank)                  # different per-rank generators: draws must still agree
+        pu, nz = par.shared_draws(101, 128 * T - 1, torch.device("cpu"))
+        render = lambda a, b, p, n: oracle(a, b, p, n)  # noqa: E731
+        full = par.render_sharded(render, f0, control, phase_u=pu, noise=nz)
+        out, work = par.render_sharded(render, f0, control, phase_u=pu, noise=nz, async_op=True)
+        if work is not None:
+            work.wait()
+        ref = oracle(f0, control, pu, nz)
+        np.save(os.path.join(tmp, f"r{rank}.npy"), np.stack([full.numpy(), out.numpy(), ref.numpy()]))
+        np.save(os.path.join(tmp, f"d{rank}.npy"), np.concatenate([pu.numpy(), nz.numpy()]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [4, 5])
+def test_two_rank_sharded_render_equals_unsharded(tmp_path, B):
+    port = 29500 + (os.getpid() % 2000) + B
+    mp.spawn(_worker, args=(2, port, B, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
+    d0, d1 = np.load(tmp_path / "d0.npy"), np.load(tmp_path / "d1.npy")
+    assert np.array_equal(d0, d1)                       # one draw, broadcast from rank 0
+    for r in (r0, r1):
+        assert r.shape[1] == B
+        assert np.array_equal(r[0], r[2])               # gathered shards == un-sharded render, bit for bit
+        assert np.array_equal(r[1], r[2])
+    assert np.array_equal(r0, r1)
