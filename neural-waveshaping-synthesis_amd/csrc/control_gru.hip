@@ -33,8 +33,6 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 // sigmoid / tanh from the hardware exp2 + reciprocal (each ~1 ulp): same error class as the
 // libm forms inside torch's CPU GRU, a fraction of their latency on the sequential critical path
 __device__ __forceinline__ float fast_sigmoid(float x) {

@@ -196,6 +196,33 @@ __device__ __forceinline__ float lut_shaper(const LutParams& P, int row_off, flo
   return (uv - lv) * fract + lv;
 }
 
+// two adjacent shapers (row_off, row_off + size) at once; index chain in packed fp32, rounding for rounding as above
+template <bool PAIRS, bool DIV6>
+__device__ __forceinline__ f32x2 lut_shaper2(const LutParams& P, int row_off, f32x2 x) {
+  const f32x2 t = splat2((float)P.size) * (x - splat2(P.tmin));
+  f32x2 idx;
+  if (DIV6) {
+    const f32x2 q = t * splat2(P.rcp_range);
+    const f32x2 r = fma2(-q, splat2(P.trange), t);
+    idx = fma2(r, splat2(P.rcp_range), q);
+  } else {
+    idx = f32x2{__fdiv_rn(t.x, P.trange), __fdiv_rn(t.y, P.trange)};
+  }
+  const float top = (float)(P.size - 1);
+  const f32x2 fl = {__builtin_amdgcn_fmed3f(floorf(idx.x), 0.0f, top), __builtin_amdgcn_fmed3f(floorf(idx.y), 0.0f, top)};
+  const f32x2 fract = idx - fl;
+  const int lo0 = (int)fl.x, lo1 = (int)fl.y;
+  if (PAIRS) {
+    const float2 a = P.pairs[(unsigned)(row_off + lo0)];
+    const float2 b = P.pairs[(unsigned)(row_off + P.size + lo1)];
+    return f32x2{a.y * fract.x + a.x, b.y * fract.y + b.x};
+  }
+  const int up0 = lo0 + 1 < P.size ? lo0 + 1 : P.size - 1, up1 = lo1 + 1 < P.size ? lo1 + 1 : P.size - 1;
+  const float l0 = P.table[(unsigned)(row_off + lo0)], u0 = P.table[(unsigned)(row_off + up0)];
+  const float l1 = P.table[(unsigned)(row_off + P.size + lo1)], u1 = P.table[(unsigned)(row_off + P.size + up1)];
+  return f32x2{(u0 - l0) * fract.x + l0, (u1 - l1) * fract.y + l1};
+}
+
 __device__ __forceinline__ LutParams make_lut_params(const NwsWeights& w) {
   LutParams P;
   P.table = w.lut;
@@ -212,10 +239,22 @@ __device__ __forceinline__ LutParams make_lut_params(const NwsWeights& w) {
 struct ExcLds {
   f16x8 whi[kKSteps * 2 * 2 * 32];
   f16x8 wlo[kKSteps * 2 * 2 * 32];
-  float4 film[3][kS];           // frames j-1, j, j+1 (clamped): {g_idx, b_idx, g_norm, b_norm} of shaper s
-  float2 shp[kS];               // {harmonic_mixer.bias[s], newt.mixer.weight[s]}
+  float film[3][4][kS];         // frames j-1, j, j+1 (clamped) x {g_idx, b_idx, g_norm, b_norm} x shaper (SoA: 4
+                                // consecutive shapers = one ds_read_b128 = two packed-fp32 operands)
+  float mix_b[kS];              // harmonic_mixer.bias
+  float out_w[kS];              // newt.mixer.weight
   float shift[kKPad];
 };
+
+// two sines at once: every step except rint and v_sin_f32 is a packed-fp32 instruction
+__device__ __forceinline__ f32x2 sin_turns2(f32x2 x) {
+  const f32x2 c_hi = splat2(0.15915493667125702f), c_lo = splat2(6.4206382432985265e-09f);
+  const f32x2 p = x * c_hi;
+  const f32x2 e = fma2(x, c_hi, -p);
+  const f32x2 r = {rintf(p.x), rintf(p.y)};
+  const f32x2 t = (p - r) + fma2(x, c_lo, e);
+  return f32x2{__builtin_amdgcn_sinf(t.x), __builtin_amdgcn_sinf(t.y)};
+}
 
 // v = hi + lo with hi, lo fp16 (lo exact residual rounded to fp16: ~2^-22 relative)
 __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
@@ -266,7 +305,8 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
     }
   }
   if (tid < kS) {
-    L.shp[tid] = make_float2(w.mixer_b[tid], MODE != kModeExciterOnly ? w.newt_out_w[tid] : 0.0f);
+    L.mix_b[tid] = w.mixer_b[tid];
+    L.out_w[tid] = MODE != kModeExciterOnly ? w.newt_out_w[tid] : 0.0f;
   }
   // _create_phase_shift (generators.py:54-56): fl(fl(u * rand_phase) - fl32(pi))
   if (tid < kKPad) L.shift[tid] = tid < kK ? phase_u[tid] * rand_phase[tid] - kPi : 0.0f;  // kKPad = 112 <= 256
@@ -275,7 +315,7 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
       const int q = e >> 8, c = e & 255;
       int f = j - 1 + q;
       f = f < 0 ? 0 : (f > T - 1 ? T - 1 : f);
-      reinterpret_cast<float*>(&L.film[q][c & 63])[c >> 6] = film[((size_t)b * T + f) * NWS_FILM_CH + c];
+      L.film[q][c >> 6][c & 63] = film[((size_t)b * T + f) * NWS_FILM_CH + c];
     }
   }
   if (MODE == kModeExact) load_shaper_lds(SH, w, tid, 256);
@@ -312,36 +352,58 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
     acc0[r] = 0.0f;
     acc1[r] = 0.0f;
   }
-  // no sine argument of this wave can exceed the fast reduction's range -> drop the per-sine range test
+  // no sine argument of this wave can exceed the fast reduction's range -> packed sines without range tests
   const bool small_args = __all(fabsf(phase) * (float)kKPad + 4.0f < 6.0e6f);
+  // anti-alias mask (generators.py:50-52): harmonic k is live iff fl(f0*k) < sr/2.  fl(f0*k) is monotone in k for
+  // f0 > 0, so the live set is a prefix 1..kmax; count it once per lane with the exact comparison.
+  int kmax;
+  if (!(f0n > 0.0f)) {
+    kmax = f0n == f0n ? kK : 0;  // f0 <= 0: every product is <= 0 < sr/2;  NaN: nothing is live
+  } else {
+    const float q = nyquist / f0n;
+    int kc = q > (float)kK ? kK : (int)q;
+    while (kc < kK && (f0n * (float)(kc + 1)) < nyquist) ++kc;
+    while (kc > 0 && !((f0n * (float)kc) < nyquist)) --kc;
+    kmax = kc;
+  }
   const int frag_lane = half * 32 + col;
+  const f32x2 ph2 = splat2(phase);
   for (int ks = 0; ks < kKSteps; ++ks) {
     const int kk0 = 16 * ks + 8 * half;
-    bool live[8];
-    bool any = false;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      // anti-alias mask on the upsampled F0 (generators.py:50-52); padding harmonics are dead
-      live[e] = (f0n * (float)(kk0 + e + 1)) < nyquist && (kk0 + e) < kK;
-      any |= live[e];
-    }
-    if (!__any(any)) break;  // k*f0 only grows with k: everything above is masked too
+    const int rem = kmax - kk0;        // this lane's live elements in the step: e < rem
+    if (!__any(rem > 0)) break;        // k*f0 only grows with k: everything above is masked too
+    const bool full = __all(rem >= 8);
     const float4 sh0 = *reinterpret_cast<const float4*>(&L.shift[kk0]);
     const float4 sh1 = *reinterpret_cast<const float4*>(&L.shift[kk0 + 4]);
-    const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
+    const f32x2 sh2[4] = {{sh0.x, sh0.y}, {sh0.z, sh0.w}, {sh1.x, sh1.y}, {sh1.z, sh1.w}};
+    const f32x2 kb2 = splat2((float)kk0);
+    f32x2 v2[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const f32x2 kf2 = kb2 + f32x2{(float)(2 * p + 1), (float)(2 * p + 2)};  // exact small integers
+      const f32x2 arg2 = kf2 * ph2 + sh2[p];  // fl(fl(k*phase) + shift): the reference's own rounding chain
+      if (DBG == 1) v2[p] = arg2;
+      else if (small_args) v2[p] = sin_turns2(arg2);
+      else v2[p] = f32x2{nws_sinf_fast(arg2.x), nws_sinf_fast(arg2.y)};
+    }
+    if (!full) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        v2[p].x = 2 * p < rem ? v2[p].x : 0.0f;
+        v2[p].y = 2 * p + 1 < rem ? v2[p].y : 0.0f;
+      }
+    }
+    // v = hi + lo, both fp16 (lo = exact residual rounded to fp16), packed two at a time
     f16x8 vhi, vlo;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float kf = (float)(kk0 + e + 1);
-      const float arg = kf * phase + sh[e];  // fl(fl(k*phase) + shift): the reference's own rounding chain
-      float v;
-      if (DBG == 1) v = arg;
-      else v = small_args ? nws_sin_turns(arg) : nws_sinf_fast(arg);
-      v = live[e] ? v : 0.0f;
-      _Float16 h, l;
-      split_f16(v, h, l);
-      vhi[e] = h;
-      vlo[e] = l;
+    for (int p = 0; p < 4; ++p) {
+      const f16x2 h2 = __builtin_convertvector(v2[p], f16x2);
+      const f32x2 back = __builtin_convertvector(h2, f32x2);
+      const f16x2 l2 = __builtin_convertvector(v2[p] - back, f16x2);
+      vhi[2 * p] = h2.x;
+      vhi[2 * p + 1] = h2.y;
+      vlo[2 * p] = l2.x;
+      vlo[2 * p + 1] = l2.y;
     }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -366,8 +428,8 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int s0 = (r & 3) + 8 * (r >> 2) + 4 * half;
-      exciter_out[((size_t)b * kS + s0) * N + n] = acc0[r] + L.shp[s0].x;
-      exciter_out[((size_t)b * kS + s0 + 32) * N + n] = acc1[r] + L.shp[s0 + 32].x;
+      exciter_out[((size_t)b * kS + s0) * N + n] = acc0[r] + L.mix_b[s0];
+      exciter_out[((size_t)b * kS + s0 + 32) * N + n] = acc1[r] + L.mix_b[s0 + 32];
     }
   }
   if (MODE == kModeExciterOnly) return;
@@ -381,40 +443,56 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
   }
 
   // ---- FiLM -> shaper -> FiLM -> 64->1 mix, all in registers ----
-  const float4* p0 = L.film[lc.i0 - (j - 1)];
-  const float4* p1 = L.film[lc.i1 - (j - 1)];
+  const float(*p0)[kS] = L.film[lc.i0 - (j - 1)];
+  const float(*p1)[kS] = L.film[lc.i1 - (j - 1)];
   LutParams LP;
   if (is_lut(MODE)) LP = make_lut_params(w);
   const int lane_row_off = is_lut(MODE) ? 4 * half * w.lut_size : 0;
-  float partial = 0.0f;
+  const f32x2 w0_2 = splat2(lc.w0), w1_2 = splat2(lc.w1);
+  f32x2 part2 = {0.0f, 0.0f};
+  // accumulator registers 4g..4g+3 of M-tile m are the 4 consecutive shapers 32m + 8g + 4half + 0..3
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int sb = 32 * m + (r & 3) + 8 * (r >> 2);  // compile-time part of the shaper index
-      const int s0 = sb + 4 * half;
-      const float2 sp = L.shp[s0];
-      const float x = (m == 0 ? acc0[r] : acc1[r]) + sp.x;
-      const float4 a = p0[s0], c = p1[s0];
-      const float g_i = nws_lerp(a.x, c.x, lc.w0, lc.w1);
-      const float b_i = nws_lerp(a.y, c.y, lc.w0, lc.w1);
-      const float g_n = nws_lerp(a.z, c.z, lc.w0, lc.w1);
-      const float b_n = nws_lerp(a.w, c.w, lc.w0, lc.w1);
-      const float xi = g_i * x + b_i;  // FiLM (models/modules/dynamic.py:8)
-      float sh;
-      if (DBG == 2) {
-        sh = xi;
-      } else if (is_lut(MODE)) {
-        sh = lut_shaper<MODE != kModeLut, MODE == kModeLutPairsDiv6>(LP, sb * LP.size + lane_row_off, xi);
-      } else {
-        sh = exact_shaper(SH, s0, xi);
+    for (int g = 0; g < 4; ++g) {
+      const int sb = 32 * m + 8 * g;  // compile-time part of the shaper index
+      const int s4 = sb + 4 * half;
+      const float4 mb = *reinterpret_cast<const float4*>(&L.mix_b[s4]);
+      const float4 ow = *reinterpret_cast<const float4*>(&L.out_w[s4]);
+      float4 fa[4], fc[4];
+#pragma unroll
+      for (int ty = 0; ty < 4; ++ty) {
+        fa[ty] = *reinterpret_cast<const float4*>(&p0[ty][s4]);
+        fc[ty] = *reinterpret_cast<const float4*>(&p1[ty][s4]);
       }
-      const float y = g_n * sh + b_n;
-      partial = fmaf(sp.y, y, partial);
-      // fence the scheduler every 8 pairs: at most 8 gathers (+ their FiLM operands) are live at once
-      if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {  // shaper pairs (s4, s4+1) and (s4+2, s4+3)
+        const int r0 = 4 * g + 2 * h2;
+        const f32x2 accp = m == 0 ? f32x2{acc0[r0], acc0[r0 + 1]} : f32x2{acc1[r0], acc1[r0 + 1]};
+        const f32x2 x2 = accp + (h2 == 0 ? f32x2{mb.x, mb.y} : f32x2{mb.z, mb.w});
+#define NWS_PAIR(v) (h2 == 0 ? f32x2{(v).x, (v).y} : f32x2{(v).z, (v).w})
+        const f32x2 g_i = fma2(w0_2, NWS_PAIR(fa[0]), w1_2 * NWS_PAIR(fc[0]));  // F.upsample of the FiLM parameters
+        const f32x2 b_i = fma2(w0_2, NWS_PAIR(fa[1]), w1_2 * NWS_PAIR(fc[1]));
+        const f32x2 g_n = fma2(w0_2, NWS_PAIR(fa[2]), w1_2 * NWS_PAIR(fc[2]));
+        const f32x2 b_n = fma2(w0_2, NWS_PAIR(fa[3]), w1_2 * NWS_PAIR(fc[3]));
+        const f32x2 xi = g_i * x2 + b_i;  // FiLM (models/modules/dynamic.py:8)
+        f32x2 sh;
+        if (DBG == 2) {
+          sh = xi;
+        } else if (is_lut(MODE)) {
+          sh = lut_shaper2<MODE != kModeLut, MODE == kModeLutPairsDiv6>(LP, (sb + 2 * h2) * LP.size + lane_row_off, xi);
+        } else {
+          sh = f32x2{exact_shaper(SH, s4 + 2 * h2, xi.x), exact_shaper(SH, s4 + 2 * h2 + 1, xi.y)};
+        }
+        const f32x2 y = g_n * sh + b_n;
+        part2 = fma2(NWS_PAIR(ow), y, part2);
+#undef NWS_PAIR
+      }
+      // fence the scheduler per group of 4 shapers: bounded number of gathers / FiLM operands live at once
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
+  const float partial = part2.x + part2.y;
   const float total = partial + nws_swap_halves(partial) + w.newt_out_b[0];
   if (half == 0) newt_out[(size_t)b * N + n] = total;
 }

@@ -13,6 +13,7 @@
 
 #define NWS_WAVE 64
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));  // one v_pk_*_f32 operand
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -111,6 +112,9 @@ __device__ __forceinline__ float nws_sinf_fast(float x) {
   if (__builtin_expect(fabsf(x) > 6.0e6f, 0)) return nws_sinf_huge(x);
   return nws_sin_turns(x);
 }
+
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
 
 // 32-lane-half exchange (lane l <-> lane l^32)
 __device__ __forceinline__ float nws_swap_halves(float v) { return __shfl_xor(v, 32, 64); }
