@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=60)
     ap.add_argument("--batch1-iters", type=int, default=200)
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the steps are issued on round-robin (independent forwards overlap: the GRU of "
+                         "step i+1 only occupies B CUs while step i's sample-rate kernels fill the rest)")
     return ap.parse_args()
 
 
@@ -95,17 +98,25 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     f0 = torch.rand(B, 1, T, device=dev, generator=g)         # time_forward_pass.py:34-40
     control = torch.rand(B, 2, T, device=dev, generator=g)    # time_forward_pass.py:27-33
-    full = [torch.empty((B * world, N), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
+
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, a.streams))]
+    full = [torch.empty((B * world, N), dtype=torch.float32, device=dev) for _ in streams] if world > 1 else None
 
     def step(i, pending):
-        if world > 1:
-            pu, nz = par.shared_draws(101, N - 1, dev)       # identical draws on all ranks
-            y = model(f0, control, phase_u=pu, noise=nz)
-            if pending is not None:
-                pending.wait()
-            return dist.all_gather_into_tensor(full[i & 1], y, async_op=True)
-        model(f0, control)
+        s = streams[i % len(streams)]
+        with torch.cuda.stream(s):
+            if world > 1:
+                pu, nz = par.shared_draws(101, N - 1, dev)       # identical draws on all ranks
+                y = model(f0, control, phase_u=pu, noise=nz)
+                if pending is not None:
+                    pending.wait()
+                return dist.all_gather_into_tensor(full[i % len(streams)], y, async_op=True)
+            model(f0, control)
         return None
+
+    def join_streams():
+        for s in streams:
+            torch.cuda.current_stream().wait_stream(s)
 
     with torch.no_grad():
         pending = None
@@ -113,6 +124,7 @@ def main():
             pending = step(i, pending)
         if pending is not None:
             pending.wait()
+        join_streams()
         torch.cuda.synchronize()
         # live HIP-event timing of the dominant kernel on its launch stream, inside the timed region
         _lib.check(_lib.lib().nws_profile_begin(a.steps, 1 << 3))
@@ -125,6 +137,7 @@ def main():
             pending = step(i, pending)
         if pending is not None:
             pending.wait()
+        join_streams()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -184,7 +197,8 @@ def main():
             "config": {"workload": f"NEWT forward, vn checkpoint, {'exact sin-MLP shapers' if a.exact else 'FastNEWT LUT'}, "
                                    f"batch {B}/GPU x {T} frames (4 s @ 16 kHz), torch.rand F0/control, "
                                    f"RNG draws on device{', RCCL all-gather of waveforms' if world > 1 else ''}",
-                       "batch_per_gpu": B, "frames": T, "samples_per_utterance": N, "parallelism": f"batch-shard x{world}"},
+                       "batch_per_gpu": B, "frames": T, "samples_per_utterance": N, "parallelism": f"batch-shard x{world}",
+                       "streams": len(streams)},
             "x_realtime_aggregate": value / 16000.0,
             "rtf_per_utterance": (ms_per_step * 1e-3) / (N / 16000.0) / B,
             "roofline": {"bound": "mfma", "kernel": "exciter_newt_kernel", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,

@@ -69,6 +69,9 @@ typedef struct NwsWeights {
   const float* hgen_b[4];
   const float* hgen_ln_g[3];
   const float* hgen_ln_b[3];
+  /* optional 819200 B from nws_mlp_frags(): proj / newt.mlp / h_generator / FIR-design weights as two fp16 terms in MFMA
+   * fragment order -> frame MLPs on the fp16 matrix pipe; NULL -> exact-fp32 MFMA kernel */
+  const void* mlp_frags;
   /* newt.shaping_fn = TrainableNonlinearity(64, 8, depth=4) (models/modules/shaping.py:15-37) */
   const float* shaper_in_scale; /* (64) */
   const float* shaper_w0; /* (512)    net.0.weight (512,1,1) */
@@ -145,6 +148,11 @@ int nws_control_gru(const NwsWeights* w, const float* control, int B, int C, int
  */
 int nws_frame_mlps(const NwsWeights* w, const float* gru_out, const float* fir_design, int B, int T,
                    float* emb_out, float* film_out, float* H_out, float* fir_out, void* stream);
+
+/* pre-split weight fragments for the fp16 two-term frame-MLP kernel (valid while |layer inputs| stay inside fp16 range:
+ * the caller checks the weight-norm bounds, see engine.py) */
+#define NWS_MLP_FRAGS_BYTES 819200
+int nws_mlp_frags(const NwsWeights* w, const float* fir_design /* (256,132) */, void* frags_out, void* stream);
 
 /* D[n][k]: fir[n] = sum_k D[n][k] H[k]  (irfft + roll(128) + window folded), (256, 132) fp32, cols 129..131 = 0. */
 int nws_fir_design_matrix(const float* window /* (256) */, float* D_out, void* stream);

@@ -30,6 +30,7 @@ class NwsWeights(C.Structure):
         ("mixer_w", _fp), ("mixer_b", _fp), ("mixer_frags", _fp),
         ("newt_mlp_w", _fp * 4), ("newt_mlp_b", _fp * 4), ("newt_ln_g", _fp * 3), ("newt_ln_b", _fp * 3),
         ("hgen_w", _fp * 4), ("hgen_b", _fp * 4), ("hgen_ln_g", _fp * 3), ("hgen_ln_b", _fp * 3),
+        ("mlp_frags", _fp),
         ("shaper_in_scale", _fp),
         ("shaper_w0", _fp), ("shaper_b0", _fp), ("shaper_w2", _fp), ("shaper_b2", _fp),
         ("shaper_w4", _fp), ("shaper_b4", _fp), ("shaper_w6", _fp), ("shaper_b6", _fp),
@@ -58,6 +59,7 @@ _PROTOTYPES = {
                                    _fp, _fp, _fp]),
     "nws_control_gru": (C.c_int, [C.POINTER(NwsWeights), _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "nws_frame_mlps": (C.c_int, [C.POINTER(NwsWeights), _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp]),
+    "nws_mlp_frags": (C.c_int, [C.POINTER(NwsWeights), _fp, _fp, _fp]),
     "nws_fir_design_matrix": (C.c_int, [_fp, _fp, _fp]),
     "nws_fir_noise": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp]),
     "nws_reverb_plan": (C.c_int, [C.c_int, C.c_int, C.POINTER(NwsReverbPlan)]),

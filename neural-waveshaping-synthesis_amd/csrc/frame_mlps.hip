@@ -220,6 +220,268 @@ __global__ __launch_bounds__(256) void frame_mlps_kernel(NwsWeights w, const flo
   }
 }
 
+// =============================================================================================
+// fp16 two-term-split variant (default): every layer on v_mfma_f32_32x32x16_f16.
+//   W = W_hi + W_lo  pre-split once per weight version into A-fragment order (nws_mlp_frags, 800 KB),
+//   X = X_hi + X_lo  kept in LDS TRANSPOSED (XT[frame][channel], fp16, row stride 304 B -> the B fragment
+//                    of lane (frame j, half h) at K-step ks is ONE conflict-free ds_read_b128),
+//   W X ~= W_hi X_hi + W_hi X_lo + W_lo X_hi  (22+ bits per product, fp32 accumulate).
+// 24 MFMAs of 32 cycles per 32x128 tile instead of 64 fp32 MFMAs of 64 cycles.  Inputs of every layer are
+// bounded by weight norms (|gru| < 1, LayerNorm outputs <= sqrt(127)|gamma|+|beta|); the host checks those
+// bounds against the fp16 range and falls back to the exact-fp32 kernel above otherwise.
+// =============================================================================================
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kRowB = 304;  // bytes per frame row of an XT buffer (144 halfs + 16 B pad: 19 x 16 B, odd -> no conflicts)
+constexpr int kXtBytes = kFT * kRowB;
+
+// fragment-table geometry (units of f16x8); per (M-tile, K-step): 64 hi fragments then 64 lo fragments
+struct FragMap {
+  int base, mt, ks;
+};
+__host__ __device__ constexpr FragMap frag_map(int id) {
+  // 0 proj | 1-3 newt hidden | 4 newt out (256) | 5-7 hgen hidden | 8 hgen out (129 -> 160) | 9 FIR design (K 132 -> 144)
+  return id == 0 ? FragMap{0, 4, 8}
+       : id <= 3 ? FragMap{4096 * id, 4, 8}
+       : id == 4 ? FragMap{16384, 8, 8}
+       : id <= 7 ? FragMap{24576 + 4096 * (id - 5), 4, 8}
+       : id == 8 ? FragMap{36864, 5, 8}
+                 : FragMap{41984, 8, 9};
+}
+constexpr int kFragTotal = 51200;  // x 16 B = 819200 B
+
+struct MlpLds16 {
+  char emb[2][kXtBytes];  // [hi|lo]
+  char p0[2][kXtBytes];
+  char p1[2][kXtBytes];
+  float stage[4][kFT * kXS];
+  float red[2][4][kFT];
+};
+
+__device__ __forceinline__ void split4_store(char* xt_hi, char* xt_lo, int frame, int ch, float a, float b, float c, float d) {
+  f16x4 h, l;
+  const float v[4] = {a, b, c, d};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = (_Float16)v[i];
+    l[i] = (_Float16)(v[i] - (float)h[i]);
+  }
+  *reinterpret_cast<f16x4*>(xt_hi + frame * kRowB + ch * 2) = h;
+  *reinterpret_cast<f16x4*>(xt_lo + frame * kRowB + ch * 2) = l;
+}
+
+// acc(32 rows x 32 frames) = W[M-tile mt of map] * X  for the XT buffer (hi, lo)
+template <int KS>
+__device__ __forceinline__ void gemm_tile16(const f16x8* __restrict__ frags, int mt, const char* xt_hi,
+                                            const char* xt_lo, int lane, f32x16& acc) {
+  const int half = lane >> 5, col = lane & 31;
+  const f16x8* a = frags + (size_t)mt * KS * 128 + lane;
+  f16x8 ahi[KS], alo[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    ahi[ks] = a[ks * 128];
+    alo[ks] = a[ks * 128 + 64];
+  }
+  f32x16 cross;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    acc[r] = 0.0f;
+    cross[r] = 0.0f;
+  }
+  const char* bh = xt_hi + col * kRowB + half * 16;
+  const char* bl = xt_lo + col * kRowB + half * 16;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const f16x8 xh = *reinterpret_cast<const f16x8*>(bh + ks * 32);
+    const f16x8 xl = *reinterpret_cast<const f16x8*>(bl + ks * 32);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], xh, acc, 0, 0, 0);
+    cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], xl, cross, 0, 0, 0);
+    cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], xh, cross, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += cross[r];
+}
+
+// write a 32-channel x 32-frame tile held in the D layout into an XT buffer (4 consecutive channels per store)
+__device__ __forceinline__ void store_tile_xt(char* xt_hi, char* xt_lo, int c0, const float v[16], int lane) {
+  const int half = lane >> 5, col = lane & 31;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    split4_store(xt_hi, xt_lo, col, c0 + 8 * g + 4 * half, v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+}
+
+__device__ __forceinline__ void hidden_layer16(MlpLds16& L, const f16x8* frags, const float* bias, const float* ln_g,
+                                               const float* ln_b, const char* in_hi, const char* in_lo, char* out_hi,
+                                               char* out_lo, int wave, int lane) {
+  const int half = lane >> 5, col = lane & 31;
+  f32x16 acc;
+  gemm_tile16<8>(frags, wave, in_hi, in_lo, lane, acc);
+  float v[16];
+  float s = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    v[r] = acc[r] + bias[32 * wave + frag_row(r, half)];
+    s += v[r];
+  }
+  s += nws_swap_halves(s);
+  if (half == 0) L.red[0][wave][col] = s;
+  __syncthreads();
+  const float mean = ((L.red[0][0][col] + L.red[0][1][col]) + (L.red[0][2][col] + L.red[0][3][col])) * (1.0f / NWS_HIDDEN);
+  float q = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float d = v[r] - mean;
+    q = fmaf(d, d, q);
+  }
+  q += nws_swap_halves(q);
+  if (half == 0) L.red[1][wave][col] = q;
+  __syncthreads();
+  const float var = ((L.red[1][0][col] + L.red[1][1][col]) + (L.red[1][2][col] + L.red[1][3][col])) * (1.0f / NWS_HIDDEN);
+  const float rstd = 1.0f / sqrtf(var + kLnEps);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int c = 32 * wave + frag_row(r, half);
+    v[r] = nws_leaky_relu((v[r] - mean) * rstd * ln_g[c] + ln_b[c]);
+  }
+  store_tile_xt(out_hi, out_lo, 32 * wave, v, lane);
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void frame_mlps16_kernel(NwsWeights w, const float* __restrict__ gru_out, int T,
+                                                           float* __restrict__ emb_out, float* __restrict__ film_out,
+                                                           float* __restrict__ H_out, float* __restrict__ fir_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  MlpLds16& L = *reinterpret_cast<MlpLds16*>(smem_raw);
+  const f16x8* F = reinterpret_cast<const f16x8*>(w.mlp_frags);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * kFT;
+  const int frames_valid = T - t0 < kFT ? T - t0 : kFT;
+
+  // ---- gru_out tile -> XT p0 (4 channels per thread per pass) ----
+  for (int e = tid; e < kFT * (NWS_HIDDEN / 4); e += 256) {
+    const int f = e >> 5, c4 = (e & 31) * 4;
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (f < frames_valid) v = *reinterpret_cast<const float4*>(&gru_out[((size_t)b * T + t0 + f) * NWS_HIDDEN + c4]);
+    split4_store(L.p0[0], L.p0[1], f, c4, v.x, v.y, v.z, v.w);
+  }
+  // zero the K padding (channels 128..143) of p1, which will hold H for the FIR-design contraction
+  for (int e = tid; e < kFT * 2 * 2; e += 256) {
+    const int f = e >> 2, part = e & 3;
+    *reinterpret_cast<float4*>(L.p1[part >> 1] + f * kRowB + 256 + (part & 1) * 16) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+  __syncthreads();
+
+  // ---- emb = proj(gru_out) ----
+  {
+    f32x16 acc;
+    gemm_tile16<8>(F + frag_map(0).base, wave, L.p0[0], L.p0[1], lane, acc);
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = 32 * wave + frag_row(r, half);
+      v[r] = acc[r] + w.proj_b[c];
+      if (emb_out != nullptr && col < frames_valid) emb_out[((size_t)b * NWS_HIDDEN + c) * T + t0 + col] = v[r];
+    }
+    store_tile_xt(L.emb[0], L.emb[1], 32 * wave, v, lane);
+  }
+  __syncthreads();
+
+  // ---- film = newt.mlp(emb) ----
+  hidden_layer16(L, F + frag_map(1).base, w.newt_mlp_b[0], w.newt_ln_g[0], w.newt_ln_b[0], L.emb[0], L.emb[1], L.p0[0], L.p0[1], wave, lane);
+  hidden_layer16(L, F + frag_map(2).base, w.newt_mlp_b[1], w.newt_ln_g[1], w.newt_ln_b[1], L.p0[0], L.p0[1], L.p1[0], L.p1[1], wave, lane);
+  hidden_layer16(L, F + frag_map(3).base, w.newt_mlp_b[2], w.newt_ln_g[2], w.newt_ln_b[2], L.p1[0], L.p1[1], L.p0[0], L.p0[1], wave, lane);
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const int mt = wave + 4 * pass;
+    f32x16 acc;
+    gemm_tile16<8>(F + frag_map(4).base, mt, L.p0[0], L.p0[1], lane, acc);
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc[r] + w.newt_mlp_b[3][32 * mt + frag_row(r, half)];
+    store_tile_frame_major(L.stage[wave], v, lane, film_out + ((size_t)b * T + t0) * NWS_FILM_CH + 32 * mt, NWS_FILM_CH,
+                           frames_valid);
+  }
+  __syncthreads();
+
+  // ---- H = h_generator(emb) ----
+  hidden_layer16(L, F + frag_map(5).base, w.hgen_b[0], w.hgen_ln_g[0], w.hgen_ln_b[0], L.emb[0], L.emb[1], L.p0[0], L.p0[1], wave, lane);
+  hidden_layer16(L, F + frag_map(6).base, w.hgen_b[1], w.hgen_ln_g[1], w.hgen_ln_b[1], L.p0[0], L.p0[1], L.p1[0], L.p1[1], wave, lane);
+  hidden_layer16(L, F + frag_map(7).base, w.hgen_b[2], w.hgen_ln_g[2], w.hgen_ln_b[2], L.p1[0], L.p1[1], L.p0[0], L.p0[1], wave, lane);
+  // 129 outputs: M-tiles 0..3 by the four waves, M-tile 4 (row 128 only) by wave 0; H -> p1 channels 0..128,
+  // channels 129..143 stay zero (tile 4 stores rows 128..143: row 128 = H[128], the rest computes to 0 from zero weights
+  // and a zero bias, keeping the padding clean)
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1 && wave != 0) break;
+    const int mt = pass == 0 ? wave : 4;
+    f32x16 acc;
+    gemm_tile16<8>(F + frag_map(8).base, mt, L.p0[0], L.p0[1], lane, acc);
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = 32 * mt + frag_row(r, half);
+      v[r] = c < NWS_N_BANDS ? acc[r] + w.hgen_b[3][c] : 0.0f;
+      if (H_out != nullptr && c < NWS_N_BANDS && col < frames_valid) H_out[((size_t)b * T + t0 + col) * NWS_N_BANDS + c] = v[r];
+    }
+    if (mt < 4) {
+      store_tile_xt(L.p1[0], L.p1[1], 32 * mt, v, lane);
+    } else {  // rows 128..143 only (g = 0, 1): the XT row holds 144 channels
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+        split4_store(L.p1[0], L.p1[1], col, 128 + 8 * g + 4 * half, v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+    }
+  }
+  __syncthreads();
+
+  // ---- fir = D * H  (256 taps, K = 144 padded) ----
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const int mt = wave + 4 * pass;
+    f32x16 acc;
+    gemm_tile16<9>(F + frag_map(9).base, mt, L.p1[0], L.p1[1], lane, acc);
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc[r];
+    store_tile_frame_major(L.stage[wave], v, lane, fir_out + ((size_t)b * T + t0) * NWS_FIR_LEN + 32 * mt, NWS_FIR_LEN,
+                           frames_valid);
+  }
+}
+
+// one thread per fragment pair: 8 consecutive-k weights of one row, split into hi / lo
+__global__ void mlp_frags_kernel(NwsWeights w, const float* __restrict__ fir_design, f16x8* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= kFragTotal / 2) return;
+  // locate the map: entries are counted in (hi,lo) PAIRS here, so bases are halved
+  int id = 9;
+#pragma unroll
+  for (int i = 9; i >= 0; --i)
+    if (e < (i == 9 ? kFragTotal / 2 : frag_map(i + 1).base / 2)) id = i;
+  const FragMap m = frag_map(id);
+  const int local = e - m.base / 2;          // [mt][ks][h*32 + i]
+  const int li = local & 63, ks = (local >> 6) % m.ks, mt = (local >> 6) / m.ks;
+  const int row = 32 * mt + (li & 31), k0 = 16 * ks + 8 * (li >> 5);
+  const float* W;
+  int rows, ld, kmax;
+  if (id == 0) { W = w.proj_w; rows = 128; ld = 128; kmax = 128; }
+  else if (id <= 4) { W = w.newt_mlp_w[id - 1]; rows = id == 4 ? 256 : 128; ld = 128; kmax = 128; }
+  else if (id <= 8) { W = w.hgen_w[id - 5]; rows = id == 8 ? NWS_N_BANDS : 128; ld = 128; kmax = 128; }
+  else { W = fir_design; rows = NWS_FIR_LEN; ld = kDK; kmax = NWS_N_BANDS; }
+  f16x8 hi, lo;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = k0 + i;
+    const float v = (row < rows && k < kmax) ? W[(size_t)row * ld + k] : 0.0f;
+    hi[i] = (_Float16)v;
+    lo[i] = (_Float16)(v - (float)hi[i]);
+  }
+  f16x8* dst = out + m.base + ((size_t)mt * m.ks + ks) * 128 + li;
+  dst[0] = hi;
+  dst[64] = lo;
+}
+
 // D[n][k] (256 x 132): fir[n] = window[n] * h0[(n - 128) mod 256],
 //   h0[m] = irfft(H)[m] = (1/256) (H_0 + (-1)^m H_128 + 2 sum_{k=1}^{127} H_k cos(2 pi k m / 256))
 __global__ void fir_design_kernel(const float* __restrict__ window, float* __restrict__ D) {
@@ -248,6 +510,16 @@ int nws_fir_design_matrix(const float* window, float* D_out, void* stream) {
   return NWS_OK;
 }
 
+int nws_mlp_frags(const NwsWeights* w, const float* fir_design, void* frags_out, void* stream) {
+  if (!w || !fir_design || !frags_out || !w->proj_w) return NWS_ERR_BAD_ARG;
+  for (int i = 0; i < 4; ++i)
+    if (!w->newt_mlp_w[i] || !w->hgen_w[i]) return NWS_ERR_BAD_ARG;
+  mlp_frags_kernel<<<(kFragTotal / 2 + 255) / 256, 256, 0, (hipStream_t)stream>>>(*w, fir_design,
+                                                                                   static_cast<f16x8*>(frags_out));
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
 int nws_frame_mlps(const NwsWeights* w, const float* gru_out, const float* fir_design, int B, int T, float* emb_out,
                    float* film_out, float* H_out, float* fir_out, void* stream) {
   if (!w || !gru_out || !fir_design || !film_out || !fir_out || B <= 0 || T <= 0) return NWS_ERR_BAD_ARG;
@@ -262,11 +534,18 @@ int nws_frame_mlps(const NwsWeights* w, const float* gru_out, const float* fir_d
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_mlps_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpLds));
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_mlps16_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpLds16));
+    if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   const dim3 grid((T + kFT - 1) / kFT, B);
-  frame_mlps_kernel<<<grid, 256, sizeof(MlpLds), (hipStream_t)stream>>>(*w, gru_out, fir_design, T, emb_out, film_out,
-                                                                        H_out, fir_out);
+  if (w->mlp_frags != nullptr)
+    frame_mlps16_kernel<<<grid, 256, sizeof(MlpLds16), (hipStream_t)stream>>>(*w, gru_out, T, emb_out, film_out, H_out,
+                                                                              fir_out);
+  else
+    frame_mlps_kernel<<<grid, 256, sizeof(MlpLds), (hipStream_t)stream>>>(*w, gru_out, fir_design, T, emb_out, film_out,
+                                                                          H_out, fir_out);
   NWS_CHECK_LAUNCH();
   return NWS_OK;
 }

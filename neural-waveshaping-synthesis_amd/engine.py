@@ -8,6 +8,7 @@ device RNG that the reference itself draws from inside forward().
 from __future__ import annotations
 
 import ctypes as C
+import math
 
 import torch
 
@@ -135,6 +136,18 @@ class Engine:
         w.newt_out_w = P(m.newt.mixer[0].weight, "newt.mixer.0.weight", 64)
         w.newt_out_b = P(m.newt.mixer[0].bias, "newt.mixer.0.bias", 1)
         w.noise_window = P(m.noise_synth.window, "noise_synth.window", 256)
+        # FIR design matrix (weights-independent apart from the window buffer) and, when every layer input provably
+        # stays inside fp16 range, the pre-split fp16 fragment table that moves the frame MLPs to the fp16 matrix pipe
+        fd = torch.empty(_lib.FIR_LEN * _lib.FIR_DESIGN_COLS, dtype=torch.float32, device=keep[0].device)
+        check(_lib.lib().nws_fir_design_matrix(w.noise_window, ptr(fd), stream_ptr()), "nws_fir_design_matrix")
+        self._fir_design = fd
+        keep.append(fd)
+        w.mlp_frags = None
+        if self.fp16_mlp_safe():
+            frags = torch.empty(819200, dtype=torch.uint8, device=fd.device)
+            check(_lib.lib().nws_mlp_frags(C.byref(w), ptr(fd), ptr(frags), stream_ptr()), "nws_mlp_frags")
+            keep.append(frags)
+            w.mlp_frags = frags.data_ptr()
         keep.append(_req(m.osc.rand_phase.detach(), "osc.rand_phase", 101))
         keep.append(_req(m.reverb.ir.detach(), "reverb.ir"))
         devs = {t.device for t in keep}
@@ -142,6 +155,26 @@ class Engine:
             raise RuntimeError(f"model parameters are spread over several devices: {devs}")
         self._w = (w, keep, next(iter(devs)))
         return self._w
+
+    def fp16_mlp_safe(self, limit: float = 3.0e4) -> bool:
+        """Worst-case magnitude of every frame-MLP layer input, from weight norms (one-time host check).
+        |gru_out| < 1; emb rows <= ||W_proj||_1 + |b|; LayerNorm outputs <= sqrt(C-1)|gamma| + |beta|;
+        H rows <= ||W_9||_1 * ln_bound + |b_9|.  All must stay well inside fp16 range for the two-term split."""
+        m = self._model_ref
+        with torch.no_grad():
+            def l1(wt, b, scale):
+                return float((wt.detach().abs().flatten(1).sum(1) * scale + b.detach().abs()).max())
+
+            def ln(mod):
+                return float(math.sqrt(_lib.HIDDEN - 1) * mod.layer_norm.weight.detach().abs().max()
+                             + mod.layer_norm.bias.detach().abs().max())
+
+            bounds = [l1(m.embedding.proj.weight, m.embedding.proj.bias, 1.0)]
+            for mlp in (m.newt.mlp, m.h_generator):
+                bounds += [ln(mlp.net[1]), ln(mlp.net[4]), ln(mlp.net[7])]
+            bounds.append(l1(m.h_generator.net[9].weight, m.h_generator.net[9].bias, ln(m.h_generator.net[7])))
+            wmax = max(float(p.detach().abs().max()) for mlp in (m.newt.mlp, m.h_generator) for p in mlp.parameters())
+        return max(bounds + [wmax]) < limit and all(b == b for b in bounds)
 
     @property
     def device(self):
@@ -155,11 +188,7 @@ class Engine:
 
     # ---- weight-independent / cached tables ----------------------------------------------------
     def fir_design(self):
-        if self._fir_design is None:
-            w, _, dev = self.weights()
-            d = torch.empty(_lib.FIR_LEN * _lib.FIR_DESIGN_COLS, dtype=torch.float32, device=dev)
-            check(_lib.lib().nws_fir_design_matrix(w.noise_window, ptr(d), stream_ptr()), "nws_fir_design_matrix")
-            self._fir_design = d
+        self.weights()
         return self._fir_design
 
     def reverb_aux(self, n_samples: int):
@@ -253,7 +282,7 @@ class Engine:
         B, Cc, T = control.shape
         N = T * _lib.HOP
         plan, tables, spec = self.reverb_aux(N)
-        key = (B, T)
+        key = (B, T, stream_ptr())   # one scratch arena per stream: forwards on different streams may overlap
         ws = self._workspaces.get(key)
         if ws is None:
             nbytes = _lib.lib().nws_forward_workspace_bytes(C.byref(plan), B, T)

@@ -148,6 +148,23 @@ def test_gru_and_frame_mlps(models, oracle, weights):
     assert maxabs(emb.cpu().numpy(), g["embedding"]) <= 1e-5
 
 
+def test_frame_mlps_fp32_fallback_kernel(models, oracle):
+    """The exact-fp32 MFMA kernel (used when weight norms could overflow the fp16 two-term split) stays correct."""
+    m = build_model(False)
+    m._engine.fp16_mlp_safe = lambda *a, **k: False
+    m.invalidate_cache()
+    assert not m._engine.weights()[0].mlp_frags
+    g = load_npz("g1_realistic.npz")
+    st = {}
+    oracle[0](g["f0"], g["control"], g["phase_u"], g["noise"], stages=st)
+    emb, film, H, fir = m._engine.frame_mlps(st["gru_out"].contiguous().cuda(), want_emb=True, want_H=True)
+    assert maxabs(emb.cpu().numpy(), st["embedding"].numpy()) <= 1e-5
+    assert maxabs(film.cpu().numpy(), st["film"].numpy().transpose(0, 2, 1)) <= 5e-5
+    assert maxabs(H.cpu().numpy(), st["H"].numpy().transpose(0, 2, 1)) <= 5e-5
+    y = m(dev(g["f0"]), dev(g["control"]), phase_u=dev(g["phase_u"]), noise=dev(g["noise"])).cpu().numpy()
+    assert rms(y - g["y_newt"]) <= 1e-4
+
+
 def test_fir_noise_stage(models, oracle):
     m, _ = models
     g1 = load_npz("g1_realistic.npz")
