@@ -3,9 +3,10 @@
 //
 // Design: a hand-written four-step FFT of length L = N1 * N2 (N2 = largest power of
 // two dividing L, <= 1024; L = 64000 -> 125 x 512, L = 32000 -> 125 x 256):
-//   (1) column DFT over n1 (size N1, any integer) as a dense fp32 MFMA contraction against a cached
-//       DFT matrix  -- exact-fp32 v_mfma_f32_32x32x2_f32, the complex product written as a real
-//       [2N1 x 2N1] matrix so that one MFMA step consumes (re, im) of one input row;
+//   (1) column DFT over n1: for N1 = 125 (every standard size) three radix-5 Stockham stages in LDS on a
+//       125 x 32-column tile; for any other N1 a dense fp32 MFMA contraction against a cached DFT matrix
+//       (exact-fp32 v_mfma_f32_32x32x2_f32, the complex product written as a real [2N1 x 2N1] matrix so
+//       that one MFMA step consumes (re, im) of one input row);
 //   (2) twiddle + radix-2 Stockham row FFT of size N2 in LDS, pointwise product with the cached IR
 //       spectrum, inverse row FFT, conjugate twiddle, 1/L  -- one workgroup per row, one kernel;
 //   (3) inverse column DFT (same MFMA kernel, conjugate matrix) + dry signal, only for rows < N/N2.
@@ -39,7 +40,8 @@ inline size_t off_afwd(const PlanDev&) { return 0; }
 inline size_t off_ainv(const PlanDev& d) { return (size_t)d.N1 * 2 * d.M2; }
 inline size_t off_tw(const PlanDev& d) { return 2 * (size_t)d.N1 * 2 * d.M2; }
 inline size_t off_rowtw(const PlanDev& d) { return off_tw(d) + 2 * (size_t)d.L; }
-inline size_t table_floats(const PlanDev& d) { return off_rowtw(d) + (size_t)d.N2; }
+inline size_t off_tw125(const PlanDev& d) { return off_rowtw(d) + (size_t)d.N2; }
+inline size_t table_floats(const PlanDev& d) { return off_tw125(d) + 250; }
 
 // A[(step*2 + h)*M2 + row]: the real form of the (inverse) DFT matrix, see header comment.
 //   forward  F = cos - i sin :  real row k1: [cos, +sin]   imag row k1: [-sin, cos]
@@ -65,7 +67,13 @@ __global__ void build_dft_matrix_kernel(float* __restrict__ A, int N1, int NP, i
   }
 }
 
-__global__ void build_twiddle_kernel(float2* __restrict__ tw, float2* __restrict__ rowtw, int L, int N1, int N2) {
+__global__ void build_twiddle_kernel(float2* __restrict__ tw, float2* __restrict__ rowtw, float2* __restrict__ tw125,
+                                     int L, int N1, int N2) {
+  if (blockIdx.x == 0 && threadIdx.x < 125) {
+    double s, c;
+    sincospi(2.0 * (double)threadIdx.x / 125.0, &s, &c);
+    tw125[threadIdx.x] = make_float2((float)c, (float)-s);
+  }
   const size_t total = (size_t)L + N2 / 2;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     double s, c;
@@ -81,6 +89,128 @@ __global__ void build_twiddle_kernel(float2* __restrict__ tw, float2* __restrict
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// N1 == 125 (L = 64000, 32000, ...: every standard size): the column DFT as a real FFT, three radix-5
+// Stockham stages in LDS on a 125 x 32-column tile (lanes = columns -> every LDS access is 64 consecutive
+// float2, conflict-free; global traffic is whole 128 B row segments).  ~100x fewer flops than the GEMM form.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
+  return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
+
+template <bool INVERSE>
+__device__ __forceinline__ void dft5(float2 (&v)[5]) {
+  const float c1 = 0.30901699437494745f, c2 = -0.8090169943749473f;
+  const float s1 = 0.9510565162951535f, s2 = 0.5877852522924731f;
+  const float2 t1 = make_float2(v[1].x + v[4].x, v[1].y + v[4].y), t2 = make_float2(v[2].x + v[3].x, v[2].y + v[3].y);
+  const float2 t3 = make_float2(v[1].x - v[4].x, v[1].y - v[4].y), t4 = make_float2(v[2].x - v[3].x, v[2].y - v[3].y);
+  const float2 a1 = make_float2(fmaf(c2, t2.x, fmaf(c1, t1.x, v[0].x)), fmaf(c2, t2.y, fmaf(c1, t1.y, v[0].y)));
+  const float2 a2 = make_float2(fmaf(c1, t2.x, fmaf(c2, t1.x, v[0].x)), fmaf(c1, t2.y, fmaf(c2, t1.y, v[0].y)));
+  const float2 b1 = make_float2(fmaf(s2, t4.x, s1 * t3.x), fmaf(s2, t4.y, s1 * t3.y));
+  const float2 b2 = make_float2(fmaf(-s1, t4.x, s2 * t3.x), fmaf(-s1, t4.y, s2 * t3.y));
+  v[0] = make_float2(v[0].x + t1.x + t2.x, v[0].y + t1.y + t2.y);
+  // forward: V1 = a1 - i b1, V4 = a1 + i b1, V2 = a2 - i b2, V3 = a2 + i b2   (-i (x+iy) = y - ix); inverse: conjugate
+  const float sg = INVERSE ? -1.0f : 1.0f;
+  v[1] = make_float2(a1.x + sg * b1.y, a1.y - sg * b1.x);
+  v[4] = make_float2(a1.x - sg * b1.y, a1.y + sg * b1.x);
+  v[2] = make_float2(a2.x + sg * b2.y, a2.y - sg * b2.x);
+  v[3] = make_float2(a2.x - sg * b2.y, a2.y + sg * b2.x);
+}
+
+// three Stockham radix-5 stages over bufA -> bufB -> bufA -> bufB; returns with the result in bufB (natural order)
+template <bool INVERSE>
+__device__ __forceinline__ void fft125_tile(float2* bufA, float2* bufB, const float2* tw125, int tid) {
+  const int c = tid & 31, g = tid >> 5;
+  float2* in = bufA;
+  float2* out = bufB;
+#pragma unroll
+  for (int Ns = 1; Ns < 125; Ns *= 5) {
+    const int twstep = 25 / Ns;
+    for (int j = g; j < 25; j += 8) {
+      const int k = j % Ns;
+      float2 v[5];
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+        v[r] = in[(j + 25 * r) * 32 + c];
+        if (Ns > 1 && r > 0) {
+          float2 t = tw125[r * k * twstep];
+          if (INVERSE) t.y = -t.y;
+          v[r] = cmulf(v[r], t);
+        }
+      }
+      dft5<INVERSE>(v);
+      const int j0 = (j / Ns) * Ns * 5 + k;
+#pragma unroll
+      for (int r = 0; r < 5; ++r) out[(j0 + r * Ns) * 32 + c] = v[r];
+    }
+    __syncthreads();
+    float2* t = in;
+    in = out;
+    out = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void col125_fwd_kernel(PlanDev d, const float2* __restrict__ tw125_g,
+                                                         const float* __restrict__ x, int B, int N, long long x_stride,
+                                                         float* __restrict__ Ure, float* __restrict__ Uim) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float2* bufA = reinterpret_cast<float2*>(smem_raw);
+  float2* bufB = bufA + 125 * 32;
+  float2* tw125 = bufB + 125 * 32;
+  const int tid = threadIdx.x;
+  const int p = blockIdx.y;
+  const int c0 = blockIdx.x * 32;
+  if (tid < 125) tw125[tid] = tw125_g[tid];
+  const float* x0 = 2 * p < B ? x + (size_t)(2 * p) * x_stride : nullptr;
+  const float* x1 = 2 * p + 1 < B ? x + (size_t)(2 * p + 1) * x_stride : nullptr;
+  for (int e = tid; e < 125 * 32; e += 256) {
+    const long long n = (long long)d.N2 * (e >> 5) + c0 + (e & 31);
+    const bool in = n < N;
+    bufA[e] = make_float2((in && x0) ? x0[n] : 0.0f, (in && x1) ? x1[n] : 0.0f);
+  }
+  __syncthreads();
+  fft125_tile<false>(bufA, bufB, tw125, tid);
+  for (int e = tid; e < 125 * 32; e += 256) {
+    const size_t o = ((size_t)p * 125 + (e >> 5)) * d.N2 + c0 + (e & 31);
+    const float2 v = bufB[e];
+    Ure[o] = v.x;
+    Uim[o] = v.y;
+  }
+}
+
+__global__ __launch_bounds__(256) void col125_inv_kernel(PlanDev d, const float2* __restrict__ tw125_g,
+                                                         const float* __restrict__ Ure, const float* __restrict__ Uim,
+                                                         const float* __restrict__ x, int B, int N,
+                                                         float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float2* bufA = reinterpret_cast<float2*>(smem_raw);
+  float2* bufB = bufA + 125 * 32;
+  float2* tw125 = bufB + 125 * 32;
+  const int tid = threadIdx.x;
+  const int p = blockIdx.y;
+  const int c0 = blockIdx.x * 32;
+  if (tid < 125) tw125[tid] = tw125_g[tid];
+  for (int e = tid; e < 125 * 32; e += 256) {
+    const size_t o = ((size_t)p * 125 + (e >> 5)) * d.N2 + c0 + (e & 31);
+    bufA[e] = make_float2(Ure[o], Uim[o]);
+  }
+  __syncthreads();
+  fft125_tile<true>(bufA, bufB, tw125, tid);
+  const int rows_out = (N + d.N2 - 1) / d.N2;
+  const bool has1 = 2 * p + 1 < B;
+  for (int e = tid; e < rows_out * 32; e += 256) {
+    const long long n = (long long)d.N2 * (e >> 5) + c0 + (e & 31);
+    if (n < N) {
+      const float2 v = bufB[e];
+      const size_t o0 = (size_t)(2 * p) * N + n;
+      y[o0] = x[o0] + v.x;
+      if (has1) y[o0 + N] = x[o0 + N] + v.y;
+    }
+  }
+}
+
+constexpr size_t kCol125Lds = (2 * 125 * 32 + 125) * sizeof(float2);
 
 // ---- column DFT (forward): real utterances -> planar U[p][k1][n2] ----
 __global__ __launch_bounds__(256) void col_fwd_kernel(const float* __restrict__ A, PlanDev d, const float* __restrict__ x,
@@ -276,8 +406,23 @@ size_t nws_reverb_workspace_bytes(const NwsReverbPlan* plan, int B) {
   return (f > g ? f : g) * sizeof(float);
 }
 
+static int ensure_col125_attrs() {
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(col125_fwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCol125Lds);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(col125_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kCol125Lds);
+    if (e != hipSuccess) return (int)e;
+    done = true;
+  }
+  return NWS_OK;
+}
+
 int nws_reverb_build_tables(const NwsReverbPlan* plan, void* tables, void* stream) {
   if (!plan_ok(plan) || !tables) return NWS_ERR_BAD_ARG;
+  if (int rc = ensure_col125_attrs()) return rc;
   const PlanDev d = plan_dev(plan);
   float* t = static_cast<float*>(tables);
   hipStream_t st = (hipStream_t)stream;
@@ -286,7 +431,8 @@ int nws_reverb_build_tables(const NwsReverbPlan* plan, void* tables, void* strea
   build_dft_matrix_kernel<<<1024, 256, 0, st>>>(t + off_ainv(d), d.N1, d.NP, d.M2, 1);
   NWS_CHECK_LAUNCH();
   build_twiddle_kernel<<<512, 256, 0, st>>>(reinterpret_cast<float2*>(t + off_tw(d)),
-                                            reinterpret_cast<float2*>(t + off_rowtw(d)), d.L, d.N1, d.N2);
+                                            reinterpret_cast<float2*>(t + off_rowtw(d)),
+                                            reinterpret_cast<float2*>(t + off_tw125(d)), d.L, d.N1, d.N2);
   NWS_CHECK_LAUNCH();
   return NWS_OK;
 }
@@ -308,8 +454,13 @@ int nws_reverb_ir_spectrum(const NwsReverbPlan* plan, const void* tables, const 
   float* Sim = Sre + d.L;
   build_ir_kernel<<<(ir_len + 1 + 255) / 256, 256, 0, st>>>(ir, ir_len, irp);
   NWS_CHECK_LAUNCH();
-  const dim3 g1(d.N2 / 32, (d.M2 / 32 + 3) / 4, 1);
-  col_fwd_kernel<<<g1, 256, 0, st>>>(t + off_afwd(d), d, irp, 1, ir_len + 1, 0, Ure, Uim);
+  if (d.N1 == 125) {
+    col125_fwd_kernel<<<dim3(d.N2 / 32, 1), 256, kCol125Lds, st>>>(d, reinterpret_cast<const float2*>(t + off_tw125(d)),
+                                                                    irp, 1, ir_len + 1, 0, Ure, Uim);
+  } else {
+    const dim3 g1(d.N2 / 32, (d.M2 / 32 + 3) / 4, 1);
+    col_fwd_kernel<<<g1, 256, 0, st>>>(t + off_afwd(d), d, irp, 1, ir_len + 1, 0, Ure, Uim);
+  }
   NWS_CHECK_LAUNCH();
   const dim3 g2(d.N1, 1);
   row_kernel<true><<<g2, 256, row_lds_bytes(d), st>>>(d, Ure, Uim, reinterpret_cast<const float2*>(t + off_tw(d)),
@@ -334,18 +485,27 @@ int nws_reverb(const NwsReverbPlan* plan, const void* tables, const void* spectr
   const float* Sre = static_cast<const float*>(spectrum);
   const float* Sim = Sre + d.L;
 
-  const dim3 g1(d.N2 / 32, (d.M2 / 32 + 3) / 4, pairs);
-  col_fwd_kernel<<<g1, 256, 0, st>>>(t + off_afwd(d), d, x, B, N, (long long)N, Ure, Uim);
+  const float2* tw125 = reinterpret_cast<const float2*>(t + off_tw125(d));
+  if (d.N1 == 125) {
+    col125_fwd_kernel<<<dim3(d.N2 / 32, pairs), 256, kCol125Lds, st>>>(d, tw125, x, B, N, (long long)N, Ure, Uim);
+  } else {
+    const dim3 g1(d.N2 / 32, (d.M2 / 32 + 3) / 4, pairs);
+    col_fwd_kernel<<<g1, 256, 0, st>>>(t + off_afwd(d), d, x, B, N, (long long)N, Ure, Uim);
+  }
   NWS_CHECK_LAUNCH();
   const dim3 g2(d.N1, pairs);
   row_kernel<false><<<g2, 256, row_lds_bytes(d), st>>>(d, Ure, Uim, reinterpret_cast<const float2*>(t + off_tw(d)),
                                                        reinterpret_cast<const float2*>(t + off_rowtw(d)), Sre, Sim,
                                                        nullptr, nullptr);
   NWS_CHECK_LAUNCH();
-  const int rows_out = (N + d.N2 - 1) / d.N2;
-  const int nt = (rows_out + 31) / 32;
-  const dim3 g3(d.N2 / 32, (2 * nt + 3) / 4, pairs);
-  col_inv_kernel<<<g3, 256, 0, st>>>(t + off_ainv(d), d, Ure, Uim, x, B, N, y);
+  if (d.N1 == 125) {
+    col125_inv_kernel<<<dim3(d.N2 / 32, pairs), 256, kCol125Lds, st>>>(d, tw125, Ure, Uim, x, B, N, y);
+  } else {
+    const int rows_out = (N + d.N2 - 1) / d.N2;
+    const int nt = (rows_out + 31) / 32;
+    const dim3 g3(d.N2 / 32, (2 * nt + 3) / 4, pairs);
+    col_inv_kernel<<<g3, 256, 0, st>>>(t + off_ainv(d), d, Ure, Uim, x, B, N, y);
+  }
   NWS_CHECK_LAUNCH();
   return NWS_OK;
 }
