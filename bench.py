@@ -78,12 +78,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the product path)"
+    # NWS_BENCH_SHARE_GPU=1 (smoke-testing the N>1 code path on a 1-GPU box): every rank uses cuda:0 and the
+    # collectives go through gloo on host copies (NCCL/RCCL refuses two ranks on one device).  Never set by the driver.
+    share_gpu = os.environ.get("NWS_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     nws = importlib.import_module("neural-waveshaping-synthesis_amd")
     _lib = importlib.import_module("neural-waveshaping-synthesis_amd._lib")
     par = importlib.import_module("neural-waveshaping-synthesis_amd.parallel")
@@ -105,6 +113,13 @@ def main():
     def step(i, pending):
         s = streams[i % len(streams)]
         with torch.cuda.stream(s):
+            if world > 1 and share_gpu:   # smoke mode only: host-staged gloo collectives
+                pu, nz = par.shared_draws(101, N - 1, torch.device("cpu"))
+                y = model(f0, control, phase_u=pu.to(dev), noise=nz.to(dev))
+                parts = [torch.empty((B, N)) for _ in range(world)]
+                dist.all_gather(parts, y.cpu())
+                full[i % len(streams)].copy_(torch.cat(parts, 0))
+                return None
             if world > 1:
                 pu, nz = par.shared_draws(101, N - 1, dev)       # identical draws on all ranks
                 y = model(f0, control, phase_u=pu, noise=nz)
@@ -148,9 +163,12 @@ def main():
         k_ms = float(np.mean([ms[i * 6 + 3] for i in range(n.value)])) if n.value else float("nan")
 
         if world > 1:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
+            # the gathered batch must hold every rank's rows (rank r at rows [r*B, (r+1)*B))
+            last = full[(a.steps - 1) % len(streams)]
+            assert torch.isfinite(last).all() and float(last[B * (world - 1):].abs().max()) > 0.0
 
         extra = {}
         if rank == 0:
@@ -184,6 +202,33 @@ def main():
                                    "x_realtime_p50": round(dur_ms / float(np.percentile(lat, 50)), 1),
                                    "rtf_mean": float(np.mean(lat) / dur_ms)}
 
+    if rank == 0 and world == 1 and a.batch1_iters > 0:
+        # config "streaming 256-sample hop": stateless forward of one 16 ms buffer, captured once into a hipGraph
+        with torch.no_grad():
+            fs, cs = torch.rand(1, 1, 2, device=dev), torch.rand(1, 2, 2, device=dev)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    model(fs, cs)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                model(fs, cs)
+            for _ in range(20):
+                graph.replay()
+            torch.cuda.synchronize()
+            lat = []
+            for _ in range(500):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                graph.replay()
+                e1.record()
+                e1.synchronize()
+                lat.append(e0.elapsed_time(e1) * 1e3)
+            extra["streaming_hop256_hipgraph"] = {"p50_us": round(float(np.percentile(lat, 50)), 2),
+                                                  "p99_us": round(float(np.percentile(lat, 99)), 2),
+                                                  "buffer_period_us": 16000.0}
     if rank == 0:
         total_samples = B * world * N * a.steps
         value = total_samples / elapsed

@@ -353,3 +353,48 @@ def test_hipgraph_capture_replay(models):
     ref = fast(f0, c, phase_u=pu, noise=nz)
     assert torch.equal(out, ref)
     assert not torch.equal(out, eager)
+
+
+@pytest.mark.parametrize("B,T", [(3, 501), (1, 1000), (5, 33), (2, 250)])
+def test_e2e_odd_shapes_against_oracle(models, oracle, B, T):
+    """Shapes off the beaten path: T=501 -> L=64128=501x128 (general-N1 MFMA DFT), T=1000 -> L=128000=125x1024,
+    odd batch (one half-empty reverb pair), partial 32-frame MLP tiles, N<32000 (zero-padded to L=32000)."""
+    exact, fast = models
+    g = torch.Generator().manual_seed(1000 * B + T)
+    f0 = (80 + 1500 * torch.rand(B, 1, 1, generator=g)) * (1 + 0.02 * torch.randn(B, 1, T, generator=g))
+    control = torch.randn(B, 4, T, generator=g)
+    pu, nz = torch.rand(101, generator=g), torch.rand(128 * T - 1, generator=g)
+    for model, orc, tag in ((fast, oracle[1], "fast"), (exact, oracle[0], "exact")):
+        if tag == "exact" and T > 600:
+            continue  # the exact-shaper oracle is slow on 8 s clips; FastNEWT covers the shape
+        y = model(f0.cuda(), control.cuda(), phase_u=pu.cuda(), noise=nz.cuda()).cpu().numpy()
+        ref = orc(f0, control, pu, nz).numpy()
+        e = rms(y - ref)
+        record(f"odd_B{B}_T{T}_{tag}", rms_err=e, out_rms=rms(ref))
+        assert y.shape == (B, 128 * T) and e <= 1e-4, (tag, e)
+
+
+def test_e2e_f0_edge_cases(models, oracle):
+    """F0 = 0, negative, exactly at / above Nyquist, tiny and huge: the anti-alias mask and the phase chain must agree
+    with the reference semantics (fl(f0*k) < sr/2 on the upsampled F0; negative F0 keeps every harmonic)."""
+    _, fast = models
+    T = 24
+    rows = [np.zeros(T), np.full(T, -220.0), np.full(T, 8000.0), np.full(T, 7999.5), np.full(T, 12000.0),
+            np.full(T, 79.3), np.linspace(0.0, 9000.0, T), np.full(T, 3999.9999), np.full(T, 1e-3)]
+    f0 = torch.tensor(np.stack(rows), dtype=torch.float32).unsqueeze(1)
+    g = torch.Generator().manual_seed(4)
+    control = torch.randn(len(rows), 2, T, generator=g)
+    pu, nz = torch.rand(101, generator=g), torch.rand(128 * T - 1, generator=g)
+    y = fast(f0.cuda(), control.cuda(), phase_u=pu.cuda(), noise=nz.cuda()).cpu().numpy()
+    ref = oracle[1](f0, control, pu, nz).numpy()
+    errs = [rms(y[i] - ref[i]) for i in range(len(rows))]
+    record("f0_edge_cases", **{f"row{i}": e for i, e in enumerate(errs)})
+    assert max(errs) <= 1e-4, errs
+    exc = fast.render_exciter  # public API with a pre-upsampled F0 that is NOT a linear ramp
+    f0_up = (200 + 100 * torch.rand(2, 1, 128 * 6, generator=g)).cuda()
+    torch.manual_seed(11)
+    e1 = exc(f0_up).cpu().numpy()
+    torch.manual_seed(11)
+    u = torch.rand_like(fast.osc.rand_phase).cpu().reshape(-1)
+    ref_e = oracle[0].exciter(f0_up.cpu(), u).numpy()
+    assert maxabs(e1, ref_e) <= 2e-5
