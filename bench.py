@@ -235,6 +235,13 @@ def main():
         ms_per_step = elapsed / a.steps * 1e3
         flops = FLOP_PER_SAMPLE_EXCITER_NEWT * B * N
         achieved = flops / (k_ms * 1e-3) / 1e12
+        traffic = None   # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
+            if tr["batch_per_gpu"] == B and tr["frames"] == T and not a.exact:
+                traffic = tr["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "audio_samples_per_sec", "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
@@ -247,7 +254,7 @@ def main():
             "x_realtime_aggregate": value / 16000.0,
             "rtf_per_utterance": (ms_per_step * 1e-3) / (N / 16000.0) / B,
             "roofline": {"bound": "mfma", "kernel": "exciter_newt_kernel", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "kernel_ms": k_ms, "flop_per_launch": flops},
         }
         out.update(extra)

@@ -52,7 +52,8 @@ __device__ __forceinline__ float nws_lerp(float a, float b, float w0, float w1) 
 // sinf with full-range argument reduction.  |error| <~ 1.5e-7 absolute for |x| <= 6e6 (two-constant
 // Cody-Waite in fp32 with FMA: the product q*P1 is exact inside the fma), fp64 reduction above.
 // The reference's torch.sin (Sleef u10) is itself within 1 ulp of the true value; the oscillator
-// needs ~1e-6 (SURVEY.md §7 hard part 2).  Fast intrinsics (__sinf / v_sin_f32) are NOT used.
+// needs ~1e-6 (SURVEY.md §7 hard part 2).  Used where accuracy matters most (FastNEWT table construction,
+// stand-alone shapers, |x| > 6e6); the oscillator uses nws_sinf_fast below.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float nws_sin_poly(float r) {
   const float z = r * r;
