@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=60)
     ap.add_argument("--batch1-iters", type=int, default=200)
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the steps are issued on round-robin (independent forwards overlap: the GRU of "
                          "step i+1 only occupies B CUs while step i's sample-rate kernels fill the rest)")
     return ap.parse_args()
@@ -180,7 +180,7 @@ def main():
             ms2 = (C.c_float * 60)()
             _lib.check(_lib.lib().nws_profile_collect(ms2, C.byref(n)))
             extra["stage_ms"] = {nm: round(float(np.mean([ms2[i * 6 + s] for i in range(n.value)])), 4)
-                                 for s, nm in enumerate(_lib.STAGE_NAMES)}
+                                 for s, nm in enumerate(_lib.STAGE_NAMES)}   # one stream, nothing overlapping
             _lib.lib().nws_profile_end()
             if world == 1 and a.batch1_iters > 0:
                 # config "batch=1, single MI355X, FastNEWT": latency / x real-time per utterance

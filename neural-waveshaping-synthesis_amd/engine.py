@@ -45,6 +45,9 @@ def reverb_plan_and_tables(device: torch.device, n_samples: int, ir_len_plus1: i
         nbytes = _lib.lib().nws_reverb_table_bytes(C.byref(plan))
         tables = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
         check(_lib.lib().nws_reverb_build_tables(C.byref(plan), ptr(tables), stream_ptr()), "nws_reverb_build_tables")
+        # one-time: make the tables visible to every stream before anybody can use them (callers may issue forwards
+        # round-robin on several streams; the builder stream is whichever one got here first)
+        torch.cuda.current_stream().synchronize()
         hit = (plan, tables)
         _TABLE_CACHE[key] = hit
     return hit
@@ -153,6 +156,7 @@ class Engine:
         devs = {t.device for t in keep}
         if len(devs) != 1:
             raise RuntimeError(f"model parameters are spread over several devices: {devs}")
+        torch.cuda.current_stream().synchronize()   # derived tables complete before any other stream can use them
         self._w = (w, keep, next(iter(devs)))
         return self._w
 
@@ -202,6 +206,7 @@ class Engine:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             check(_lib.lib().nws_reverb_ir_spectrum(C.byref(plan), ptr(tables), ptr(ir), ir.numel(), ptr(spec), ptr(ws),
                                                     nbytes, stream_ptr()), "nws_reverb_ir_spectrum")
+            torch.cuda.current_stream().synchronize()
             self._spectra[plan.L] = spec
         return plan, tables, spec
 

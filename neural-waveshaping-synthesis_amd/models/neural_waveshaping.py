@@ -97,7 +97,7 @@ class NeuralWaveshaping(nn.Module):
     # ---- public surface ----------------------------------------------------------------------------
     def render_exciter(self, f0):
         """(B, 1, N) upsampled F0 in Hz -> (B, n_waveshapers, N) exciter (reference :64-67)."""
-        f0 = _req(f0, "f0")
+        f0 = _req(f0 if f0.is_contiguous() else f0.contiguous(), "f0")
         if f0.dim() != 3 or f0.shape[1] != 1 or f0.shape[-1] % _lib.HOP:
             raise RuntimeError(f"expected (B, 1, 128*T), got {tuple(f0.shape)}")
         eng = self._engine
@@ -109,14 +109,15 @@ class NeuralWaveshaping(nn.Module):
 
     def get_embedding(self, control):
         """(B, C>=2, T) normalised control -> (B, 128, T) embedding (reference :69-72)."""
-        control = _req(control, "control")
+        control = _req(control if control.is_contiguous() else control.contiguous(), "control")
         gru = self._engine.control_gru(control)
         emb, _, _, _ = self._engine.frame_mlps(gru, want_emb=True)
         return emb
 
     def forward(self, f0, control, *, phase_u=None, noise=None):
-        f0 = _req(f0, "f0")
-        control = _req(control, "control")
+        # strided views (control[:, :2], expand()) are accepted like in the reference: compacted by torch
+        f0 = _req(f0 if f0.is_contiguous() else f0.contiguous(), "f0")
+        control = _req(control if control.is_contiguous() else control.contiguous(), "control")
         if f0.dim() != 3 or f0.shape[1] != 1:
             raise RuntimeError(f"f0: expected (B, 1, T), got {tuple(f0.shape)}")
         if control.dim() != 3 or control.shape[1] < 2:

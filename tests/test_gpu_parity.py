@@ -398,3 +398,28 @@ def test_e2e_f0_edge_cases(models, oracle):
     u = torch.rand_like(fast.osc.rand_phase).cpu().reshape(-1)
     ref_e = oracle[0].exciter(f0_up.cpu(), u).numpy()
     assert maxabs(e1, ref_e) <= 2e-5
+
+
+def test_multi_stream_forwards_and_strided_inputs(models, oracle):
+    """Forwards issued on different streams right after a cache rebuild must not race the derived tables; strided
+    inputs (channel slices, expand) are accepted like in the reference."""
+    _, fast = models
+    g = torch.Generator().manual_seed(77)
+    T = 40
+    f0 = (150 + 300 * torch.rand(2, 1, T, generator=g)).cuda()
+    big = torch.randn(2, 6, T, generator=g).cuda()
+    pu, nz = torch.rand(101, generator=g).cuda(), torch.rand(128 * T - 1, generator=g).cuda()
+    ref = oracle[1](f0.cpu(), big[:, 1:3].cpu(), pu.cpu(), nz.cpu()).numpy()
+    fast.invalidate_cache()                          # force a rebuild of every derived table on the next call
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = []
+    for i in range(6):
+        with torch.cuda.stream(streams[i % 3]):
+            streams[i % 3].wait_stream(torch.cuda.current_stream())
+            outs.append(fast(f0, big[:, 1:3], phase_u=pu, noise=nz))   # non-contiguous channel slice
+    torch.cuda.synchronize()
+    for y in outs:
+        assert rms(y.cpu().numpy() - ref) <= 1e-4
+    y2 = fast(f0[:1, :, 0:1].expand(1, 1, T), big[:1, 1:3], phase_u=pu, noise=nz)   # expand() view of a constant F0
+    ref2 = oracle[1](f0[:1, :, 0:1].expand(1, 1, T).cpu(), big[:1, 1:3].cpu(), pu.cpu(), nz.cpu()).numpy()
+    assert rms(y2.cpu().numpy() - ref2) <= 1e-4
