@@ -76,7 +76,7 @@ def test_gin_reader_parses_reference_and_packaged_config():
     for path in ([REF_GIN] if os.path.exists(REF_GIN) else []) + [nws.DEFAULT_GIN]:
         gin.clear_config()
         gin.parse_config_file(path)
-        assert gin.query_parameter("%sample_rate") == 16000
+        assert gin.query_parameter("Reverb.sr") == 16000
         assert gin.query_parameter("HarmonicOscillator.n_harmonics") == 101
         assert gin.query_parameter("NEWT.shaping_fn_size") == 8
         assert gin.query_parameter("noise_synth/TimeDistributedMLP.out_size") == 129
