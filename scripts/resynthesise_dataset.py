@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Batched offline rendering of a control-feature dataset to wav files on MI355X (one process per GPU under
+torchrun: the item list is sharded round-robin, every rank writes its own files, no collective).
+
+    python scripts/resynthesise_dataset.py --model-checkpoint ckpt --dataset-root data/ --use-fastnewt
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/resynthesise_dataset.py ...
+"""
+import importlib
+import os
+import sys
+import time
+
+import click
+import numpy as np
+import torch
+from scipy.io import wavfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+@click.command()
+@click.option("--model-gin", default=None)
+@click.option("--model-checkpoint", required=True)
+@click.option("--dataset-root", required=True)
+@click.option("--dataset-split", default="test")
+@click.option("--output-path", default="audio_output")
+@click.option("--batch-size", default=64)
+@click.option("--use-fastnewt", is_flag=True)
+@click.option("--write-targets", is_flag=True, help="also write <name>.target.wav when the dataset holds audio")
+def main(model_gin, model_checkpoint, dataset_root, dataset_split, output_path, batch_size, use_fastnewt, write_targets):
+    nws = importlib.import_module("neural-waveshaping-synthesis_amd")
+    ds_mod = importlib.import_module("neural-waveshaping-synthesis_amd.dataset")
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    torch.cuda.set_device(dev)
+    if model_gin:
+        nws.gin.parse_config_file(model_gin)
+    else:
+        nws.ensure_default_config()
+    os.makedirs(output_path, exist_ok=True)
+    data = ds_mod.ControlDataset(dataset_root, dataset_split)
+    model = nws.NeuralWaveshaping.load_from_checkpoint(model_checkpoint).eval()
+    if use_fastnewt:
+        model.newt = nws.FastNEWT(model.newt)
+    model = model.to(dev)
+    mine = data.shard(rank, world)
+    t0, n_samples = time.time(), 0
+    with torch.no_grad():
+        for batch in data.batches(mine, batch_size):
+            out = model(torch.from_numpy(batch["f0"]).to(dev), torch.from_numpy(batch["control"]).to(dev)).cpu().numpy()
+            n_samples += out.size
+            for j, name in enumerate(batch["names"]):
+                wavfile.write(os.path.join(output_path, f"{name}.output.wav"), int(model.sample_rate), out[j])
+                if write_targets and batch["audio"][j] is not None:
+                    wavfile.write(os.path.join(output_path, f"{name}.target.wav"), int(model.sample_rate), batch["audio"][j])
+    dt = time.time() - t0
+    print(f"[rank {rank}/{world}] rendered {len(mine)} items, {n_samples} samples in {dt:.2f} s "
+          f"({n_samples / max(dt, 1e-9) / 16000.0:.0f}x real-time incl. file I/O)")
+
+
+if __name__ == "__main__":
+    main()
