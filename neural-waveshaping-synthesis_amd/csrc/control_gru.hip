@@ -14,6 +14,9 @@
 // writes h' into the other half of a ping-pong LDS buffer: ONE workgroup barrier per step that waits
 // on LDS only (raw s_barrier + lgkmcnt(0); the 512 B h_t global store is never drained on the critical
 // path), control values staged in LDS 1024 frames at a time.
+// Measured alternatives (MI355X, 500 steps): 4 K-slices + LDS partial-sum exchange + libm gates + two
+// __syncthreads per step 0.457 ms; this kernel 0.271 ms; an 8-wave variant (2 waves/SIMD, lane = unit x
+// K-quarter) 0.290 ms -- the step is bound by VALU issue (96 v_pk_fma_f32 + gate math per lane), not latency.
 #include "nws_common.h"
 
 namespace {

@@ -423,3 +423,31 @@ def test_multi_stream_forwards_and_strided_inputs(models, oracle):
     y2 = fast(f0[:1, :, 0:1].expand(1, 1, T), big[:1, 1:3], phase_u=pu, noise=nz)   # expand() view of a constant F0
     ref2 = oracle[1](f0[:1, :, 0:1].expand(1, 1, T).cpu(), big[:1, 1:3].cpu(), pu.cpu(), nz.cpu()).numpy()
     assert rms(y2.cpu().numpy() - ref2) <= 1e-4
+
+
+def test_offline_render_cli(tmp_path):
+    """scripts/resynthesise_dataset.py on a tiny synthetic dataset: one wav per item, right length, finite."""
+    import subprocess
+    import sys
+    from scipy.io import wavfile
+    from conftest import ROOT
+    import os
+
+    root = tmp_path / "data"
+    (root / "test" / "control").mkdir(parents=True)
+    w = load_npz("weights_vn.npz")
+    mean, std = np.zeros((19, 1)), np.ones((19, 1))
+    mean[:2, 0], std[:2, 0] = w["__data_mean__"], w["__data_std__"]
+    np.save(root / "data_mean.npy", mean)
+    np.save(root / "data_std.npy", std)
+    rng = np.random.default_rng(1)
+    for i, T in enumerate([16, 16, 9, 16, 9]):
+        np.save(root / "test" / "control" / f"control_clip{i}.npy", rng.normal(size=(19, T)).astype(np.float32))
+    out = tmp_path / "wav"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "resynthesise_dataset.py"), "--model-checkpoint",
+                        os.path.join(ROOT, "tests", "golden", "weights_vn.npz"), "--dataset-root", str(root),
+                        "--output-path", str(out), "--use-fastnewt", "--batch-size", "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for i, T in enumerate([16, 16, 9, 16, 9]):
+        sr, audio = wavfile.read(out / f"clip{i}.output.wav")
+        assert sr == 16000 and audio.shape == (128 * T,) and np.isfinite(audio).all() and np.abs(audio).max() > 0
