@@ -102,12 +102,65 @@ __global__ __launch_bounds__(1024) void phase_carry_kernel(const float* __restri
 struct ShaperLds {
   float in_scale[64];
   float w0[512], b0[512];
-  float w2[4096], b2[512];
-  float w4[4096], b4[512];
+  float w2t[4096], b2[512];  // w2t[s][i][o] = net.2.weight[s*8+o][i]: the 8 outputs of one input are contiguous
+  float w4t[4096], b4[512];  //   -> two packed-fp32 operands per ds_read_b128
   float w6[512], b6[64];
 };
 
-__device__ __forceinline__ float exact_shaper(const ShaperLds& W, int s, float x) {
+// packed fast sine without range test: only for arguments bounded by construction (|sum_i w_i h_i + b| with |h_i| <= 1,
+// i.e. by the layer's weight norms, orders of magnitude below the 6e6 limit of the reduction)
+__device__ __forceinline__ f32x2 sin_pair_bounded(f32x2 x) {
+  const f32x2 c_hi = splat2(0.15915493667125702f), c_lo = splat2(6.4206382432985265e-09f);
+  const f32x2 p = x * c_hi;
+  const f32x2 e = fma2(x, c_hi, -p);
+  const f32x2 r = {rintf(p.x), rintf(p.y)};
+  const f32x2 t = (p - r) + fma2(x, c_lo, e);
+  return f32x2{__builtin_amdgcn_sinf(t.x), __builtin_amdgcn_sinf(t.y)};
+}
+
+// one dense 8 -> 8 sine layer in packed fp32: out[o] = sin(b[o] + sum_i w[o][i] h[i]), weights transposed in LDS
+__device__ __forceinline__ void sine_layer8(const float* __restrict__ wt, const float* __restrict__ bias,
+                                            const f32x2 (&h)[4], f32x2 (&out)[4]) {
+  const float4 b0 = *reinterpret_cast<const float4*>(bias), b1 = *reinterpret_cast<const float4*>(bias + 4);
+  f32x2 acc[4] = {{b0.x, b0.y}, {b0.z, b0.w}, {b1.x, b1.y}, {b1.z, b1.w}};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float4 wa = *reinterpret_cast<const float4*>(wt + 8 * i), wb = *reinterpret_cast<const float4*>(wt + 8 * i + 4);
+    const f32x2 hi = splat2((i & 1) ? h[i >> 1].y : h[i >> 1].x);
+    acc[0] = fma2(f32x2{wa.x, wa.y}, hi, acc[0]);
+    acc[1] = fma2(f32x2{wa.z, wa.w}, hi, acc[1]);
+    acc[2] = fma2(f32x2{wb.x, wb.y}, hi, acc[2]);
+    acc[3] = fma2(f32x2{wb.z, wb.w}, hi, acc[3]);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) out[q] = sin_pair_bounded(acc[q]);
+}
+
+// in-kernel exact shaper (TrainableNonlinearity, models/modules/shaping.py:36-37) on the packed-fp32 / v_sin_f32 path.
+// Not inlined: 32 inlined copies in the unrolled tail push the kernel past 256 VGPRs into scratch.
+__device__ __noinline__ float exact_shaper(const ShaperLds& W, int s, float x) {
+  const float a = W.in_scale[s] * x;
+  const float4 wa = *reinterpret_cast<const float4*>(&W.w0[s * 8]), wb = *reinterpret_cast<const float4*>(&W.w0[s * 8 + 4]);
+  const float4 ba = *reinterpret_cast<const float4*>(&W.b0[s * 8]), bb = *reinterpret_cast<const float4*>(&W.b0[s * 8 + 4]);
+  // first layer: the argument scales with the (unbounded) FiLM output -> range-checked sine
+  f32x2 h1[4] = {{nws_sinf_fast(fmaf(wa.x, a, ba.x)), nws_sinf_fast(fmaf(wa.y, a, ba.y))},
+                 {nws_sinf_fast(fmaf(wa.z, a, ba.z)), nws_sinf_fast(fmaf(wa.w, a, ba.w))},
+                 {nws_sinf_fast(fmaf(wb.x, a, bb.x)), nws_sinf_fast(fmaf(wb.y, a, bb.y))},
+                 {nws_sinf_fast(fmaf(wb.z, a, bb.z)), nws_sinf_fast(fmaf(wb.w, a, bb.w))}};
+  f32x2 h2[4];
+  sine_layer8(&W.w2t[s * 64], &W.b2[s * 8], h1, h2);
+  sine_layer8(&W.w4t[s * 64], &W.b4[s * 8], h2, h1);
+  const float4 va = *reinterpret_cast<const float4*>(&W.w6[s * 8]), vb = *reinterpret_cast<const float4*>(&W.w6[s * 8 + 4]);
+  f32x2 acc = f32x2{va.x, va.y} * h1[0];
+  acc = fma2(f32x2{va.z, va.w}, h1[1], acc);
+  acc = fma2(f32x2{vb.x, vb.y}, h1[2], acc);
+  acc = fma2(f32x2{vb.z, vb.w}, h1[3], acc);
+  return nws_sin_turns_checked(W.b6[s] + (acc.x + acc.y));
+}
+
+// reference-grade variant (Cody-Waite polynomial sine, scalar): used to BUILD the FastNEWT table and by the stand-alone
+// shaper entry point, where accuracy matters more than speed
+__device__ __forceinline__ float exact_shaper_precise(const ShaperLds& W, int s, float x) {
   const float a = W.in_scale[s] * x;
   float h1[8], h2[8];
 #pragma unroll
@@ -115,17 +168,15 @@ __device__ __forceinline__ float exact_shaper(const ShaperLds& W, int s, float x
 #pragma unroll
   for (int o = 0; o < 8; ++o) {
     float acc = W.b2[s * 8 + o];
-    const float* wr = &W.w2[(s * 8 + o) * 8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc = fmaf(wr[i], h1[i], acc);
+    for (int i = 0; i < 8; ++i) acc = fmaf(W.w2t[s * 64 + i * 8 + o], h1[i], acc);
     h2[o] = nws_sinf(acc);
   }
 #pragma unroll
   for (int o = 0; o < 8; ++o) {
     float acc = W.b4[s * 8 + o];
-    const float* wr = &W.w4[(s * 8 + o) * 8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc = fmaf(wr[i], h2[i], acc);
+    for (int i = 0; i < 8; ++i) acc = fmaf(W.w4t[s * 64 + i * 8 + o], h2[i], acc);
     h1[o] = nws_sinf(acc);
   }
   float acc = W.b6[s];
@@ -146,9 +197,10 @@ __device__ __forceinline__ void load_shaper_lds(ShaperLds& L, const NwsWeights& 
     L.b4[i] = w.shaper_b4[i];
     L.w6[i] = w.shaper_w6[i];
   }
-  for (int i = tid; i < 4096; i += nthreads) {
-    L.w2[i] = w.shaper_w2[i];
-    L.w4[i] = w.shaper_w4[i];
+  for (int i = tid; i < 4096; i += nthreads) {  // i = (s*8 + o)*8 + in  ->  [s][in][o]
+    const int sidx = i >> 6, o = (i >> 3) & 7, in = i & 7;
+    L.w2t[sidx * 64 + in * 8 + o] = w.shaper_w2[i];
+    L.w4t[sidx * 64 + in * 8 + o] = w.shaper_w4[i];
   }
 }
 
@@ -511,7 +563,7 @@ __global__ __launch_bounds__(256) void shaper_apply_kernel(NwsWeights w, const f
   if (MODE == kModeLut) LP = make_lut_params(w);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
     const float v = x[row * N + i];
-    y[row * N + i] = MODE == kModeLut ? lut_shaper<false, false>(LP, s * LP.size, v) : exact_shaper(SH, s, v);
+    y[row * N + i] = MODE == kModeLut ? lut_shaper<false, false>(LP, s * LP.size, v) : exact_shaper_precise(SH, s, v);
   }
 }
 
@@ -529,7 +581,7 @@ __global__ __launch_bounds__(256) void shaper_table_kernel(NwsWeights w, int siz
   const int halfway = size / 2;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < size; i += gridDim.x * 256) {
     const float xv = i < halfway ? fmaf(step, (float)i, tmin) : fmaf(-step, (float)(size - 1 - i), tmax);
-    table[(size_t)s * size + i] = exact_shaper(SH, s, xv);
+    table[(size_t)s * size + i] = exact_shaper_precise(SH, s, xv);
   }
 }
 

@@ -109,6 +109,10 @@ __device__ __forceinline__ float nws_sin_turns(float x) {  // caller guarantees 
   return __builtin_amdgcn_sinf(t);
 }
 
+__device__ __forceinline__ float nws_sin_turns_checked(float x) {
+  return __builtin_expect(fabsf(x) > 6.0e6f, 0) ? nws_sinf_huge(x) : nws_sin_turns(x);
+}
+
 __device__ __forceinline__ float nws_sinf_fast(float x) {
   if (__builtin_expect(fabsf(x) > 6.0e6f, 0)) return nws_sinf_huge(x);
   return nws_sin_turns(x);
