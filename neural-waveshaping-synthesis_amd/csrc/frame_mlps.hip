@@ -271,18 +271,26 @@ __device__ __forceinline__ void split4_store(char* xt_hi, char* xt_lo, int frame
   *reinterpret_cast<f16x4*>(xt_lo + frame * kRowB + ch * 2) = l;
 }
 
-// acc(32 rows x 32 frames) = W[M-tile mt of map] * X  for the XT buffer (hi, lo)
+// weight fragments of one M-tile in registers (KS K-steps x (hi, lo) x 8 halfs)
 template <int KS>
-__device__ __forceinline__ void gemm_tile16(const f16x8* __restrict__ frags, int mt, const char* xt_hi,
-                                            const char* xt_lo, int lane, f32x16& acc) {
-  const int half = lane >> 5, col = lane & 31;
+struct AFrag {
+  f16x8 hi[KS], lo[KS];
+};
+
+template <int KS>
+__device__ __forceinline__ void load_frags(AFrag<KS>& A, const f16x8* __restrict__ frags, int mt, int lane) {
   const f16x8* a = frags + (size_t)mt * KS * 128 + lane;
-  f16x8 ahi[KS], alo[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    ahi[ks] = a[ks * 128];
-    alo[ks] = a[ks * 128 + 64];
+    A.hi[ks] = a[ks * 128];
+    A.lo[ks] = a[ks * 128 + 64];
   }
+}
+
+// acc(32 rows x 32 frames) = A * X  for the XT buffer (hi, lo):  W_hi X_hi + (W_hi X_lo + W_lo X_hi)
+template <int KS>
+__device__ __forceinline__ void mma_tile(const AFrag<KS>& A, const char* xt_hi, const char* xt_lo, int lane, f32x16& acc) {
+  const int half = lane >> 5, col = lane & 31;
   f32x16 cross;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -295,9 +303,9 @@ __device__ __forceinline__ void gemm_tile16(const f16x8* __restrict__ frags, int
   for (int ks = 0; ks < KS; ++ks) {
     const f16x8 xh = *reinterpret_cast<const f16x8*>(bh + ks * 32);
     const f16x8 xl = *reinterpret_cast<const f16x8*>(bl + ks * 32);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], xh, acc, 0, 0, 0);
-    cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], xl, cross, 0, 0, 0);
-    cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], xh, cross, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.hi[ks], xh, acc, 0, 0, 0);
+    cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.hi[ks], xl, cross, 0, 0, 0);
+    cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.lo[ks], xh, cross, 0, 0, 0);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] += cross[r];
@@ -311,12 +319,10 @@ __device__ __forceinline__ void store_tile_xt(char* xt_hi, char* xt_lo, int c0, 
     split4_store(xt_hi, xt_lo, col, c0 + 8 * g + 4 * half, v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
 }
 
-__device__ __forceinline__ void hidden_layer16(MlpLds16& L, const f16x8* frags, const float* bias, const float* ln_g,
-                                               const float* ln_b, const char* in_hi, const char* in_lo, char* out_hi,
-                                               char* out_lo, int wave, int lane) {
+// bias + LayerNorm(channels) + LeakyReLU on the accumulator tile of wave `wave`, result -> XT buffer `out`
+__device__ __forceinline__ void ln_epilogue(MlpLds16& L, const f32x16& acc, const float* bias, const float* ln_g,
+                                            const float* ln_b, char* out_hi, char* out_lo, int wave, int lane) {
   const int half = lane >> 5, col = lane & 31;
-  f32x16 acc;
-  gemm_tile16<8>(frags, wave, in_hi, in_lo, lane, acc);
   float v[16];
   float s = 0.0f;
 #pragma unroll
@@ -348,9 +354,13 @@ __device__ __forceinline__ void hidden_layer16(MlpLds16& L, const f16x8* frags, 
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void frame_mlps16_kernel(NwsWeights w, const float* __restrict__ gru_out, int T,
-                                                           float* __restrict__ emb_out, float* __restrict__ film_out,
-                                                           float* __restrict__ H_out, float* __restrict__ fir_out) {
+// The layer sequence is static, so the weight fragments are software-pipelined by hand: while layer l's epilogue
+// (LayerNorm: two workgroup barriers and an LDS exchange) runs, layer l+1's 16 KB of fragments are already in flight
+// from L2 into the other register set (A0 / A1 alternate; a barrier is a memory fence to hipcc, so loads written
+// after it would only be issued once every wave has arrived).
+__global__ __launch_bounds__(256, 2) void frame_mlps16_kernel(NwsWeights w, const float* __restrict__ gru_out, int T,
+                                                              float* __restrict__ emb_out, float* __restrict__ film_out,
+                                                              float* __restrict__ H_out, float* __restrict__ fir_out) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   MlpLds16& L = *reinterpret_cast<MlpLds16*>(smem_raw);
   const f16x8* F = reinterpret_cast<const f16x8*>(w.mlp_frags);
@@ -359,7 +369,11 @@ __global__ __launch_bounds__(256) void frame_mlps16_kernel(NwsWeights w, const f
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * kFT;
   const int frames_valid = T - t0 < kFT ? T - t0 : kFT;
+  AFrag<8> A0, A1;
+  AFrag<9> A9;
+  f32x16 acc;
 
+  load_frags<8>(A0, F + frag_map(0).base, wave, lane);  // proj
   // ---- gru_out tile -> XT p0 (4 channels per thread per pass) ----
   for (int e = tid; e < kFT * (NWS_HIDDEN / 4); e += 256) {
     const int f = e >> 5, c4 = (e & 31) * 4;
@@ -375,9 +389,9 @@ __global__ __launch_bounds__(256) void frame_mlps16_kernel(NwsWeights w, const f
   __syncthreads();
 
   // ---- emb = proj(gru_out) ----
+  mma_tile<8>(A0, L.p0[0], L.p0[1], lane, acc);
+  load_frags<8>(A1, F + frag_map(1).base, wave, lane);  // newt hidden 0
   {
-    f32x16 acc;
-    gemm_tile16<8>(F + frag_map(0).base, wave, L.p0[0], L.p0[1], lane, acc);
     float v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -390,63 +404,85 @@ __global__ __launch_bounds__(256) void frame_mlps16_kernel(NwsWeights w, const f
   __syncthreads();
 
   // ---- film = newt.mlp(emb) ----
-  hidden_layer16(L, F + frag_map(1).base, w.newt_mlp_b[0], w.newt_ln_g[0], w.newt_ln_b[0], L.emb[0], L.emb[1], L.p0[0], L.p0[1], wave, lane);
-  hidden_layer16(L, F + frag_map(2).base, w.newt_mlp_b[1], w.newt_ln_g[1], w.newt_ln_b[1], L.p0[0], L.p0[1], L.p1[0], L.p1[1], wave, lane);
-  hidden_layer16(L, F + frag_map(3).base, w.newt_mlp_b[2], w.newt_ln_g[2], w.newt_ln_b[2], L.p1[0], L.p1[1], L.p0[0], L.p0[1], wave, lane);
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    const int mt = wave + 4 * pass;
-    f32x16 acc;
-    gemm_tile16<8>(F + frag_map(4).base, mt, L.p0[0], L.p0[1], lane, acc);
+  mma_tile<8>(A1, L.emb[0], L.emb[1], lane, acc);
+  load_frags<8>(A0, F + frag_map(2).base, wave, lane);
+  ln_epilogue(L, acc, w.newt_mlp_b[0], w.newt_ln_g[0], w.newt_ln_b[0], L.p0[0], L.p0[1], wave, lane);
+  mma_tile<8>(A0, L.p0[0], L.p0[1], lane, acc);
+  load_frags<8>(A1, F + frag_map(3).base, wave, lane);
+  ln_epilogue(L, acc, w.newt_mlp_b[1], w.newt_ln_g[1], w.newt_ln_b[1], L.p1[0], L.p1[1], wave, lane);
+  mma_tile<8>(A1, L.p1[0], L.p1[1], lane, acc);
+  load_frags<8>(A0, F + frag_map(4).base, wave, lane);      // newt out, M-tile wave
+  ln_epilogue(L, acc, w.newt_mlp_b[2], w.newt_ln_g[2], w.newt_ln_b[2], L.p0[0], L.p0[1], wave, lane);
+  {
     float v[16];
+    mma_tile<8>(A0, L.p0[0], L.p0[1], lane, acc);
+    load_frags<8>(A1, F + frag_map(4).base, wave + 4, lane);  // newt out, M-tile wave+4
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = acc[r] + w.newt_mlp_b[3][32 * mt + frag_row(r, half)];
-    store_tile_frame_major(L.stage[wave], v, lane, film_out + ((size_t)b * T + t0) * NWS_FILM_CH + 32 * mt, NWS_FILM_CH,
+    for (int r = 0; r < 16; ++r) v[r] = acc[r] + w.newt_mlp_b[3][32 * wave + frag_row(r, half)];
+    store_tile_frame_major(L.stage[wave], v, lane, film_out + ((size_t)b * T + t0) * NWS_FILM_CH + 32 * wave, NWS_FILM_CH,
                            frames_valid);
+    mma_tile<8>(A1, L.p0[0], L.p0[1], lane, acc);
+    load_frags<8>(A0, F + frag_map(5).base, wave, lane);      // hgen hidden 0
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc[r] + w.newt_mlp_b[3][32 * (wave + 4) + frag_row(r, half)];
+    store_tile_frame_major(L.stage[wave], v, lane, film_out + ((size_t)b * T + t0) * NWS_FILM_CH + 32 * (wave + 4),
+                           NWS_FILM_CH, frames_valid);
   }
   __syncthreads();
 
   // ---- H = h_generator(emb) ----
-  hidden_layer16(L, F + frag_map(5).base, w.hgen_b[0], w.hgen_ln_g[0], w.hgen_ln_b[0], L.emb[0], L.emb[1], L.p0[0], L.p0[1], wave, lane);
-  hidden_layer16(L, F + frag_map(6).base, w.hgen_b[1], w.hgen_ln_g[1], w.hgen_ln_b[1], L.p0[0], L.p0[1], L.p1[0], L.p1[1], wave, lane);
-  hidden_layer16(L, F + frag_map(7).base, w.hgen_b[2], w.hgen_ln_g[2], w.hgen_ln_b[2], L.p1[0], L.p1[1], L.p0[0], L.p0[1], wave, lane);
+  mma_tile<8>(A0, L.emb[0], L.emb[1], lane, acc);
+  load_frags<8>(A1, F + frag_map(6).base, wave, lane);
+  ln_epilogue(L, acc, w.hgen_b[0], w.hgen_ln_g[0], w.hgen_ln_b[0], L.p0[0], L.p0[1], wave, lane);
+  mma_tile<8>(A1, L.p0[0], L.p0[1], lane, acc);
+  load_frags<8>(A0, F + frag_map(7).base, wave, lane);
+  ln_epilogue(L, acc, w.hgen_b[1], w.hgen_ln_g[1], w.hgen_ln_b[1], L.p1[0], L.p1[1], wave, lane);
+  mma_tile<8>(A0, L.p1[0], L.p1[1], lane, acc);
+  load_frags<8>(A1, F + frag_map(8).base, wave, lane);      // hgen out, M-tile wave
+  ln_epilogue(L, acc, w.hgen_b[2], w.hgen_ln_g[2], w.hgen_ln_b[2], L.p0[0], L.p0[1], wave, lane);
   // 129 outputs: M-tiles 0..3 by the four waves, M-tile 4 (row 128 only) by wave 0; H -> p1 channels 0..128,
-  // channels 129..143 stay zero (tile 4 stores rows 128..143: row 128 = H[128], the rest computes to 0 from zero weights
-  // and a zero bias, keeping the padding clean)
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    if (pass == 1 && wave != 0) break;
-    const int mt = pass == 0 ? wave : 4;
-    f32x16 acc;
-    gemm_tile16<8>(F + frag_map(8).base, mt, L.p0[0], L.p0[1], lane, acc);
+  // channels 129..143 stay zero (zero weights, zero bias)
+  {
     float v[16];
+    mma_tile<8>(A1, L.p0[0], L.p0[1], lane, acc);
+    load_frags<9>(A9, F + frag_map(9).base, wave, lane);     // FIR design, M-tile wave
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int c = 32 * mt + frag_row(r, half);
-      v[r] = c < NWS_N_BANDS ? acc[r] + w.hgen_b[3][c] : 0.0f;
-      if (H_out != nullptr && c < NWS_N_BANDS && col < frames_valid) H_out[((size_t)b * T + t0 + col) * NWS_N_BANDS + c] = v[r];
+      const int c = 32 * wave + frag_row(r, half);
+      v[r] = acc[r] + w.hgen_b[3][c];
+      if (H_out != nullptr && col < frames_valid) H_out[((size_t)b * T + t0 + col) * NWS_N_BANDS + c] = v[r];
     }
-    if (mt < 4) {
-      store_tile_xt(L.p1[0], L.p1[1], 32 * mt, v, lane);
-    } else {  // rows 128..143 only (g = 0, 1): the XT row holds 144 channels
+    store_tile_xt(L.p1[0], L.p1[1], 32 * wave, v, lane);
+    if (wave == 0) {
+      load_frags<8>(A0, F + frag_map(8).base, 4, lane);      // M-tile 4 = row 128 (not prefetched: register budget)
+      mma_tile<8>(A0, L.p0[0], L.p0[1], lane, acc);
 #pragma unroll
-      for (int g = 0; g < 2; ++g)
+      for (int r = 0; r < 16; ++r) {
+        const int c = 128 + frag_row(r, half);
+        v[r] = c < NWS_N_BANDS ? acc[r] + w.hgen_b[3][c] : 0.0f;
+        if (H_out != nullptr && c < NWS_N_BANDS && col < frames_valid) H_out[((size_t)b * T + t0 + col) * NWS_N_BANDS + c] = v[r];
+      }
+#pragma unroll
+      for (int g = 0; g < 2; ++g)  // rows 128..143 only: the XT row holds 144 channels
         split4_store(L.p1[0], L.p1[1], col, 128 + 8 * g + 4 * half, v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
     }
   }
   __syncthreads();
 
   // ---- fir = D * H  (256 taps, K = 144 padded) ----
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    const int mt = wave + 4 * pass;
-    f32x16 acc;
-    gemm_tile16<9>(F + frag_map(9).base, mt, L.p1[0], L.p1[1], lane, acc);
+  {
     float v[16];
+    mma_tile<9>(A9, L.p1[0], L.p1[1], lane, acc);
+    load_frags<9>(A9, F + frag_map(9).base, wave + 4, lane);
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = acc[r];
-    store_tile_frame_major(L.stage[wave], v, lane, fir_out + ((size_t)b * T + t0) * NWS_FIR_LEN + 32 * mt, NWS_FIR_LEN,
+    store_tile_frame_major(L.stage[wave], v, lane, fir_out + ((size_t)b * T + t0) * NWS_FIR_LEN + 32 * wave, NWS_FIR_LEN,
                            frames_valid);
+    mma_tile<9>(A9, L.p1[0], L.p1[1], lane, acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc[r];
+    store_tile_frame_major(L.stage[wave], v, lane, fir_out + ((size_t)b * T + t0) * NWS_FIR_LEN + 32 * (wave + 4),
+                           NWS_FIR_LEN, frames_valid);
   }
 }
 
