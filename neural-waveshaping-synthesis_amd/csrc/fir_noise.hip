@@ -9,8 +9,9 @@
 // 0-31 compute the first half of frame t's circular convolution (4 outputs each), lanes 32-63 the
 // second half of frame t-1's; the two contributions meet with one half-swap.  Taps and noise are
 // staged in LDS per workgroup (4 consecutive hops share 5 frames).  Each lane keeps a sliding
-// 8-tap register window, so one ds_read_b128 of taps + one broadcast ds_read_b128 of noise feed
-// 16 FMAs.  The NEWT branch is added here (cat + sum(1), models/neural_waveshaping.py:85-86).
+// 8-tap register window of the taps and of a copy delayed by one sample (so that tap PAIRS are
+// even-aligned for both output parities): two ds_read_b128 of taps + one broadcast ds_read_b128 of
+// noise feed 8 v_pk_fma_f32 = 16 MACs.  The NEWT branch is added here (cat + sum(1), models/neural_waveshaping.py:85-86).
 #include "nws_common.h"
 
 namespace {
@@ -21,6 +22,7 @@ constexpr int kHopsPerBlock = 4;
 
 struct NoiseLds {
   float taps[kHopsPerBlock + 1][kL];          // fir of frames t0-1 .. t0+3
+  float taps1[kHopsPerBlock + 1][kL];         // the same taps delayed by one: taps1[k] = taps[(k-1) & 255]
   float sig[(kHopsPerBlock + 1) * kHop + kHop];  // padded noise [128(t0-1), 128(t0+3)+256)
 };
 
@@ -47,7 +49,9 @@ __global__ __launch_bounds__(256) void fir_noise_kernel(const float* __restrict_
   for (int e = tid; e < (kHopsPerBlock + 1) * kL; e += 256) {
     const int fr = e >> 8, k = e & 255;
     const int t = t0 - 1 + fr;
-    L.taps[fr][k] = (t >= 0 && t < T) ? fir[((size_t)b * T + t) * kL + k] : 0.0f;
+    const float v = (t >= 0 && t < T) ? fir[((size_t)b * T + t) * kL + k] : 0.0f;
+    L.taps[fr][k] = v;
+    L.taps1[fr][(k + 1) & 255] = v;
   }
   for (int e = tid; e < (kHopsPerBlock + 1) * kHop + kHop; e += 256) {
     const int i = (t0 - 1) * kHop + e;  // index into the padded noise, valid range [0, N+255)
@@ -63,35 +67,36 @@ __global__ __launch_bounds__(256) void fir_noise_kernel(const float* __restrict_
   const float* f = &L.sig[slot * kHop];        // frame samples f[0..255]
   const float* h = L.taps[slot];
 
-  float y0 = 0.0f, y1 = 0.0f, y2 = 0.0f, y3 = 0.0f;
-  // y[nb+i] = sum_m f[m] h[(nb+i-m) & 255];  m = m0+k, window hi = h[nb-m0 .. +3], lo = h[nb-m0-4 .. -1]
-  float4 hi = *reinterpret_cast<const float4*>(&h[nb & 255]);
+  // y[nb+i] = sum_m f[m] h[(nb+i-m) & 255], four outputs per lane, TWO taps per packed FMA:
+  //   y_i += {f[m+1], f[m]} * {A[je], A[je+1]}   (m even; lanes: f[m+1] h[n_i-m-1]  and  f[m] h[n_i-m])
+  // the pair (A[je], A[je+1]) must be even-aligned: for odd i it is (h[j-1], h[j]) of the natural array, for even i
+  // (h[j-1], h[j]) = (h1[j], h1[j+1]) of the copy delayed by one sample.  With base = nb - m0 (multiple of 4) the pairs
+  // needed per 4 taps are at base-2, base, base+2 of each array: a sliding window of two quads (hi = [base, base+4),
+  // lo = [base-4, base)), one new ds_read_b128 per array per iteration.
+  const float* h1 = L.taps1[slot];
+  f32x2 a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f}, a2 = {0.0f, 0.0f}, a3 = {0.0f, 0.0f};
+  float4 hi0 = *reinterpret_cast<const float4*>(&h[nb & 255]);
+  float4 hi1 = *reinterpret_cast<const float4*>(&h1[nb & 255]);
 #pragma unroll 4
   for (int m0 = 0; m0 < kL; m0 += 4) {
-    const float4 lo = *reinterpret_cast<const float4*>(&h[(nb - m0 - 4) & 255]);
+    const float4 lo0 = *reinterpret_cast<const float4*>(&h[(nb - m0 - 4) & 255]);
+    const float4 lo1 = *reinterpret_cast<const float4*>(&h1[(nb - m0 - 4) & 255]);
     const float4 fv = *reinterpret_cast<const float4*>(&f[m0]);
-    // k = 0: h[nb+i-m0]
-    y0 = fmaf(fv.x, hi.x, y0);
-    y1 = fmaf(fv.x, hi.y, y1);
-    y2 = fmaf(fv.x, hi.z, y2);
-    y3 = fmaf(fv.x, hi.w, y3);
-    // k = 1: h[nb+i-m0-1]
-    y0 = fmaf(fv.y, lo.w, y0);
-    y1 = fmaf(fv.y, hi.x, y1);
-    y2 = fmaf(fv.y, hi.y, y2);
-    y3 = fmaf(fv.y, hi.z, y3);
-    // k = 2
-    y0 = fmaf(fv.z, lo.z, y0);
-    y1 = fmaf(fv.z, lo.w, y1);
-    y2 = fmaf(fv.z, hi.x, y2);
-    y3 = fmaf(fv.z, hi.y, y3);
-    // k = 3
-    y0 = fmaf(fv.w, lo.y, y0);
-    y1 = fmaf(fv.w, lo.z, y1);
-    y2 = fmaf(fv.w, lo.w, y2);
-    y3 = fmaf(fv.w, hi.x, y3);
-    hi = lo;
+    const f32x2 fs0 = {fv.y, fv.x}, fs1 = {fv.w, fv.z};
+    // odd outputs (natural taps)
+    a1 = fma2(fs0, f32x2{hi0.x, hi0.y}, a1);
+    a3 = fma2(fs0, f32x2{hi0.z, hi0.w}, a3);
+    a1 = fma2(fs1, f32x2{lo0.z, lo0.w}, a1);
+    a3 = fma2(fs1, f32x2{hi0.x, hi0.y}, a3);
+    // even outputs (taps delayed by one)
+    a0 = fma2(fs0, f32x2{hi1.x, hi1.y}, a0);
+    a2 = fma2(fs0, f32x2{hi1.z, hi1.w}, a2);
+    a0 = fma2(fs1, f32x2{lo1.z, lo1.w}, a0);
+    a2 = fma2(fs1, f32x2{hi1.x, hi1.y}, a2);
+    hi0 = lo0;
+    hi1 = lo1;
   }
+  const float y0 = a0.x + a0.y, y1 = a1.x + a1.y, y2 = a2.x + a2.y, y3 = a3.x + a3.y;
   // overlap-add of the two frames covering this hop, divided by the overlap count
   const float o0 = y0 + nws_swap_halves(y0);
   const float o1 = y1 + nws_swap_halves(y1);
