@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=60)
     ap.add_argument("--batch1-iters", type=int, default=200)
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps are issued on round-robin (independent forwards overlap: the GRU of "
                          "step i+1 only occupies B CUs while step i's sample-rate kernels fill the rest)")
     return ap.parse_args()
@@ -255,7 +255,12 @@ def main():
             "rtf_per_utterance": (ms_per_step * 1e-3) / (N / 16000.0) / B,
             "roofline": {"bound": "mfma", "kernel": "exciter_newt_kernel", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel_ms": k_ms, "flop_per_launch": flops},
+                         "kernel_ms": k_ms, "flop_per_launch": flops,
+                         # the same kernel with nothing else in flight (diagnostic pass, one stream): steps of the timed
+                         # region overlap on --streams HIP streams, which stretches each individual launch
+                         "kernel_ms_isolated": extra.get("stage_ms", {}).get("exciter_newt"),
+                         "frac_isolated": (flops / (extra["stage_ms"]["exciter_newt"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS)
+                         if extra.get("stage_ms") else None},
         }
         out.update(extra)
         if world == 1 and not a.no_cpu_baseline:
