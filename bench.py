@@ -108,6 +108,7 @@ def main():
     control = torch.rand(B, 2, T, device=dev, generator=g)    # time_forward_pass.py:27-33
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, a.streams))]
+    shared_gen = par.make_shared_generator(dev) if world > 1 else None   # same draws on every rank, no broadcast
     full = [torch.empty((B * world, N), dtype=torch.float32, device=dev) for _ in streams] if world > 1 else None
 
     def step(i, pending):
@@ -121,7 +122,7 @@ def main():
                 full[i % len(streams)].copy_(torch.cat(parts, 0))
                 return None
             if world > 1:
-                pu, nz = par.shared_draws(101, N - 1, dev)       # identical draws on all ranks
+                pu, nz = par.shared_draws(101, N - 1, dev, generator=shared_gen)   # identical on all ranks
                 y = model(f0, control, phase_u=pu, noise=nz)
                 if pending is not None:
                     pending.wait()

@@ -22,8 +22,20 @@ def shard_bounds(batch: int, world: int, rank: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def shared_draws(n_harmonics: int, n_noise: int, device, group=None, src: int = 0):
-    """The two hidden draws of forward(), identical on every rank (drawn on `src`, broadcast)."""
+def make_shared_generator(device, seed: int = 0x5EED):
+    """A generator seeded identically on every rank: draws from it agree across ranks with no communication
+    (same Philox seed and offset sequence), which keeps the per-step broadcast off the critical path."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    return g
+
+
+def shared_draws(n_harmonics: int, n_noise: int, device, group=None, src: int = 0, generator=None):
+    """The two hidden draws of forward(), identical on every rank: either drawn from an identically seeded
+    `generator` on every rank (no collective), or drawn on `src` and broadcast."""
+    if generator is not None:
+        return (torch.rand(n_harmonics, device=device, generator=generator),      # draw #1 (generators.py:55)
+                torch.rand(n_noise, device=device, generator=generator))          # draw #2 (generators.py:30)
     buf = torch.empty(n_harmonics + n_noise, dtype=torch.float32, device=device)
     if not dist.is_initialized() or dist.get_rank(group) == src:
         buf[:n_harmonics] = torch.rand(n_harmonics, device=device)   # draw #1 (generators.py:55)

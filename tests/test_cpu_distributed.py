@@ -47,6 +47,11 @@ def _worker(rank, world, port, B, tmp):
         if work is not None:
             work.wait()
         ref = oracle(f0, control, pu, nz)
+        gen = par.make_shared_generator(torch.device("cpu"), seed=99)     # collective-free variant: same seed everywhere
+        pu2, nz2 = par.shared_draws(101, 128 * T - 1, torch.device("cpu"), generator=gen)
+        pu3, nz3 = par.shared_draws(101, 128 * T - 1, torch.device("cpu"), generator=gen)
+        assert not torch.equal(nz2, nz3)                                     # the stream advances between steps
+        np.save(os.path.join(tmp, f"g{rank}.npy"), np.concatenate([pu2.numpy(), nz2.numpy(), pu3.numpy(), nz3.numpy()]))
         np.save(os.path.join(tmp, f"r{rank}.npy"), np.stack([full.numpy(), out.numpy(), ref.numpy()]))
         np.save(os.path.join(tmp, f"d{rank}.npy"), np.concatenate([pu.numpy(), nz.numpy()]))
     finally:
@@ -60,6 +65,7 @@ def test_two_rank_sharded_render_equals_unsharded(tmp_path, B):
     r0, r1 = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
     d0, d1 = np.load(tmp_path / "d0.npy"), np.load(tmp_path / "d1.npy")
     assert np.array_equal(d0, d1)                       # one draw, broadcast from rank 0
+    assert np.array_equal(np.load(tmp_path / "g0.npy"), np.load(tmp_path / "g1.npy"))   # seeded generators agree
     for r in (r0, r1):
         assert r.shape[1] == B
         assert np.array_equal(r[0], r[2])               # gathered shards == un-sharded render, bit for bit
