@@ -165,3 +165,26 @@ def test_product_path_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("oracle's", "").lower() or f in ("parallel.py",), (dirpath, f)
+
+
+def test_normalisation_front_end(tmp_path):
+    """checkpoint.load_normalisation / make_control (colab cells 6 and 15): control = (x - mean) / std with
+    rows 0 (F0) and 1 (loudness) of data_mean / data_std, F0 itself handed to the model in Hz."""
+    ck = importlib.import_module("neural-waveshaping-synthesis_amd.checkpoint")
+    rng = np.random.default_rng(3)
+    mean, std = rng.normal(size=(19, 1)).astype(np.float32), rng.uniform(0.5, 2, size=(19, 1))
+    np.save(tmp_path / "data_mean.npy", mean)
+    np.save(tmp_path / "data_std.npy", std)
+    m, s = ck.load_normalisation(str(tmp_path))
+    assert m.shape == (19,) and s.dtype == np.float64
+    f0_hz, loud = 440.0 + rng.normal(size=50), rng.uniform(0, 1, size=50)
+    f0, control = ck.make_control(f0_hz, loud, m, s)
+    assert f0.shape == (1, 50) and control.shape == (2, 50) and f0.dtype == torch.float32
+    assert np.allclose(f0.numpy()[0], f0_hz, rtol=1e-6)
+    assert np.allclose(control.numpy()[0], (f0_hz - mean[0, 0]) / std[0, 0], rtol=1e-5)
+    assert np.allclose(control.numpy()[1], (loud - mean[1, 0]) / std[1, 0], rtol=1e-5)
+    ref = "/root/reference/checkpoints/nws/vn"
+    if os.path.exists(ref):
+        m2, s2 = ck.load_normalisation(ref)
+        w = np.load(os.path.join(ROOT, "tests", "golden", "weights_vn.npz"))
+        assert np.allclose(m2[:2], w["__data_mean__"]) and np.allclose(s2[:2], w["__data_std__"])
