@@ -136,6 +136,10 @@ int nws_exciter_newt(const NwsWeights* w, const float* f0, const float* f0_up, c
  * gru_out: (B, T, 128).
  */
 int nws_control_gru(const NwsWeights* w, const float* control, int B, int C, int T, float* gru_out, void* stream);
+/* same with an explicit initial state h0 (B,128) [NULL = zeros] and the final state written to hT (B,128) [NULL = dropped]:
+ * stateful streaming; the reference's forward is the h0 = 0 case */
+int nws_control_gru_state(const NwsWeights* w, const float* control, int B, int C, int T, const float* h0, float* gru_out,
+                          float* hT, void* stream);
 
 /*
  * Frame-rate MLPs on the GRU output (one kernel):
@@ -165,6 +169,10 @@ int nws_fir_design_matrix(const float* window /* (256) */, float* D_out, void* s
  */
 int nws_fir_noise(const float* fir /* (B,T,256) */, const float* noise /* (N-1) */, const float* add_in /* (B,N) */,
                   int B, int T, float* out /* (B,N) */, void* stream);
+/* general form: STFT frame t covers noise[128 t - origin, 128 t - origin + 256), reflected about 0 and noise_len-1 like
+ * torch.stft's reflect padding (nws_fir_noise == origin 128, noise_len N-1); streaming windows use origin 0 */
+int nws_fir_noise_window(const float* fir, const float* noise, int noise_len, int origin, const float* add_in, int B, int T,
+                         float* out, void* stream);
 
 /* ---- learned reverb (models/modules/shaping.py:161-173): y = x + circconv_L(x, [0, ir])[:N], L = max(N, ir_len+1) ---- */
 typedef struct NwsReverbPlan {
@@ -185,6 +193,12 @@ int nws_reverb_ir_spectrum(const NwsReverbPlan* plan, const void* tables, const 
                            void* spectrum, void* workspace, size_t workspace_bytes, void* stream);
 int nws_reverb(const NwsReverbPlan* plan, const void* tables, const void* spectrum, const float* x /* (B,N) */,
                int B, int N, float* y /* (B,N) */, void* workspace, size_t workspace_bytes, void* stream);
+
+/* streaming (LINEAR, non-wrapping) variant, one chunk of M samples: y = x + wet[0:M] + tail_in[0:M]; tail_out = shifted
+ * tail_in + rest of wet.  plan->L >= M + tail_len (tail_len = len(ir)+1 = 32000); workspace (2*ceil(B/2)*L + B*L) floats. */
+int nws_reverb_linear_chunk(const NwsReverbPlan* plan, const void* tables, const void* spectrum, const float* x, int B, int M,
+                            const float* tail_in, float* tail_out, int tail_len, float* y, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 /* ---- FastNEWT table (models/modules/shaping.py:107-119): table[s][i] = shaper_s(linspace(min,max,size)[i]) ---- */
 int nws_shaper_table(const NwsWeights* w, int table_size, float table_min, float table_max, float* table_out, void* stream);

@@ -58,10 +58,14 @@ _PROTOTYPES = {
     "nws_exciter_newt": (C.c_int, [C.POINTER(NwsWeights), _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_float,
                                    _fp, _fp, _fp]),
     "nws_control_gru": (C.c_int, [C.POINTER(NwsWeights), _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "nws_control_gru_state": (C.c_int, [C.POINTER(NwsWeights), _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
     "nws_frame_mlps": (C.c_int, [C.POINTER(NwsWeights), _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp]),
     "nws_mlp_frags": (C.c_int, [C.POINTER(NwsWeights), _fp, _fp, _fp]),
     "nws_fir_design_matrix": (C.c_int, [_fp, _fp, _fp]),
     "nws_fir_noise": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp]),
+    "nws_fir_noise_window": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp]),
+    "nws_reverb_linear_chunk": (C.c_int, [C.POINTER(NwsReverbPlan), _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, C.c_int, _fp, _fp,
+                                          C.c_size_t, _fp]),
     "nws_reverb_plan": (C.c_int, [C.c_int, C.c_int, C.POINTER(NwsReverbPlan)]),
     "nws_reverb_table_bytes": (C.c_size_t, [C.POINTER(NwsReverbPlan)]),
     "nws_reverb_spectrum_bytes": (C.c_size_t, [C.POINTER(NwsReverbPlan)]),

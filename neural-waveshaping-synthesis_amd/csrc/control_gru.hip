@@ -47,7 +47,8 @@ __device__ __forceinline__ float fast_tanh(float x) {
 }
 
 __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const float* __restrict__ control, int C,
-                                                             int T, float* __restrict__ gru_out) {
+                                                             int T, const float* __restrict__ h0,
+                                                             float* __restrict__ gru_out, float* __restrict__ hT) {
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -76,10 +77,11 @@ __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const
   const float bi_r = w.gru_b_ih[unit], bi_z = w.gru_b_ih[kH + unit], bi_n = w.gru_b_ih[2 * kH + unit];
   const float bh_r = w.gru_b_hh[unit], bh_z = w.gru_b_hh[kH + unit], bh_n = w.gru_b_hh[2 * kH + unit];
 
-  if (tid < kH) h_lds[0][tid] = 0.0f;
+  // h0 == nullptr: zero initial state (the reference's stateless forward); streaming passes the carried state
+  float h_prev = h0 != nullptr ? h0[(size_t)b * kH + unit] : 0.0f;
+  if (tid < kH) h_lds[0][tid] = h0 != nullptr ? h0[(size_t)b * kH + tid] : 0.0f;
   const float* x0p = control + ((size_t)b * C + 0) * T;
   const float* x1p = control + ((size_t)b * C + 1) * T;
-  float h_prev = 0.0f;
 
   for (int t0 = 0; t0 < T; t0 += kXChunk) {
     const int nt = T - t0 < kXChunk ? T - t0 : kXChunk;
@@ -127,15 +129,21 @@ __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const
       lds_barrier();
     }
   }
+  if (hT != nullptr && kh == 0) hT[(size_t)b * kH + unit] = h_prev;
 }
 
 }  // namespace
 
-extern "C" int nws_control_gru(const NwsWeights* w, const float* control, int B, int C, int T, float* gru_out,
-                               void* stream) {
+extern "C" int nws_control_gru_state(const NwsWeights* w, const float* control, int B, int C, int T, const float* h0,
+                                     float* gru_out, float* hT, void* stream) {
   if (!w || !w->gru_w_ih || !w->gru_w_hh || !w->gru_b_ih || !w->gru_b_hh || !control || !gru_out) return NWS_ERR_BAD_ARG;
   if (B <= 0 || T <= 0 || C < 2) return NWS_ERR_BAD_ARG;
-  control_gru_kernel<<<B, 256, 0, (hipStream_t)stream>>>(*w, control, C, T, gru_out);
+  control_gru_kernel<<<B, 256, 0, (hipStream_t)stream>>>(*w, control, C, T, h0, gru_out, hT);
   NWS_CHECK_LAUNCH();
   return NWS_OK;
+}
+
+extern "C" int nws_control_gru(const NwsWeights* w, const float* control, int B, int C, int T, float* gru_out,
+                               void* stream) {
+  return nws_control_gru_state(w, control, B, C, T, nullptr, gru_out, nullptr, stream);
 }

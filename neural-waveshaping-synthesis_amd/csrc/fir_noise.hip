@@ -26,9 +26,10 @@ struct NoiseLds {
   float sig[(kHopsPerBlock + 1) * kHop + kHop];  // padded noise [128(t0-1), 128(t0+3)+256)
 };
 
-// reflect-padded noise (torch.stft center=True, pad_mode="reflect", pad 128 each side); len = N-1
-__device__ __forceinline__ float padded_noise(const float* __restrict__ noise, int len, int i) {
-  int s = i - kL / 2;
+// reflect-padded noise (torch.stft center=True, pad_mode="reflect", pad 128 each side).  One-shot forward: origin = 128,
+// len = N-1.  Streaming windows pass the absolute noise stream with origin 0 and a len that only bites at the stream's end.
+__device__ __forceinline__ float padded_noise(const float* __restrict__ noise, int len, int origin, int i) {
+  int s = i - origin;
   if (s < 0) s = -s;
   if (s > len - 1) s = 2 * (len - 1) - s;
   s = s < 0 ? 0 : s;
@@ -36,7 +37,7 @@ __device__ __forceinline__ float padded_noise(const float* __restrict__ noise, i
 }
 
 __global__ __launch_bounds__(256) void fir_noise_kernel(const float* __restrict__ fir, const float* __restrict__ noise,
-                                                        const float* __restrict__ add_in, int T,
+                                                        const float* __restrict__ add_in, int T, int len, int origin,
                                                         float* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) NoiseLds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -44,7 +45,6 @@ __global__ __launch_bounds__(256) void fir_noise_kernel(const float* __restrict_
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * kHopsPerBlock;
   const int N = T * kHop;
-  const int len = N - 1;
 
   for (int e = tid; e < (kHopsPerBlock + 1) * kL; e += 256) {
     const int fr = e >> 8, k = e & 255;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void fir_noise_kernel(const float* __restrict_
   }
   for (int e = tid; e < (kHopsPerBlock + 1) * kHop + kHop; e += 256) {
     const int i = (t0 - 1) * kHop + e;  // index into the padded noise, valid range [0, N+255)
-    L.sig[e] = (i >= 0 && i < N + kL - 1) ? padded_noise(noise, len, i) : 0.0f;
+    L.sig[e] = (i >= 0 && i < N + kL - 1) ? padded_noise(noise, len, origin, i) : 0.0f;
   }
   __syncthreads();
 
@@ -119,12 +119,17 @@ __global__ __launch_bounds__(256) void fir_noise_kernel(const float* __restrict_
 
 }  // namespace
 
-extern "C" int nws_fir_noise(const float* fir, const float* noise, const float* add_in, int B, int T, float* out,
-                             void* stream) {
-  if (!fir || !noise || !out || B <= 0 || T <= 0) return NWS_ERR_BAD_ARG;
+extern "C" int nws_fir_noise_window(const float* fir, const float* noise, int noise_len, int origin, const float* add_in,
+                                    int B, int T, float* out, void* stream) {
+  if (!fir || !noise || !out || B <= 0 || T <= 0 || noise_len < 2 || origin < 0) return NWS_ERR_BAD_ARG;
   if (B > 65535) return NWS_ERR_UNSUPPORTED;
   const dim3 grid((T + kHopsPerBlock - 1) / kHopsPerBlock, B);
-  fir_noise_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(fir, noise, add_in, T, out);
+  fir_noise_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(fir, noise, add_in, T, noise_len, origin, out);
   NWS_CHECK_LAUNCH();
   return NWS_OK;
+}
+
+extern "C" int nws_fir_noise(const float* fir, const float* noise, const float* add_in, int B, int T, float* out,
+                             void* stream) {
+  return nws_fir_noise_window(fir, noise, T * kHop - 1, kL / 2, add_in, B, T, out, stream);
 }

@@ -204,8 +204,8 @@ __global__ __launch_bounds__(256) void col125_inv_kernel(PlanDev d, const float2
     if (n < N) {
       const float2 v = bufB[e];
       const size_t o0 = (size_t)(2 * p) * N + n;
-      y[o0] = x[o0] + v.x;
-      if (has1) y[o0 + N] = x[o0 + N] + v.y;
+      y[o0] = (x != nullptr ? x[o0] : 0.0f) + v.x;
+      if (has1) y[o0 + N] = (x != nullptr ? x[o0 + N] : 0.0f) + v.y;
     }
   }
 }
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void col_inv_kernel(const float* __restrict__ 
     const long long n = (long long)d.N2 * n1 + c;
     if (n1 < d.N1 && utt < B && n < N) {
       const size_t o = (size_t)utt * N + n;
-      y[o] = x[o] + acc[r];
+      y[o] = (x != nullptr ? x[o] : 0.0f) + acc[r];
     }
   }
 }
@@ -361,6 +361,22 @@ __global__ __launch_bounds__(256) void row_kernel(PlanDev d, float* __restrict__
 __global__ void build_ir_kernel(const float* __restrict__ ir, int ir_len, float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i <= ir_len) out[i] = i == 0 ? 0.0f : ir[i - 1];
+}
+
+// streaming (linear) reverb: y = x + wet[0:M] + tail[0:M];  tail'[k] = tail[k+M] + wet[M+k]   (k < TL; tail beyond TL is 0)
+__global__ void reverb_tail_kernel(const float* __restrict__ x, const float* __restrict__ wet, const float* __restrict__ tail_in,
+                                   float* __restrict__ tail_out, float* __restrict__ y, int M, int L, int TL) {
+  const int b = blockIdx.y;
+  const float* w = wet + (size_t)b * L;
+  const float* ti = tail_in + (size_t)b * TL;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M + TL; i += gridDim.x * blockDim.x) {
+    if (i < M) {
+      y[(size_t)b * M + i] = x[(size_t)b * M + i] + w[i] + (i < TL ? ti[i] : 0.0f);
+    } else {
+      const int k = i - M;
+      tail_out[(size_t)b * TL + k] = (k + M < TL ? ti[k + M] : 0.0f) + (M + k < L ? w[M + k] : 0.0f);
+    }
+  }
 }
 
 bool plan_ok(const NwsReverbPlan* p) {
@@ -506,6 +522,49 @@ int nws_reverb(const NwsReverbPlan* plan, const void* tables, const void* spectr
     const dim3 g3(d.N2 / 32, (2 * nt + 3) / 4, pairs);
     col_inv_kernel<<<g3, 256, 0, st>>>(t + off_ainv(d), d, Ure, Uim, x, B, N, y);
   }
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+// One chunk of a LINEAR (streaming) reverb: the chunk's wet part is a circular convolution of length plan->L >= M + ir_len,
+// which cannot wrap; its first M samples plus the carried tail are emitted, the rest is accumulated into the new tail.
+int nws_reverb_linear_chunk(const NwsReverbPlan* plan, const void* tables, const void* spectrum, const float* x, int B, int M,
+                            const float* tail_in, float* tail_out, int tail_len, float* y, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  if (!plan_ok(plan) || !tables || !spectrum || !x || !y || !tail_in || !tail_out || !workspace) return NWS_ERR_BAD_ARG;
+  if (B <= 0 || M <= 0 || tail_len <= 0 || M + tail_len > plan->L) return NWS_ERR_BAD_ARG;
+  const PlanDev d = plan_dev(plan);
+  const int pairs = (B + 1) / 2;
+  const size_t need = (2 * (size_t)pairs * d.L + (size_t)B * d.L) * sizeof(float);
+  if (workspace_bytes < need) return NWS_ERR_WORKSPACE;
+  const float* t = static_cast<const float*>(tables);
+  hipStream_t st = (hipStream_t)stream;
+  float* Ure = static_cast<float*>(workspace);
+  float* Uim = Ure + (size_t)pairs * d.L;
+  float* wet = Uim + (size_t)pairs * d.L;  // (B, L)
+  const float* Sre = static_cast<const float*>(spectrum);
+  const float* Sim = Sre + d.L;
+  const float2* tw125 = reinterpret_cast<const float2*>(t + off_tw125(d));
+  if (d.N1 == 125) {
+    col125_fwd_kernel<<<dim3(d.N2 / 32, pairs), 256, kCol125Lds, st>>>(d, tw125, x, B, M, (long long)M, Ure, Uim);
+  } else {
+    const dim3 g1(d.N2 / 32, (d.M2 / 32 + 3) / 4, pairs);
+    col_fwd_kernel<<<g1, 256, 0, st>>>(t + off_afwd(d), d, x, B, M, (long long)M, Ure, Uim);
+  }
+  NWS_CHECK_LAUNCH();
+  row_kernel<false><<<dim3(d.N1, pairs), 256, row_lds_bytes(d), st>>>(d, Ure, Uim, reinterpret_cast<const float2*>(t + off_tw(d)),
+                                                                      reinterpret_cast<const float2*>(t + off_rowtw(d)), Sre,
+                                                                      Sim, nullptr, nullptr);
+  NWS_CHECK_LAUNCH();
+  if (d.N1 == 125) {
+    col125_inv_kernel<<<dim3(d.N2 / 32, pairs), 256, kCol125Lds, st>>>(d, tw125, Ure, Uim, nullptr, B, d.L, wet);
+  } else {
+    const int nt = (d.N1 + 31) / 32;
+    const dim3 g3(d.N2 / 32, (2 * nt + 3) / 4, pairs);
+    col_inv_kernel<<<g3, 256, 0, st>>>(t + off_ainv(d), d, Ure, Uim, nullptr, B, d.L, wet);
+  }
+  NWS_CHECK_LAUNCH();
+  reverb_tail_kernel<<<dim3(64, B), 256, 0, st>>>(x, wet, tail_in, tail_out, y, M, d.L, tail_len);
   NWS_CHECK_LAUNCH();
   return NWS_OK;
 }

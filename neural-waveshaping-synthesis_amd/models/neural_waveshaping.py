@@ -157,3 +157,13 @@ def ensure_default_config():
         gin.query_parameter("NeuralWaveshaping.control_hop")
     except ValueError:
         gin.parse_config_file(_DEFAULT_GIN)
+
+
+def _stream(self, batch_size: int = 1, *, phase_u=None, noise=None):
+    """Stateful streaming synthesiser bound to this model (see streaming.NewtStream)."""
+    from ..streaming import NewtStream
+
+    return NewtStream(self, batch_size, phase_u=phase_u, noise=noise)
+
+
+NeuralWaveshaping.stream = _stream
