@@ -223,7 +223,6 @@ typedef struct NwsForwardAux {
   const NwsReverbPlan* plan;     /* host */
   const void* reverb_tables;
   const void* reverb_spectrum;
-  const float* reverb_ir_unused; /* reserved */
 } NwsForwardAux;
 
 size_t nws_forward_workspace_bytes(const NwsReverbPlan* plan, int B, int T);

@@ -46,7 +46,7 @@ class NwsReverbPlan(C.Structure):
 
 class NwsForwardAux(C.Structure):
     _fields_ = [("fir_design", _fp), ("plan", C.POINTER(NwsReverbPlan)), ("reverb_tables", _fp),
-                ("reverb_spectrum", _fp), ("reverb_ir_unused", _fp)]
+                ("reverb_spectrum", _fp)]
 
 
 _PROTOTYPES = {

@@ -11,10 +11,7 @@ Hidden inputs, exactly like the reference: every forward draws ``rand_like(osc.r
 (generators.py:55, :30).  For parity testing the two draws can be injected with the keyword-only
 arguments ``phase_u`` and ``noise``.
 """
-import contextlib
 import os
-import sys
-import types
 
 import torch
 import torch.nn as nn

@@ -11,7 +11,6 @@ import sys
 import time
 
 import click
-import numpy as np
 import torch
 from scipy.io import wavfile
 

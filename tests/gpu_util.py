@@ -5,7 +5,7 @@ import os
 import numpy as np
 import torch
 
-from conftest import ROOT, load_npz
+from conftest import ROOT
 
 REPORT = os.path.join(ROOT, "gpurun_out", "parity_report.json")
 

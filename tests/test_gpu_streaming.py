@@ -7,7 +7,7 @@ import torch
 from scipy.signal import fftconvolve
 
 from conftest import rms
-from gpu_util import build_model, dev, maxabs, record
+from gpu_util import build_model, maxabs, record
 
 pytestmark = pytest.mark.gpu
 
