@@ -291,10 +291,14 @@ __device__ __forceinline__ LutParams make_lut_params(const NwsWeights& w) {
 struct ExcLds {
   f16x8 whi[kKSteps * 2 * 2 * 32];
   f16x8 wlo[kKSteps * 2 * 2 * 32];
-  float film[3][4][kS];         // frames j-1, j, j+1 (clamped) x {g_idx, b_idx, g_norm, b_norm} x shaper (SoA: 4
-                                // consecutive shapers = one ds_read_b128 = two packed-fp32 operands)
+  // FiLM rows of frames j-1, j, j+1 (clamped) as value + difference to the next frame, so that the reference's linear
+  // upsampling (shaping.py:69) is ONE packed FMA per parameter: p(n) = fa + w1(n) * fd.  Types: 0 g_idx, 1 b_idx,
+  // 2 out_w * g_norm (the 64->1 mixer weight folded in; its bias part  sum_s out_w[s] b_norm[s]  is the per-frame scalar bsum).
+  // SoA: 4 consecutive shapers = one ds_read_b128 = two packed-fp32 operands.
+  float fa[2][3][kS];
+  float fd[2][3][kS];
+  float bsum[4];
   float mix_b[kS];              // harmonic_mixer.bias
-  float out_w[kS];              // newt.mixer.weight
   float shift[kKPad];
 };
 
@@ -356,18 +360,28 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
       split_f16(wv, whi[frag * 8 + (kk & 7)], wlo[frag * 8 + (kk & 7)]);
     }
   }
-  if (tid < kS) {
-    L.mix_b[tid] = w.mixer_b[tid];
-    L.out_w[tid] = MODE != kModeExciterOnly ? w.newt_out_w[tid] : 0.0f;
-  }
+  if (tid < kS) L.mix_b[tid] = w.mixer_b[tid];
   // _create_phase_shift (generators.py:54-56): fl(fl(u * rand_phase) - fl32(pi))
   if (tid < kKPad) L.shift[tid] = tid < kK ? phase_u[tid] * rand_phase[tid] - kPi : 0.0f;  // kKPad = 112 <= 256
   if (MODE != kModeExciterOnly) {
-    for (int e = tid; e < 3 * NWS_FILM_CH; e += 256) {
-      const int q = e >> 8, c = e & 255;
-      int f = j - 1 + q;
-      f = f < 0 ? 0 : (f > T - 1 ? T - 1 : f);
-      L.film[q][c >> 6][c & 63] = film[((size_t)b * T + f) * NWS_FILM_CH + c];
+    const float* fb = film + (size_t)b * T * NWS_FILM_CH;
+    auto frame_of = [&](int q) {
+      const int f = j - 1 + q;
+      return f < 0 ? 0 : (f > T - 1 ? T - 1 : f);
+    };
+    for (int e = tid; e < 2 * 3 * kS; e += 256) {
+      const int q = e / (3 * kS), ty = (e / kS) % 3, sidx = e % kS;
+      const float scale = ty == 2 ? w.newt_out_w[sidx] : 1.0f;
+      const float v0 = scale * fb[(size_t)frame_of(q) * NWS_FILM_CH + ty * kS + sidx];
+      const float v1 = scale * fb[(size_t)frame_of(q + 1) * NWS_FILM_CH + ty * kS + sidx];
+      L.fa[q][ty][sidx] = v0;
+      L.fd[q][ty][sidx] = v1 - v0;
+    }
+    if (wave < 3) {  // bsum[q] = sum_s out_w[s] * b_norm[frame q][s]
+      float v = w.newt_out_w[lane] * fb[(size_t)frame_of(wave) * NWS_FILM_CH + 3 * kS + lane];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) L.bsum[wave] = v;
     }
   }
   if (MODE == kModeExact) load_shaper_lds(SH, w, tid, 256);
@@ -390,7 +404,16 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
   }
   cs += carry[(size_t)b * (N / 32) + (n >> 5)];
   const float csum = (float)cs;                                 // fl32 of the double prefix sum
-  const float phase = __fdiv_rn(kTau * csum, sample_rate);      // math.tau * cumsum / sample_rate
+  // math.tau * cumsum / sample_rate with a TRUE division: for sr = 16000 the reciprocal + one FMA correction below is the
+  // correctly rounded quotient for every fp32 numerator (checked exhaustively over all mantissas), 3 instructions
+  const float tc = kTau * csum;
+  float phase;
+  if (sample_rate == 16000.0f) {
+    const float q = tc * 6.25e-05f;   // fl32(1/16000)
+    phase = fmaf(fmaf(-q, 16000.0f, tc), 6.25e-05f, q);
+  } else {
+    phase = __fdiv_rn(tc, sample_rate);
+  }
   const float nyquist = sample_rate * 0.5f;
 
   __syncthreads();
@@ -495,12 +518,11 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
   }
 
   // ---- FiLM -> shaper -> FiLM -> 64->1 mix, all in registers ----
-  const float(*p0)[kS] = L.film[lc.i0 - (j - 1)];
-  const float(*p1)[kS] = L.film[lc.i1 - (j - 1)];
+  const int q0 = lc.i0 - (j - 1);  // 0 or 1: slot of the left frame; fd[q0] is zero where the right frame is clamped
   LutParams LP;
   if (is_lut(MODE)) LP = make_lut_params(w);
   const int lane_row_off = is_lut(MODE) ? 4 * half * w.lut_size : 0;
-  const f32x2 w0_2 = splat2(lc.w0), w1_2 = splat2(lc.w1);
+  const f32x2 w1_2 = splat2(lc.w1);
   f32x2 part2 = {0.0f, 0.0f};
   // accumulator registers 4g..4g+3 of M-tile m are the 4 consecutive shapers 32m + 8g + 4half + 0..3
 #pragma unroll
@@ -510,24 +532,22 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
       const int sb = 32 * m + 8 * g;  // compile-time part of the shaper index
       const int s4 = sb + 4 * half;
       const float4 mb = *reinterpret_cast<const float4*>(&L.mix_b[s4]);
-      const float4 ow = *reinterpret_cast<const float4*>(&L.out_w[s4]);
-      float4 fa[4], fc[4];
+      float4 fa[3], fd[3];
 #pragma unroll
-      for (int ty = 0; ty < 4; ++ty) {
-        fa[ty] = *reinterpret_cast<const float4*>(&p0[ty][s4]);
-        fc[ty] = *reinterpret_cast<const float4*>(&p1[ty][s4]);
+      for (int ty = 0; ty < 3; ++ty) {
+        fa[ty] = *reinterpret_cast<const float4*>(&L.fa[q0][ty][s4]);
+        fd[ty] = *reinterpret_cast<const float4*>(&L.fd[q0][ty][s4]);
       }
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {  // shaper pairs (s4, s4+1) and (s4+2, s4+3)
         const int r0 = 4 * g + 2 * h2;
         const f32x2 accp = m == 0 ? f32x2{acc0[r0], acc0[r0 + 1]} : f32x2{acc1[r0], acc1[r0 + 1]};
-        const f32x2 x2 = accp + (h2 == 0 ? f32x2{mb.x, mb.y} : f32x2{mb.z, mb.w});
 #define NWS_PAIR(v) (h2 == 0 ? f32x2{(v).x, (v).y} : f32x2{(v).z, (v).w})
-        const f32x2 g_i = fma2(w0_2, NWS_PAIR(fa[0]), w1_2 * NWS_PAIR(fc[0]));  // F.upsample of the FiLM parameters
-        const f32x2 b_i = fma2(w0_2, NWS_PAIR(fa[1]), w1_2 * NWS_PAIR(fc[1]));
-        const f32x2 g_n = fma2(w0_2, NWS_PAIR(fa[2]), w1_2 * NWS_PAIR(fc[2]));
-        const f32x2 b_n = fma2(w0_2, NWS_PAIR(fa[3]), w1_2 * NWS_PAIR(fc[3]));
-        const f32x2 xi = g_i * x2 + b_i;  // FiLM (models/modules/dynamic.py:8)
+        const f32x2 x2 = accp + NWS_PAIR(mb);
+        const f32x2 g_i = fma2(w1_2, NWS_PAIR(fd[0]), NWS_PAIR(fa[0]));  // F.upsample of the FiLM parameters
+        const f32x2 b_i = fma2(w1_2, NWS_PAIR(fd[1]), NWS_PAIR(fa[1]));
+        const f32x2 g_n = fma2(w1_2, NWS_PAIR(fd[2]), NWS_PAIR(fa[2]));  // already times newt.mixer.weight
+        const f32x2 xi = fma2(g_i, x2, b_i);  // FiLM (models/modules/dynamic.py:8)
         f32x2 sh;
         if (DBG == 2) {
           sh = xi;
@@ -536,8 +556,7 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
         } else {
           sh = f32x2{exact_shaper(SH, s4 + 2 * h2, xi.x), exact_shaper(SH, s4 + 2 * h2 + 1, xi.y)};
         }
-        const f32x2 y = g_n * sh + b_n;
-        part2 = fma2(NWS_PAIR(ow), y, part2);
+        part2 = fma2(g_n, sh, part2);  // normalising FiLM gain and 64->1 mix in one FMA
 #undef NWS_PAIR
       }
       // fence the scheduler per group of 4 shapers: bounded number of gathers / FiLM operands live at once
@@ -545,7 +564,9 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
     }
   }
   const float partial = part2.x + part2.y;
-  const float total = partial + nws_swap_halves(partial) + w.newt_out_b[0];
+  // the normalising FiLM biases went through the mixer per FRAME: interpolate their sum like any other parameter
+  const float bias_n = fmaf(lc.w1, L.bsum[q0 + 1] - L.bsum[q0], L.bsum[q0]);
+  const float total = partial + nws_swap_halves(partial) + (bias_n + w.newt_out_b[0]);
   if (half == 0) newt_out[(size_t)b * N + n] = total;
 }
 
