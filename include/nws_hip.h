@@ -57,8 +57,8 @@ typedef struct NwsWeights {
   /* harmonic_mixer = Conv1d(101, 64, 1) (models/neural_waveshaping.py:54) */
   const float* mixer_w;   /* (64, 101) */
   const float* mixer_b;   /* (64) */
-  const void* mixer_frags; /* optional 28672 B from nws_mixer_frags(): mixer_w as two fp16 terms in MFMA fragment order;
-                              NULL -> every workgroup splits mixer_w itself (slower prologue) */
+  const void* mixer_frags; /* optional 28672 B from nws_mixer_frags(): [mixer_b | mixer_w] as two fp16 terms in MFMA
+                              fragment order; NULL -> every workgroup splits the weights itself (slower prologue) */
   /* newt.mlp = TimeDistributedMLP(128,128,256,depth=4) (models/modules/shaping.py:53-55) */
   const float* newt_mlp_w[4]; /* (128,128) x3, (256,128) */
   const float* newt_mlp_b[4];
@@ -203,9 +203,10 @@ int nws_reverb_linear_chunk(const NwsReverbPlan* plan, const void* tables, const
 /* ---- FastNEWT table (models/modules/shaping.py:107-119): table[s][i] = shaper_s(linspace(min,max,size)[i]) ---- */
 int nws_shaper_table(const NwsWeights* w, int table_size, float table_min, float table_max, float* table_out, void* stream);
 
-/* mixer_w (64,101) -> W_hi | W_lo fp16 fragments (7 K-steps x 2 M-tiles x 2 halves x 32 lanes x 8 halfs, twice) */
+/* mixer_b (64) as K slot 0 and mixer_w (64,101) as K slots 1..101 (slots 102..111 zero) -> W_hi | W_lo fp16 fragments
+   (7 K-steps x 2 M-tiles x 2 halves x 32 lanes x 8 halfs, twice) */
 #define NWS_MIXER_FRAGS_BYTES 28672
-int nws_mixer_frags(const float* mixer_w, void* frags_out, void* stream);
+int nws_mixer_frags(const float* mixer_w, const float* mixer_b, void* frags_out, void* stream);
 
 /* derived gather-friendly form of a FastNEWT table: pairs[s][i] = {table[s][i], fl(table[s][min(i+1,size-1)] - table[s][i])} */
 int nws_lut_pairs(const float* table /* (64, size) */, int table_size, float* pairs_out /* (64, size, 2) */, void* stream);

@@ -74,7 +74,7 @@ _PROTOTYPES = {
     "nws_reverb_ir_spectrum": (C.c_int, [C.POINTER(NwsReverbPlan), _fp, _fp, C.c_int, _fp, _fp, C.c_size_t, _fp]),
     "nws_reverb": (C.c_int, [C.POINTER(NwsReverbPlan), _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, C.c_size_t, _fp]),
     "nws_shaper_table": (C.c_int, [C.POINTER(NwsWeights), C.c_int, C.c_float, C.c_float, _fp, _fp]),
-    "nws_mixer_frags": (C.c_int, [_fp, _fp, _fp]),
+    "nws_mixer_frags": (C.c_int, [_fp, _fp, _fp, _fp]),
     "nws_lut_pairs": (C.c_int, [_fp, C.c_int, _fp, _fp]),
     "nws_shaper_apply": (C.c_int, [C.POINTER(NwsWeights), _fp, C.c_int64, C.c_int64, _fp, _fp]),
     "nws_forward_workspace_bytes": (C.c_size_t, [C.POINTER(NwsReverbPlan), C.c_int, C.c_int]),

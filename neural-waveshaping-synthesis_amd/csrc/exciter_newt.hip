@@ -15,6 +15,8 @@
 // indistinguishable from the exact-fp32 MFMA it replaced, at 1/5 of its matrix-pipe time, and unlike
 // the fp32 MFMA it overlaps with the VALU work.  The 64x32 accumulator tile then goes straight through
 // FiLM -> LUT (or sin-MLP) -> FiLM -> 64->1 mix in registers; one coalesced 128 B store per wave.
+#include <type_traits>
+
 #include "nws_common.h"
 
 namespace {
@@ -275,6 +277,47 @@ __device__ __forceinline__ f32x2 lut_shaper2(const LutParams& P, int row_off, f3
   return f32x2{(u0 - l0) * fract.x + l0, (u1 - l1) * fract.y + l1};
 }
 
+// Hot-path form of lut_shaper2<true, true> (range 6, power-of-two size; chosen by the launcher):
+//  * size * (x - min) / 6 with the power of two folded into the division constants: q = y*(size/6), r = fma(-q, 6/size, y),
+//    idx = fma(r, size/6, q) is the same correctly rounded quotient (every step is the DIV6 step scaled exactly by `size`);
+//  * the gather address is  SGPR row base + 32-bit VGPR byte offset  (one v_add_lshl_u32 instead of 64-bit address math);
+//  * the table lerp T[i] + d[i]*fract is ONE fma per shaper (a single rounding where the reference has two: <= 1/2 ulp of
+//    the output, far below the sine error upstream); scalar on purpose, packing it would cost three v_mov per pair.
+struct LutFast {
+  const char* pairs;
+  float tmin, c_r, c_d, top;
+  unsigned row_bytes;
+};
+
+__device__ __forceinline__ LutFast make_lut_fast(const NwsWeights& w) {
+  LutFast P;
+  P.pairs = reinterpret_cast<const char*>(w.lut_pairs);
+  P.tmin = w.lut_min;
+  P.c_r = (float)w.lut_size * (1.0f / 6.0f);  // fl(1/6) scaled exactly
+  P.c_d = 6.0f / (float)w.lut_size;           // exact
+  P.top = (float)(w.lut_size - 1);
+  P.row_bytes = (unsigned)w.lut_size * 8u;
+  return P;
+}
+
+__device__ __forceinline__ f32x2 lut_shaper2_fast(const LutFast& P, const char* __restrict__ row0, unsigned lane_off,
+                                                  f32x2 x) {
+  const f32x2 y = x - splat2(P.tmin);
+  const f32x2 q = y * splat2(P.c_r);
+  const f32x2 r = fma2(-q, splat2(P.c_d), y);
+  const f32x2 idx = fma2(r, splat2(P.c_r), q);
+  const f32x2 fl = {__builtin_amdgcn_fmed3f(floorf(idx.x), 0.0f, P.top), __builtin_amdgcn_fmed3f(floorf(idx.y), 0.0f, P.top)};
+  const f32x2 fract = idx - fl;
+  const unsigned o0 = lane_off + ((unsigned)(int)fl.x << 3), o1 = lane_off + ((unsigned)(int)fl.y << 3);
+  const float2 a = *reinterpret_cast<const float2*>(row0 + o0);
+  const float2 b = *reinterpret_cast<const float2*>(row0 + P.row_bytes + o1);
+  // asm: left to itself hipcc re-packs the two FMAs into one v_pk_fma_f32 behind three v_mov (4 instructions instead of 2)
+  f32x2 out;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(out.x) : "v"(a.y), "v"(fract.x), "v"(a.x));
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(out.y) : "v"(b.y), "v"(fract.y), "v"(b.x));
+  return out;
+}
+
 __device__ __forceinline__ LutParams make_lut_params(const NwsWeights& w) {
   LutParams P;
   P.table = w.lut;
@@ -298,9 +341,38 @@ struct ExcLds {
   float fa[2][3][kS];
   float fd[2][3][kS];
   float bsum[4];
-  float mix_b[kS];              // harmonic_mixer.bias
-  float shift[kKPad];
+  // K slot c = 16ks + 8half + e: slot 0 is the mixer BIAS (its "sine" is the constant 1), slot c >= 1 is harmonic c
+  float shift[kKPad];           // phase shift of slot c (0 for slot 0 and the padding slots 102..111)
+  float kf[kKPad];              // (float)c: harmonic numbers as packed-FMA operands, read instead of computed
 };
+
+// harmonic_mixer as K-slot weights: slot 0 = bias, slots 1..101 = weight[:, c-1], padding slots = 0
+__device__ __forceinline__ float mixer_slot_weight(const float* __restrict__ mixer_w, const float* __restrict__ mixer_b, int s,
+                                                   int c) {
+  return c == 0 ? mixer_b[s] : (c <= kK ? mixer_w[s * kK + c - 1] : 0.0f);
+}
+
+// lo = fp16(v - hi) for a packed pair, hi given as fp16: v_fma_mix{lo,hi}_f16 read the fp16 operand directly and round the
+// (exact) difference to fp16 on the way out: 2 instructions per pair instead of 2 cvt + 1 pk_add + 1 cvt_pk.
+// (hipcc folds fma(x,-1,y) to a subtraction before it can select the mixed-precision form, hence the asm.)
+__device__ __forceinline__ f16x2 split_lo2(f16x2 hi, f32x2 v) {
+  const unsigned hp = __builtin_bit_cast(unsigned, hi);
+  unsigned lp;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lp) : "v"(hp), "v"(v.x));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lp) : "v"(hp), "v"(v.y));
+  return __builtin_bit_cast(f16x2, lp);
+}
+
+// hot-loop form: v_fract_f32 instead of rint + subtract (one instruction less per pair; the reduced argument lives in
+// [0,1) instead of [-1/2,1/2], i.e. one bit coarser: ~1.9e-7 instead of ~0.9e-7 absolute on the sine, see tools/measure_sin.py)
+__device__ __forceinline__ f32x2 sin_turns2_fract(f32x2 x) {
+  const f32x2 c_hi = splat2(0.15915493667125702f), c_lo = splat2(6.4206382432985265e-09f);
+  const f32x2 p = x * c_hi;
+  const f32x2 e = fma2(x, c_hi, -p);
+  const f32x2 f = {__builtin_amdgcn_fractf(p.x), __builtin_amdgcn_fractf(p.y)};
+  const f32x2 t = f + fma2(x, c_lo, e);
+  return f32x2{__builtin_amdgcn_sinf(t.x), __builtin_amdgcn_sinf(t.y)};
+}
 
 // two sines at once: every step except rint and v_sin_f32 is a packed-fp32 instruction
 __device__ __forceinline__ f32x2 sin_turns2(f32x2 x) {
@@ -346,42 +418,67 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
 
   // ---- stage the workgroup constants in LDS ----
   if (w.mixer_frags != nullptr) {
-    // pre-split fragment table (nws_mixer_frags): straight 28 KB copy, 16 B per lane per load
-    const float4* src = reinterpret_cast<const float4*>(w.mixer_frags);
-    float4* dst = reinterpret_cast<float4*>(L.whi);  // whi and wlo are contiguous
-    for (int e = tid; e < 2 * kKSteps * 2 * 2 * 32; e += 256) dst[e] = src[e];
+    // pre-split fragment table (nws_mixer_frags): 28 KB = 28 pieces of 1 KB, copied by the LDS-DMA path
+    // (global_load_lds_dwordx4: per-lane global address, wave-uniform LDS base + 16 B per lane; no VGPR round trip).
+    // whi and wlo are contiguous; the workgroup barrier below drains the DMA (vmcnt) before anybody reads.
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const char* src = static_cast<const char*>(w.mixer_frags);
+    char* dst = reinterpret_cast<char*>(L.whi);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int piece = 4 * i + wave;
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + piece * 1024 + lane * 16), (lptr_t)(dst + piece * 1024), 16, 0, 0);
+    }
   } else {
     _Float16* whi = reinterpret_cast<_Float16*>(L.whi);
     _Float16* wlo = reinterpret_cast<_Float16*>(L.wlo);
     for (int e = tid; e < kS * kKPad; e += 256) {
       const int s = e / kKPad, kk = e - s * kKPad;
-      const float wv = kk < kK ? w.mixer_w[s * kK + kk] : 0.0f;  // harmonics 102..112 are padding
+      const float wv = mixer_slot_weight(w.mixer_w, w.mixer_b, s, kk);
       const int frag = (((kk >> 4) * 2 + (s >> 5)) * 2 + ((kk >> 3) & 1)) * 32 + (s & 31);
       split_f16(wv, whi[frag * 8 + (kk & 7)], wlo[frag * 8 + (kk & 7)]);
     }
   }
-  if (tid < kS) L.mix_b[tid] = w.mixer_b[tid];
-  // _create_phase_shift (generators.py:54-56): fl(fl(u * rand_phase) - fl32(pi))
-  if (tid < kKPad) L.shift[tid] = tid < kK ? phase_u[tid] * rand_phase[tid] - kPi : 0.0f;  // kKPad = 112 <= 256
+  // waves 0/1: FiLM slot 0/1 (one shaper per lane);  wave 2: bsum[0..1];  wave 3: bsum[2], phase shifts, harmonic numbers
   if (MODE != kModeExciterOnly) {
     const float* fb = film + (size_t)b * T * NWS_FILM_CH;
     auto frame_of = [&](int q) {
       const int f = j - 1 + q;
       return f < 0 ? 0 : (f > T - 1 ? T - 1 : f);
     };
-    for (int e = tid; e < 2 * 3 * kS; e += 256) {
-      const int q = e / (3 * kS), ty = (e / kS) % 3, sidx = e % kS;
-      const float scale = ty == 2 ? w.newt_out_w[sidx] : 1.0f;
-      const float v0 = scale * fb[(size_t)frame_of(q) * NWS_FILM_CH + ty * kS + sidx];
-      const float v1 = scale * fb[(size_t)frame_of(q + 1) * NWS_FILM_CH + ty * kS + sidx];
-      L.fa[q][ty][sidx] = v0;
-      L.fd[q][ty][sidx] = v1 - v0;
-    }
-    if (wave < 3) {  // bsum[q] = sum_s out_w[s] * b_norm[frame q][s]
-      float v = w.newt_out_w[lane] * fb[(size_t)frame_of(wave) * NWS_FILM_CH + 3 * kS + lane];
+    auto bias_sum = [&](int q) {  // sum_s out_w[s] * b_norm[frame q][s]
+      float v = w.newt_out_w[lane] * fb[(size_t)frame_of(q) * NWS_FILM_CH + 3 * kS + lane];
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-      if (lane == 0) L.bsum[wave] = v;
+      if (lane == 0) L.bsum[q] = v;
+    };
+    if (wave < 2) {
+      const float* r0 = fb + (size_t)frame_of(wave) * NWS_FILM_CH + lane;
+      const float* r1 = fb + (size_t)frame_of(wave + 1) * NWS_FILM_CH + lane;
+      const float ow = w.newt_out_w[lane];
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty) {
+        const float sc = ty == 2 ? ow : 1.0f;
+        const float v0 = sc * r0[ty * kS], v1 = sc * r1[ty * kS];
+        L.fa[wave][ty][lane] = v0;
+        L.fd[wave][ty][lane] = v1 - v0;
+      }
+    } else if (wave == 2) {
+      bias_sum(0);
+      bias_sum(1);
+    } else {
+      bias_sum(2);
+    }
+  }
+  if (wave == 3) {
+    // _create_phase_shift (generators.py:54-56): fl(fl(u * rand_phase) - fl32(pi)) for harmonic c = slot c
+    auto shift_of = [&](int c) { return c >= 1 && c <= kK ? phase_u[c - 1] * rand_phase[c - 1] - kPi : 0.0f; };
+    L.shift[lane] = shift_of(lane);
+    L.kf[lane] = (float)lane;
+    if (lane < kKPad - 64) {
+      L.shift[64 + lane] = shift_of(64 + lane);
+      L.kf[64 + lane] = (float)(64 + lane);
     }
   }
   if (MODE == kModeExact) load_shaper_lds(SH, w, tid, 256);
@@ -422,11 +519,6 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
   // K-step ks covers harmonics 16ks+1 .. 16ks+16; lane (col, half) evaluates the 8 sines of harmonics
   // 16ks + 8half + 1..8 for its sample: exactly the B fragment of v_mfma_f32_32x32x16_f16.
   f32x16 acc0, acc1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    acc0[r] = 0.0f;
-    acc1[r] = 0.0f;
-  }
   // no sine argument of this wave can exceed the fast reduction's range -> packed sines without range tests
   const bool small_args = __all(fabsf(phase) * (float)kKPad + 4.0f < 6.0e6f);
   // anti-alias mask (generators.py:50-52): harmonic k is live iff fl(f0*k) < sr/2.  fl(f0*k) is monotone in k for
@@ -435,31 +527,41 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
   if (!(f0n > 0.0f)) {
     kmax = f0n == f0n ? kK : 0;  // f0 <= 0: every product is <= 0 < sr/2;  NaN: nothing is live
   } else {
-    const float q = nyquist / f0n;
+    // the quotient estimate is within one of the answer (both are small integers); settle it with the exact test
+    const float q = nyquist * __builtin_amdgcn_rcpf(f0n);
     int kc = q > (float)kK ? kK : (int)q;
-    while (kc < kK && (f0n * (float)(kc + 1)) < nyquist) ++kc;
-    while (kc > 0 && !((f0n * (float)kc) < nyquist)) --kc;
+    kc += (kc < kK && (f0n * (float)(kc + 1)) < nyquist) ? 1 : 0;
+    kc -= (kc > 0 && !((f0n * (float)kc) < nyquist)) ? 1 : 0;
+    kc -= (kc > 0 && !((f0n * (float)kc) < nyquist)) ? 1 : 0;
     kmax = kc;
   }
   const int frag_lane = half * 32 + col;
   const f32x2 ph2 = splat2(phase);
-  for (int ks = 0; ks < kKSteps; ++ks) {
+  // one K-step; the first one starts the accumulators from the MFMA's inline-zero C operand (no 32 v_mov per wave)
+  auto kstep = [&](const int ks, auto first_tag) {
+    constexpr bool kFirst = decltype(first_tag)::value;
     const int kk0 = 16 * ks + 8 * half;
-    const int rem = kmax - kk0;        // this lane's live elements in the step: e < rem
-    if (!__any(rem > 0)) break;        // k*f0 only grows with k: everything above is masked too
+    const int rem = kmax + 1 - kk0;    // this lane's live slots in the step: e < rem  (slot c = kk0 + e is live iff c <= kmax)
     const bool full = __all(rem >= 8);
     const float4 sh0 = *reinterpret_cast<const float4*>(&L.shift[kk0]);
     const float4 sh1 = *reinterpret_cast<const float4*>(&L.shift[kk0 + 4]);
+    const float4 kf0 = *reinterpret_cast<const float4*>(&L.kf[kk0]);
+    const float4 kf1 = *reinterpret_cast<const float4*>(&L.kf[kk0 + 4]);
     const f32x2 sh2[4] = {{sh0.x, sh0.y}, {sh0.z, sh0.w}, {sh1.x, sh1.y}, {sh1.z, sh1.w}};
-    const f32x2 kb2 = splat2((float)kk0);
+    const f32x2 kf2[4] = {{kf0.x, kf0.y}, {kf0.z, kf0.w}, {kf1.x, kf1.y}, {kf1.z, kf1.w}};
     f32x2 v2[4];
+    if (DBG == 1) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const f32x2 kf2 = kb2 + f32x2{(float)(2 * p + 1), (float)(2 * p + 2)};  // exact small integers
-      const f32x2 arg2 = kf2 * ph2 + sh2[p];  // fl(fl(k*phase) + shift): the reference's own rounding chain
-      if (DBG == 1) v2[p] = arg2;
-      else if (small_args) v2[p] = sin_turns2(arg2);
-      else v2[p] = f32x2{nws_sinf_fast(arg2.x), nws_sinf_fast(arg2.y)};
+      for (int p = 0; p < 4; ++p) v2[p] = kf2[p] * ph2 + sh2[p];
+    } else if (small_args) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) v2[p] = sin_turns2_fract(kf2[p] * ph2 + sh2[p]);  // fl(fl(k*phase) + shift): the reference's own rounding chain
+    } else {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const f32x2 arg2 = kf2[p] * ph2 + sh2[p];
+        v2[p] = f32x2{nws_sinf_fast(arg2.x), nws_sinf_fast(arg2.y)};
+      }
     }
     if (!full) {
 #pragma unroll
@@ -468,13 +570,13 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
         v2[p].y = 2 * p + 1 < rem ? v2[p].y : 0.0f;
       }
     }
-    // v = hi + lo, both fp16 (lo = exact residual rounded to fp16), packed two at a time
+    if (kFirst && DBG != 1) v2[0].x = half == 0 ? 1.0f : v2[0].x;  // slot 0: the bias' constant input
+    // v = hi + lo, both fp16 (lo = exact residual rounded to fp16): v_cvt_pk_f16_f32 for hi, one v_fma_mix{lo,hi}_f16 per lo
     f16x8 vhi, vlo;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const f16x2 h2 = __builtin_convertvector(v2[p], f16x2);
-      const f32x2 back = __builtin_convertvector(h2, f32x2);
-      const f16x2 l2 = __builtin_convertvector(v2[p] - back, f16x2);
+      const f16x2 l2 = split_lo2(h2, v2[p]);
       vhi[2 * p] = h2.x;
       vhi[2 * p + 1] = h2.y;
       vlo[2 * p] = l2.x;
@@ -484,18 +586,24 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
     for (int m = 0; m < 2; ++m) {
       const f16x8 ahi = L.whi[(ks * 2 + m) * 64 + frag_lane];
       const f16x8 alo = L.wlo[(ks * 2 + m) * 64 + frag_lane];
+      f32x16& acc = m == 0 ? acc0 : acc1;
       if (DBG == 4) {
-        (m == 0 ? acc0 : acc1)[ks] += (float)ahi[0] * (float)vhi[0] + (float)alo[1] * (float)vlo[1];
-      } else if (m == 0) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, vhi, acc0, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, vlo, acc0, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, vhi, acc0, 0, 0, 0);
+        if (kFirst) acc = f32x16{};
+        acc[ks] += (float)ahi[0] * (float)vhi[0] + (float)alo[1] * (float)vlo[1];
       } else {
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, vhi, acc1, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, vlo, acc1, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, vhi, acc1, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, vhi, kFirst ? f32x16{} : acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, vlo, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, vhi, acc, 0, 0, 0);
       }
     }
+  };
+  // the first step always runs (it carries the bias); k*f0 only grows with k: once a step has no live lane, everything
+  // above is masked too
+  kstep(0, std::true_type{});
+#pragma unroll
+  for (int ks = 1; ks < kKSteps; ++ks) {
+    if (!__any(kmax + 1 - (16 * ks + 8 * half) > 0)) break;
+    kstep(ks, std::false_type{});
   }
 
   // accumulator element r of M-tile m: shaper 32m + (r&3) + 8(r>>2) + 4*half, sample `col`
@@ -503,8 +611,8 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int s0 = (r & 3) + 8 * (r >> 2) + 4 * half;
-      exciter_out[((size_t)b * kS + s0) * N + n] = acc0[r] + L.mix_b[s0];
-      exciter_out[((size_t)b * kS + s0 + 32) * N + n] = acc1[r] + L.mix_b[s0 + 32];
+      exciter_out[((size_t)b * kS + s0) * N + n] = acc0[r];
+      exciter_out[((size_t)b * kS + s0 + 32) * N + n] = acc1[r];
     }
   }
   if (MODE == kModeExciterOnly) return;
@@ -520,8 +628,11 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
   // ---- FiLM -> shaper -> FiLM -> 64->1 mix, all in registers ----
   const int q0 = lc.i0 - (j - 1);  // 0 or 1: slot of the left frame; fd[q0] is zero where the right frame is clamped
   LutParams LP;
-  if (is_lut(MODE)) LP = make_lut_params(w);
+  LutFast LF;
+  if (MODE == kModeLutPairsDiv6) LF = make_lut_fast(w);
+  else if (is_lut(MODE)) LP = make_lut_params(w);
   const int lane_row_off = is_lut(MODE) ? 4 * half * w.lut_size : 0;
+  const unsigned lane_off_bytes = is_lut(MODE) ? (unsigned)lane_row_off * 8u : 0u;
   const f32x2 w1_2 = splat2(lc.w1);
   f32x2 part2 = {0.0f, 0.0f};
   // accumulator registers 4g..4g+3 of M-tile m are the 4 consecutive shapers 32m + 8g + 4half + 0..3
@@ -531,7 +642,6 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
     for (int g = 0; g < 4; ++g) {
       const int sb = 32 * m + 8 * g;  // compile-time part of the shaper index
       const int s4 = sb + 4 * half;
-      const float4 mb = *reinterpret_cast<const float4*>(&L.mix_b[s4]);
       float4 fa[3], fd[3];
 #pragma unroll
       for (int ty = 0; ty < 3; ++ty) {
@@ -543,7 +653,7 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
         const int r0 = 4 * g + 2 * h2;
         const f32x2 accp = m == 0 ? f32x2{acc0[r0], acc0[r0 + 1]} : f32x2{acc1[r0], acc1[r0 + 1]};
 #define NWS_PAIR(v) (h2 == 0 ? f32x2{(v).x, (v).y} : f32x2{(v).z, (v).w})
-        const f32x2 x2 = accp + NWS_PAIR(mb);
+        const f32x2 x2 = accp;  // harmonic_mixer output, bias included (K slot 0)
         const f32x2 g_i = fma2(w1_2, NWS_PAIR(fd[0]), NWS_PAIR(fa[0]));  // F.upsample of the FiLM parameters
         const f32x2 b_i = fma2(w1_2, NWS_PAIR(fd[1]), NWS_PAIR(fa[1]));
         const f32x2 g_n = fma2(w1_2, NWS_PAIR(fd[2]), NWS_PAIR(fa[2]));  // already times newt.mixer.weight
@@ -551,6 +661,8 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
         f32x2 sh;
         if (DBG == 2) {
           sh = xi;
+        } else if (MODE == kModeLutPairsDiv6) {
+          sh = lut_shaper2_fast(LF, LF.pairs + (size_t)(sb + 2 * h2) * LF.row_bytes, lane_off_bytes, xi);
         } else if (is_lut(MODE)) {
           sh = lut_shaper2<MODE != kModeLut, MODE == kModeLutPairsDiv6>(LP, (sb + 2 * h2) * LP.size + lane_row_off, xi);
         } else {
@@ -645,11 +757,12 @@ __global__ void sin_variant_kernel(const float* __restrict__ x, float* __restric
 }
 
 // mixer_w (64,101) fp32 -> [whi fragments | wlo fragments] exactly as ExcLds holds them
-__global__ void mixer_frags_kernel(const float* __restrict__ mixer_w, _Float16* __restrict__ out) {
+__global__ void mixer_frags_kernel(const float* __restrict__ mixer_w, const float* __restrict__ mixer_b,
+                                   _Float16* __restrict__ out) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= kS * kKPad) return;
   const int s = e / kKPad, kk = e - s * kKPad;
-  const float wv = kk < kK ? mixer_w[s * kK + kk] : 0.0f;
+  const float wv = mixer_slot_weight(mixer_w, mixer_b, s, kk);
   const int frag = (((kk >> 4) * 2 + (s >> 5)) * 2 + ((kk >> 3) & 1)) * 32 + (s & 31);
   _Float16 h, l;
   split_f16(wv, h, l);
@@ -748,9 +861,10 @@ int nws_sin(const float* x, float* y, int64_t n, void* stream) {
   return NWS_OK;
 }
 
-int nws_mixer_frags(const float* mixer_w, void* frags_out, void* stream) {
-  if (!mixer_w || !frags_out) return NWS_ERR_BAD_ARG;
-  mixer_frags_kernel<<<(kS * kKPad + 255) / 256, 256, 0, (hipStream_t)stream>>>(mixer_w, static_cast<_Float16*>(frags_out));
+int nws_mixer_frags(const float* mixer_w, const float* mixer_b, void* frags_out, void* stream) {
+  if (!mixer_w || !mixer_b || !frags_out) return NWS_ERR_BAD_ARG;
+  mixer_frags_kernel<<<(kS * kKPad + 255) / 256, 256, 0, (hipStream_t)stream>>>(mixer_w, mixer_b,
+                                                                                 static_cast<_Float16*>(frags_out));
   NWS_CHECK_LAUNCH();
   return NWS_OK;
 }
@@ -798,7 +912,8 @@ int nws_exciter_newt(const NwsWeights* w, const float* f0, const float* f0_up, c
     if (!film || !w->newt_out_w || !w->newt_out_b) return NWS_ERR_BAD_ARG;
     if (w->lut != nullptr) {
       if (w->lut_size < 2 || !(w->lut_max > w->lut_min)) return NWS_ERR_BAD_ARG;
-      if (w->lut_pairs != nullptr && w->lut_max - w->lut_min == 6.0f)
+      const bool pow2 = (w->lut_size & (w->lut_size - 1)) == 0 && w->lut_size <= (1 << 20);
+      if (w->lut_pairs != nullptr && w->lut_max - w->lut_min == 6.0f && pow2)
         exciter_newt_kernel<kModeLutPairsDiv6><<<grid, 256, base, st>>>(*w, f0, f0_up, carry, phase_u, rand_phase,
                                                                         film, T, sample_rate, exciter_out, newt_out);
       else if (w->lut_pairs != nullptr)
@@ -822,7 +937,7 @@ int nws_debug_exciter_newt(int variant, const NwsWeights* w, const float* f0, co
                            float* newt_out, void* stream) {
   if (!weights_ok(w) || !f0 || !carry || !phase_u || !rand_phase || !film || !newt_out || !w->lut || !w->lut_pairs)
     return NWS_ERR_BAD_ARG;
-  if (w->lut_max - w->lut_min != 6.0f) return NWS_ERR_UNSUPPORTED;
+  if (w->lut_max - w->lut_min != 6.0f || (w->lut_size & (w->lut_size - 1)) != 0) return NWS_ERR_UNSUPPORTED;
   const dim3 grid(T, B);
   const size_t base = (sizeof(ExcLds) + 15) & ~size_t(15);
   hipStream_t st = (hipStream_t)stream;

@@ -93,7 +93,7 @@ class Engine:
         w.mixer_w = P(m.harmonic_mixer.weight, "harmonic_mixer.weight", 64 * 101)
         w.mixer_b = P(m.harmonic_mixer.bias, "harmonic_mixer.bias", 64)
         frags = torch.empty(28672, dtype=torch.uint8, device=keep[-1].device)
-        check(_lib.lib().nws_mixer_frags(w.mixer_w, ptr(frags), stream_ptr()), "nws_mixer_frags")
+        check(_lib.lib().nws_mixer_frags(w.mixer_w, w.mixer_b, ptr(frags), stream_ptr()), "nws_mixer_frags")
         keep.append(frags)
         w.mixer_frags = frags.data_ptr()
         for name, mlp, out_rows, wf, bf, gf, lf in (
