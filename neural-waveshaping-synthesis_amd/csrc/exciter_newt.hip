@@ -395,7 +395,7 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 // second launch-bound = minimum waves per SIMD: without it hipcc hoists all 32 LUT gathers of the tail, takes 256
 // VGPRs and drops the kernel to 1 wave/SIMD (measured 2x slower); 4 waves/SIMD = 128 VGPRs, LDS allows 5 blocks/CU
 template <int MODE, int DBG = 0>
-__global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_kernel(NwsWeights w, const float* __restrict__ f0,
+__global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 5) void exciter_newt_kernel(NwsWeights w, const float* __restrict__ f0,
                                                            const float* __restrict__ f0_up,
                                                            const double* __restrict__ carry,
                                                            const float* __restrict__ phase_u,
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 4) void exciter_newt_
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const f32x2 arg2 = kf2[p] * ph2 + sh2[p];
-        v2[p] = f32x2{nws_sinf_fast(arg2.x), nws_sinf_fast(arg2.y)};
+        v2[p] = f32x2{nws_sin_wide(arg2.x), nws_sin_wide(arg2.y)};
       }
     }
     if (!full) {

@@ -113,6 +113,18 @@ __device__ __forceinline__ float nws_sin_turns_checked(float x) {
   return __builtin_expect(fabsf(x) > 6.0e6f, 0) ? nws_sinf_huge(x) : nws_sin_turns(x);
 }
 
+// Any-magnitude sine without a function call (the oscillator's wave-uniform wide-argument path: phases beyond ~6e6 rad,
+// i.e. minutes of audio or very high F0): the same exact-product reduction to turns carried out in fp64 with a two-term
+// 1/(2 pi) (106 bits), then v_sin_f32.  ~1e-7 absolute up to |x| ~ 1e25; inf/NaN give NaN like sinf.
+__device__ __forceinline__ float nws_sin_wide(float x) {
+  const double c1 = 0x1.45f306dc9c883p-3, c2 = -0x1.6b01ec5417056p-57;
+  const double xd = (double)x;
+  const double p = xd * c1;
+  const double e = __builtin_fma(xd, c1, -p);
+  const double t = __builtin_amdgcn_fract(p) + __builtin_fma(xd, c2, e);
+  return __builtin_amdgcn_sinf((float)t);
+}
+
 __device__ __forceinline__ float nws_sinf_fast(float x) {
   if (__builtin_expect(fabsf(x) > 6.0e6f, 0)) return nws_sinf_huge(x);
   return nws_sin_turns(x);

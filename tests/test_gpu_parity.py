@@ -355,6 +355,27 @@ def test_hipgraph_capture_replay(models):
     assert not torch.equal(out, eager)
 
 
+def test_exciter_wide_phase_path(models, oracle):
+    """32 s at ~300 Hz: k*phase passes 6e6 rad in the last part of the clip, where the oscillator switches (per wave) from
+    the packed fp32 turn reduction to the inline fp64 one.  The fp32 argument chain is reproduced exactly on both sides, so
+    the mixed harmonics must still agree to sine accuracy."""
+    _, fast = models
+    g = torch.Generator().manual_seed(77)
+    N = 128 * 4000
+    f0_up = (250 + 100 * torch.rand(1, 1, N, generator=g))
+    torch.manual_seed(5)
+    got = fast.render_exciter(f0_up.cuda()).cpu().numpy()
+    torch.manual_seed(5)
+    u = torch.rand_like(fast.osc.rand_phase).cpu().reshape(-1)
+    ref = oracle[0].exciter(f0_up, u).numpy()
+    phase_end = 2 * np.pi * float(f0_up.double().sum()) / 16000.0
+    assert phase_end * 112 > 6.0e6, phase_end          # the wide path really is exercised
+    tail = slice(N - 65536, N)
+    record("exciter_wide_phase", max_abs_err=maxabs(got, ref), tail_max_abs_err=maxabs(got[..., tail], ref[..., tail]),
+           phase_end=phase_end)
+    assert maxabs(got, ref) <= 2e-5
+
+
 @pytest.mark.parametrize("B,T", [(3, 501), (1, 1000), (5, 33), (2, 250)])
 def test_e2e_odd_shapes_against_oracle(models, oracle, B, T):
     """Shapes off the beaten path: T=501 -> L=64128=501x128 (general-N1 MFMA DFT), T=1000 -> L=128000=125x1024,
