@@ -278,6 +278,7 @@ __device__ __forceinline__ f32x2 lut_shaper2(const LutParams& P, int row_off, f3
 }
 
 // Hot-path form of lut_shaper2<true, true> (range 6, power-of-two size; chosen by the launcher):
+//  * x arrives as x - min (the FiLM bias carries -min: one rounding where the reference has two, <= 1/2 ulp of x);
 //  * size * (x - min) / 6 with the power of two folded into the division constants: q = y*(size/6), r = fma(-q, 6/size, y),
 //    idx = fma(r, size/6, q) is the same correctly rounded quotient (every step is the DIV6 step scaled exactly by `size`);
 //  * the gather address is  SGPR row base + 32-bit VGPR byte offset  (one v_add_lshl_u32 instead of 64-bit address math);
@@ -285,14 +286,13 @@ __device__ __forceinline__ f32x2 lut_shaper2(const LutParams& P, int row_off, f3
 //    the output, far below the sine error upstream); scalar on purpose, packing it would cost three v_mov per pair.
 struct LutFast {
   const char* pairs;
-  float tmin, c_r, c_d, top;
+  float c_r, c_d, top;
   unsigned row_bytes;
 };
 
 __device__ __forceinline__ LutFast make_lut_fast(const NwsWeights& w) {
   LutFast P;
   P.pairs = reinterpret_cast<const char*>(w.lut_pairs);
-  P.tmin = w.lut_min;
   P.c_r = (float)w.lut_size * (1.0f / 6.0f);  // fl(1/6) scaled exactly
   P.c_d = 6.0f / (float)w.lut_size;           // exact
   P.top = (float)(w.lut_size - 1);
@@ -302,7 +302,7 @@ __device__ __forceinline__ LutFast make_lut_fast(const NwsWeights& w) {
 
 __device__ __forceinline__ f32x2 lut_shaper2_fast(const LutFast& P, const char* __restrict__ row0, unsigned lane_off,
                                                   f32x2 x) {
-  const f32x2 y = x - splat2(P.tmin);
+  const f32x2 y = x;  // already x - lut_min: folded into the FiLM bias when it was staged
   const f32x2 q = y * splat2(P.c_r);
   const f32x2 r = fma2(-q, splat2(P.c_d), y);
   const f32x2 idx = fma2(r, splat2(P.c_r), q);
@@ -350,6 +350,39 @@ struct ExcLds {
 __device__ __forceinline__ float mixer_slot_weight(const float* __restrict__ mixer_w, const float* __restrict__ mixer_b, int s,
                                                    int c) {
   return c == 0 ? mixer_b[s] : (c <= kK ? mixer_w[s * kK + c - 1] : 0.0f);
+}
+
+// ---- cross-lane helpers on the DPP path (no LDS round trips, no index arithmetic) ----
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// inclusive prefix sum inside each 32-lane half: row_shr 1/2/4/8 (zeros shifted in) scan the 16-lane rows, row_bcast15
+// carries the lower row's total into the upper row
+__device__ __forceinline__ double scan32_f64(double v) {
+  v += dpp_f64<0x111, 0xf>(v);
+  v += dpp_f64<0x112, 0xf>(v);
+  v += dpp_f64<0x114, 0xf>(v);
+  v += dpp_f64<0x118, 0xf>(v);
+  v += dpp_f64<0x142, 0xa>(v);
+  return v;
+}
+// sum over the wave, valid in lane 63
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v += dpp_f32<0xb1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4e, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141, 0xf>(v);  // row_half_mirror
+  v += dpp_f32<0x140, 0xf>(v);  // row_mirror: every lane holds its row's sum
+  v += dpp_f32<0x142, 0xa>(v);  // row_bcast15 -> rows 1 and 3
+  v += dpp_f32<0x143, 0xc>(v);  // row_bcast31 -> rows 2 and 3
+  return v;
 }
 
 // lo = fp16(v - hi) for a packed pair, hi given as fp16: v_fma_mix{lo,hi}_f16 read the fp16 operand directly and round the
@@ -423,13 +456,17 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 5) void exciter_newt_
     // whi and wlo are contiguous; the workgroup barrier below drains the DMA (vmcnt) before anybody reads.
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    const char* src = static_cast<const char*>(w.mixer_frags);
-    char* dst = reinterpret_cast<char*>(L.whi);
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const int piece = 4 * i + wave;
-      __builtin_amdgcn_global_load_lds((gptr_t)(src + piece * 1024 + lane * 16), (lptr_t)(dst + piece * 1024), 16, 0, 0);
-    }
+    // wave w copies pieces 7w .. 7w+6; the instruction's immediate offset (< 4 KB) moves the global and the LDS address
+    // together, so two address set-ups serve seven loads
+    const char* src = static_cast<const char*>(w.mixer_frags) + wave * 7168 + lane * 16;
+    char* dst = reinterpret_cast<char*>(L.whi) + wave * 7168;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 1024, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 2048, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 3072, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + 4096), (lptr_t)(dst + 4096), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + 4096), (lptr_t)(dst + 4096), 16, 1024, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + 4096), (lptr_t)(dst + 4096), 16, 2048, 0);
   } else {
     _Float16* whi = reinterpret_cast<_Float16*>(L.whi);
     _Float16* wlo = reinterpret_cast<_Float16*>(L.wlo);
@@ -448,10 +485,8 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 5) void exciter_newt_
       return f < 0 ? 0 : (f > T - 1 ? T - 1 : f);
     };
     auto bias_sum = [&](int q) {  // sum_s out_w[s] * b_norm[frame q][s]
-      float v = w.newt_out_w[lane] * fb[(size_t)frame_of(q) * NWS_FILM_CH + 3 * kS + lane];
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-      if (lane == 0) L.bsum[q] = v;
+      const float v = wave_sum_to_lane63(w.newt_out_w[lane] * fb[(size_t)frame_of(q) * NWS_FILM_CH + 3 * kS + lane]);
+      if (lane == 63) L.bsum[q] = v;
     };
     if (wave < 2) {
       const float* r0 = fb + (size_t)frame_of(wave) * NWS_FILM_CH + lane;
@@ -461,7 +496,8 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 5) void exciter_newt_
       for (int ty = 0; ty < 3; ++ty) {
         const float sc = ty == 2 ? ow : 1.0f;
         const float v0 = sc * r0[ty * kS], v1 = sc * r1[ty * kS];
-        L.fa[wave][ty][lane] = v0;
+        // hot LUT path: the table origin (x - lut_min) rides on the first FiLM bias, one packed add less per shaper pair
+        L.fa[wave][ty][lane] = (MODE == kModeLutPairsDiv6 && ty == 1) ? v0 - w.lut_min : v0;
         L.fd[wave][ty][lane] = v1 - v0;
       }
     } else if (wave == 2) {
@@ -493,12 +529,8 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 5) void exciter_newt_
     const float* x = f0 + (size_t)b * T;
     f0n = nws_lerp(x[lc.i0], x[lc.i1], lc.w0, lc.w1);
   }
-  double cs = (double)f0n;
-#pragma unroll
-  for (int off = 1; off < 32; off <<= 1) {
-    const double t = __shfl_up(cs, off, 32);
-    if (col >= off) cs += t;
-  }
+  const double cs_local = scan32_f64((double)f0n);  // inclusive prefix sum over the wave's 32 samples (both halves alike)
+  double cs = cs_local;
   cs += carry[(size_t)b * (N / 32) + (n >> 5)];
   const float csum = (float)cs;                                 // fl32 of the double prefix sum
   // math.tau * cumsum / sample_rate with a TRUE division: for sr = 16000 the reciprocal + one FMA correction below is the

@@ -12,6 +12,8 @@
 // 8-tap register window of the taps and of a copy delayed by one sample (so that tap PAIRS are
 // even-aligned for both output parities): two ds_read_b128 of taps + one broadcast ds_read_b128 of
 // noise feed 8 v_pk_fma_f32 = 16 MACs.  The NEWT branch is added here (cat + sum(1), models/neural_waveshaping.py:85-86).
+#include <type_traits>
+
 #include "nws_common.h"
 
 namespace {
@@ -117,12 +119,159 @@ __global__ __launch_bounds__(256) void fir_noise_kernel(const float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Batched form on the matrix cores (B >= 16).  All utterances share ONE noise vector (generators.py:30), so for frame t
+// the 256x256 circulant C_t[n][k] = f_t[(n-k) & 255] of the noise frame is the same GEMM operand for every utterance:
+//     Y_t (B x 256) = H_t (B x 256 taps) * C_t^T .
+// One workgroup = one output hop x 32 utterances; the hop needs rows 0..127 of frame t's circulant and rows 128..255 of
+// frame t-1's, i.e. ONE accumulation over K = 512: D[b][j] = sum_k h_t[b][k] f_t[(j-k)&255] + sum_k h_{t-1}[b][k] f_{t-1}[(128+j-k)&255].
+// fp32 accuracy from fp16 MFMAs by the two-term split (x = hi + lo, three products); taps are pre-scaled by a per-utterance
+// power of two and the noise by 2^10 so that the lo parts stay out of the fp16 subnormal range.
+//  * A operand (utterance rows): taps as fp16 hi/lo rows in LDS, row stride 528 B (bank-conflict-free b128 reads).
+//  * B operand (sample columns): lane (j, khalf) needs 8 CONSECUTIVE entries of the reversed noise frame starting at
+//    (k0 + 8 khalf - j) & 255 -- an arbitrary offset, but its low three bits are (-j) & 7, fixed per lane: eight copies of
+//    the reversed frame, copy c shifted by c, make every read an aligned ds_read_b128 (copy stride 544 B: conflict-free).
+//  * D rows are utterances, columns samples: each accumulator register stores 2 x 128 B contiguous segments.
+constexpr int kUtt = 32;
+constexpr int kCopyHalfs = 272;
+constexpr int kRowHalfs = 264;
+constexpr float kNoiseScale = 1024.0f;  // noise (U[0,1) in the reference; anything within +-32 is fine) times 2^10
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+struct NoiseMfmaLds {
+  _Float16 rhi[2][8][kCopyHalfs];  // [frame t | frame t-1 advanced by 128][shift c][v] = R[(v + c) & 255]
+  _Float16 rlo[2][8][kCopyHalfs];
+  _Float16 hhi[kUtt][kRowHalfs];   // taps of the frame being accumulated, times the utterance's power-of-two scale
+  _Float16 hlo[kUtt][kRowHalfs];
+  float unscale[kUtt];             // 1 / (tap scale * noise scale) per utterance
+};
+
+__device__ __forceinline__ void split16(float v, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)v;
+  lo = (_Float16)(v - (float)hi);
+}
+
+__global__ __launch_bounds__(256, 3) void fir_noise_mfma_kernel(const float* __restrict__ fir, const float* __restrict__ noise,
+                                                                const float* __restrict__ add_in, int B, int T, int len,
+                                                                int origin, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) NoiseMfmaLds L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kh = lane >> 5, col = lane & 31;
+  const int t = blockIdx.x, b0 = blockIdx.y * kUtt;
+  const int N = T * kHop;
+
+  // taps: wave w covers rows r = w + 4 it (it = 0..7), one float4 per lane: coalesced 1 KB rows
+  auto load_rows = [&](int frame, float4 (&v)[8]) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int b = b0 + wave + 4 * it;
+      v[it] = (frame >= 0 && frame < T && b < B)
+                  ? *reinterpret_cast<const float4*>(&fir[((size_t)b * T + frame) * kL + 4 * lane])
+                  : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+  };
+  float4 cur[8], prv[8];
+  load_rows(t, cur);
+  load_rows(t - 1, prv);
+
+  // reversed noise frames, eight shifted copies each.  frame 0: R[u] = f_t[(-u) & 255]; frame 1: R[u] = f_{t-1}[(128-u) & 255]
+  for (int e = tid; e < 2 * 8 * kCopyHalfs; e += 256) {
+    const int fr = e / (8 * kCopyHalfs), rem = e - fr * (8 * kCopyHalfs);
+    const int c = rem / kCopyHalfs, v = rem - c * kCopyHalfs;
+    const int u = (v + c) & 255;
+    const int i = fr == 0 ? kHop * t + ((-u) & 255) : kHop * (t - 1) + ((kHop - u) & 255);
+    const float val = (i >= 0 && i < N + kL - 1) ? padded_noise(noise, len, origin, i) : 0.0f;
+    split16(val * kNoiseScale, L.rhi[fr][c][v], L.rlo[fr][c][v]);
+  }
+
+  // one power-of-two scale per utterance (both frames): largest |tap| -> [2^14, 2^15).  Keeps hi AND lo of every tap that
+  // matters clear of the fp16 subnormals whatever the filter gain (-120 dB noise floors included); exact to undo.
+  float scale[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    float mx = fmaxf(fmaxf(fmaxf(fabsf(cur[it].x), fabsf(cur[it].y)), fmaxf(fabsf(cur[it].z), fabsf(cur[it].w))),
+                     fmaxf(fmaxf(fabsf(prv[it].x), fabsf(prv[it].y)), fmaxf(fabsf(prv[it].z), fabsf(prv[it].w))));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    int ex = (int)((__float_as_uint(mx) >> 23) & 0xff);  // biased exponent of the row maximum
+    ex = ex < 16 ? 16 : (ex > 250 ? 250 : ex);
+    scale[it] = __uint_as_float((unsigned)(268 - ex) << 23);          // 2^(14 - e)
+    if (lane == 0) L.unscale[wave + 4 * it] = __uint_as_float((unsigned)(ex - 14) << 23) * (1.0f / kNoiseScale);  // 2^(e - 14) / 2^10
+  }
+  auto stage_rows = [&](const float4 (&v)[8]) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int r = wave + 4 * it;
+      const float x[4] = {v[it].x * scale[it], v[it].y * scale[it], v[it].z * scale[it], v[it].w * scale[it]};
+      f16x4 h, l;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        _Float16 hq, lq;
+        split16(x[q], hq, lq);
+        h[q] = hq;
+        l[q] = lq;
+      }
+      *reinterpret_cast<f16x4*>(&L.hhi[r][4 * lane]) = h;
+      *reinterpret_cast<f16x4*>(&L.hlo[r][4 * lane]) = l;
+    }
+  };
+  stage_rows(cur);
+  __syncthreads();
+
+  f32x16 acc;
+  const int j = 32 * wave + col;  // output sample inside the hop
+  const int c = (-j) & 7;
+  auto accumulate = [&](const int fr, auto first_tag) {
+    constexpr bool kFirst = decltype(first_tag)::value;
+    const _Float16* rh = &L.rhi[fr][c][0];
+    const _Float16* rl = &L.rlo[fr][c][0];
+#pragma unroll 4
+    for (int ks = 0; ks < kL / 16; ++ks) {
+      const int k = 16 * ks + 8 * kh;
+      const int s8 = ((k - j) & 255) & ~7;
+      const f16x8 ahi = *reinterpret_cast<const f16x8*>(&L.hhi[col][k]);
+      const f16x8 alo = *reinterpret_cast<const f16x8*>(&L.hlo[col][k]);
+      const f16x8 bhi = *reinterpret_cast<const f16x8*>(&rh[s8]);
+      const f16x8 blo = *reinterpret_cast<const f16x8*>(&rl[s8]);
+      if (kFirst && ks == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, f32x16{}, 0, 0, 0);
+      else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc, 0, 0, 0);
+    }
+  };
+  accumulate(0, std::true_type{});
+  __syncthreads();
+  stage_rows(prv);
+  __syncthreads();
+  accumulate(1, std::false_type{});
+
+  const float ola = t == 0 ? 1.0f : 0.5f;  // overlap-add count: 1 in the first hop, else 2
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+    const int b = b0 + row;
+    if (b < B) {
+      const size_t o = (size_t)b * N + (size_t)t * kHop + j;
+      float v = acc[r] * (ola * L.unscale[row]);
+      if (add_in != nullptr) v = add_in[o] + v;
+      out[o] = v;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int nws_fir_noise_window(const float* fir, const float* noise, int noise_len, int origin, const float* add_in,
                                     int B, int T, float* out, void* stream) {
   if (!fir || !noise || !out || B <= 0 || T <= 0 || noise_len < 2 || origin < 0) return NWS_ERR_BAD_ARG;
   if (B > 65535) return NWS_ERR_UNSUPPORTED;
+  if (B >= 16) {  // shared-noise circulant GEMM on the matrix cores
+    const dim3 grid(T, (B + kUtt - 1) / kUtt);
+    fir_noise_mfma_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(fir, noise, add_in, B, T, noise_len, origin, out);
+    NWS_CHECK_LAUNCH();
+    return NWS_OK;
+  }
   const dim3 grid((T + kHopsPerBlock - 1) / kHopsPerBlock, B);
   fir_noise_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(fir, noise, add_in, T, noise_len, origin, out);
   NWS_CHECK_LAUNCH();

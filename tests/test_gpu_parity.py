@@ -185,6 +185,33 @@ def test_fir_noise_stage(models, oracle):
         assert maxabs(out2.cpu().numpy(), (add + out).cpu().numpy()) <= 1e-6
 
 
+@pytest.mark.parametrize("B,T", [(40, 9), (17, 3), (64, 33)])
+def test_fir_noise_batched_mfma_path(models, oracle, B, T):
+    """B >= 16 runs the shared-noise circulant GEMM on the matrix cores (fp16 two-term split).  Checked against the oracle's
+    STFT/iSTFT formulation and against the packed-fp32 kernel that serves small batches (run here in slices of 8)."""
+    m, _ = models
+    eng = m._engine
+    g = torch.Generator().manual_seed(100 * B + T)
+    H = (0.02 * torch.rand(B, 129, T, generator=g) ** 3 + 1e-4)
+    H[0] *= 50.0                                    # one loud utterance, one (nearly) silent: the tap scale must not matter
+    H[1] *= 1e-4
+    noise = torch.rand(128 * T - 1, generator=g)
+    ref = oracle[0].fir_noise(H, noise)[:, 0].numpy()
+    Ht = H.transpose(1, 2)
+    h = (torch.fft.irfft(torch.complex(Ht, torch.zeros_like(Ht))).roll(128, -1) * torch.hann_window(256).view(1, 1, -1)).contiguous().cuda()
+    add = torch.randn(B, 128 * T, generator=g).cuda()
+    out = eng.fir_noise(h, noise.cuda()).cpu().numpy()
+    small = torch.cat([eng.fir_noise(h[i:i + 8].contiguous(), noise.cuda()) for i in range(0, B, 8)]).cpu().numpy()
+    rowmax = np.abs(ref).max(axis=1)
+    err_rows = np.abs(out - ref).max(axis=1)
+    record(f"fir_noise_mfma_B{B}_T{T}", max_rel_row_err=float((err_rows / np.maximum(rowmax, 1e-12)).max()),
+           vs_small_kernel=maxabs(out, small), signal_max=float(rowmax.max()))
+    assert np.all(err_rows <= 2e-6 * rowmax + 1e-12), (err_rows / rowmax).max()
+    assert np.all(np.abs(out - small).max(axis=1) <= 2e-6 * rowmax + 1e-12)
+    out2 = eng.fir_noise(h, noise.cuda(), add_in=add).cpu().numpy()
+    assert maxabs(out2, add.cpu().numpy() + out) <= 1e-6
+
+
 @pytest.mark.parametrize("N", [256, 4096, 32000, 64000, 128 * 501])
 def test_reverb_stage(models, oracle, N):
     m, _ = models
