@@ -43,6 +43,12 @@ def parse():
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps are issued on round-robin (independent forwards overlap: the GRU of "
                          "step i+1 only occupies B CUs while step i's sample-rate kernels fill the rest)")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="1: ForwardPipeline (control half = carries + GRU of batch i+1 on a side stream under the audio "
+                         "half of batch i, --streams audio streams); 0: whole forwards round-robin on --streams streams")
+    ap.add_argument("--control-streams", type=int, default=1)
+    ap.add_argument("--gru", choices=("batched", "per-utterance"), default="per-utterance",
+                    help="GRU kernel of the pipeline's control half (the plain forward always uses per-utterance)")
     return ap.parse_args()
 
 
@@ -109,9 +115,27 @@ def main():
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, a.streams))]
     shared_gen = par.make_shared_generator(dev) if world > 1 else None   # same draws on every rank, no broadcast
-    full = [torch.empty((B * world, N), dtype=torch.float32, device=dev) for _ in streams] if world > 1 else None
+    use_pipe = bool(a.pipeline) and not share_gpu
+    pipe = None
+    if use_pipe:
+        pmod = importlib.import_module("neural-waveshaping-synthesis_amd.pipeline")
+        pipe = pmod.ForwardPipeline(model, depth=2 * len(streams) + 2, audio_streams=len(streams),
+                                    control_streams=max(1, a.control_streams), batched_gru=a.gru == "batched")
+        streams = pipe.audio
+    nbuf = len(pipe.slots) if use_pipe else len(streams)
+    full = [torch.empty((B * world, N), dtype=torch.float32, device=dev) for _ in range(nbuf)] if world > 1 else None
 
     def step(i, pending):
+        if use_pipe:
+            if world == 1:
+                pipe.submit(f0, control)
+                return None
+            pu, nz = par.shared_draws(101, N - 1, dev, generator=shared_gen)   # identical on all ranks
+            y = pipe.submit(f0, control, phase_u=pu, noise=nz)
+            with torch.cuda.stream(pipe.audio[i % len(pipe.audio)]):           # ordered after this batch's reverb
+                if pending is not None:
+                    pending.wait()
+                return dist.all_gather_into_tensor(full[i % nbuf], y, async_op=True)
         s = streams[i % len(streams)]
         with torch.cuda.stream(s):
             if world > 1 and share_gpu:   # smoke mode only: host-staged gloo collectives
@@ -119,18 +143,20 @@ def main():
                 y = model(f0, control, phase_u=pu.to(dev), noise=nz.to(dev))
                 parts = [torch.empty((B, N)) for _ in range(world)]
                 dist.all_gather(parts, y.cpu())
-                full[i % len(streams)].copy_(torch.cat(parts, 0))
+                full[i % nbuf].copy_(torch.cat(parts, 0))
                 return None
             if world > 1:
                 pu, nz = par.shared_draws(101, N - 1, dev, generator=shared_gen)   # identical on all ranks
                 y = model(f0, control, phase_u=pu, noise=nz)
                 if pending is not None:
                     pending.wait()
-                return dist.all_gather_into_tensor(full[i % len(streams)], y, async_op=True)
+                return dist.all_gather_into_tensor(full[i % nbuf], y, async_op=True)
             model(f0, control)
         return None
 
     def join_streams():
+        if use_pipe:
+            pipe.synchronize()
         for s in streams:
             torch.cuda.current_stream().wait_stream(s)
 
@@ -143,7 +169,7 @@ def main():
         join_streams()
         torch.cuda.synchronize()
         # live HIP-event timing of the dominant kernel on its launch stream, inside the timed region
-        _lib.check(_lib.lib().nws_profile_begin(a.steps, 1 << 3))
+        _lib.check(_lib.lib().nws_profile_begin(a.steps, (1 << 3) | (1 << 1)))
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -162,13 +188,14 @@ def main():
         n = C.c_int(0)
         _lib.check(_lib.lib().nws_profile_collect(ms, C.byref(n)))
         k_ms = float(np.mean([ms[i * 6 + 3] for i in range(n.value)])) if n.value else float("nan")
+        gru_ms_live = float(np.mean([ms[i * 6 + 1] for i in range(n.value)])) if n.value else float("nan")
 
         if world > 1:
             tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
             # the gathered batch must hold every rank's rows (rank r at rows [r*B, (r+1)*B))
-            last = full[(a.steps - 1) % len(streams)]
+            last = full[(a.steps - 1) % nbuf]
             assert torch.isfinite(last).all() and float(last[B * (world - 1):].abs().max()) > 0.0
 
         extra = {}
@@ -251,12 +278,15 @@ def main():
                                    f"batch {B}/GPU x {T} frames (4 s @ 16 kHz), torch.rand F0/control, "
                                    f"RNG draws on device{', RCCL all-gather of waveforms' if world > 1 else ''}",
                        "batch_per_gpu": B, "frames": T, "samples_per_utterance": N, "parallelism": f"batch-shard x{world}",
-                       "streams": len(streams)},
+                       "streams": len(streams),
+                       "issue": (f"ForwardPipeline: control half (carries + {a.gru} GRU) on {len(pipe.control)} side stream(s), "
+                                 f"audio half on {len(streams)} streams, {len(pipe.slots)} workspaces in flight") if use_pipe
+                       else f"whole forwards round-robin on {len(streams)} streams"},
             "x_realtime_aggregate": value / 16000.0,
             "rtf_per_utterance": (ms_per_step * 1e-3) / (N / 16000.0) / B,
             "roofline": {"bound": "mfma", "kernel": "exciter_newt_kernel", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel_ms": k_ms, "flop_per_launch": flops,
+                         "kernel_ms": k_ms, "flop_per_launch": flops, "gru_ms_in_timed_region": gru_ms_live,
                          # the same kernel with nothing else in flight (diagnostic pass, one stream): steps of the timed
                          # region overlap on --streams HIP streams, which stretches each individual launch
                          "kernel_ms_isolated": extra.get("stage_ms", {}).get("exciter_newt"),

@@ -140,6 +140,11 @@ int nws_control_gru(const NwsWeights* w, const float* control, int B, int C, int
  * stateful streaming; the reference's forward is the h0 = 0 case */
 int nws_control_gru_state(const NwsWeights* w, const float* control, int B, int C, int T, const float* h0, float* gru_out,
                           float* hT, void* stream);
+/* the same recurrence, 16 utterances per workgroup on the matrix cores (fp16 two-term split, fp32 accumulate): ~2x the
+ * latency of the per-utterance kernel above but ~1/10 of its VALU work per utterance and 1/16 of its workgroups -- the
+ * form to run beside throughput kernels of other streams (nws_forward_control, batched_gru = 1).  Any B >= 1. */
+int nws_control_gru_batched(const NwsWeights* w, const float* control, int B, int C, int T, const float* h0, float* gru_out,
+                            float* hT, void* stream);
 
 /*
  * Frame-rate MLPs on the GRU output (one kernel):
@@ -230,6 +235,19 @@ size_t nws_forward_workspace_bytes(const NwsReverbPlan* plan, int B, int T);
 int nws_forward(const NwsWeights* w, const NwsForwardAux* aux, const float* f0 /* (B,T) */, const float* control /* (B,C,T) */,
                 int B, int C, int T, float sample_rate, const float* phase_u, const float* rand_phase,
                 const float* noise, float* out /* (B,N) */, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * The same forward in two halves for throughput pipelines: `control` = phase carries + GRU (writes the head of the
+ * workspace, nws_forward_control_bytes), `audio` = frame MLPs .. reverb (reads the head, uses the rest).  Same workspace
+ * layout as nws_forward; one workspace per batch in flight.  The control half of batch i+1 may run on another stream while
+ * the audio half of batch i runs (order them with events).  batched_gru != 0 selects nws_control_gru_batched.
+ */
+size_t nws_forward_control_bytes(int B, int T);
+int nws_forward_control(const NwsWeights* w, const float* f0, const float* control, int B, int C, int T, int batched_gru,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int nws_forward_audio(const NwsWeights* w, const NwsForwardAux* aux, const float* f0, int B, int T, float sample_rate,
+                      const float* phase_u, const float* rand_phase, const float* noise, float* out, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* Diagnostics only: ablation variants of the fused kernel for timing (1 no sin, 2 no LUT gather, 3 no shaper tail,
  * 4 no MFMA; 0 = product kernel).  Outputs of variants != 0 are meaningless. */

@@ -13,5 +13,6 @@ from .models.neural_waveshaping import ControlModule, NeuralWaveshaping, ensure_
 from .models.modules.dynamic import FiLM, TimeDistributedLayerNorm, TimeDistributedMLP  # noqa: F401
 from .models.modules.generators import FIRNoiseSynth, HarmonicOscillator  # noqa: F401
 from .models.modules.shaping import NEWT, FastNEWT, Reverb, Sine, TrainableNonlinearity  # noqa: F401
+from .pipeline import ForwardPipeline  # noqa: F401
 
 __version__ = "0.1.0"

@@ -59,6 +59,7 @@ _PROTOTYPES = {
                                    _fp, _fp, _fp]),
     "nws_control_gru": (C.c_int, [C.POINTER(NwsWeights), _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "nws_control_gru_state": (C.c_int, [C.POINTER(NwsWeights), _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
+    "nws_control_gru_batched": (C.c_int, [C.POINTER(NwsWeights), _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
     "nws_frame_mlps": (C.c_int, [C.POINTER(NwsWeights), _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp]),
     "nws_mlp_frags": (C.c_int, [C.POINTER(NwsWeights), _fp, _fp, _fp]),
     "nws_fir_design_matrix": (C.c_int, [_fp, _fp, _fp]),
@@ -80,6 +81,10 @@ _PROTOTYPES = {
     "nws_forward_workspace_bytes": (C.c_size_t, [C.POINTER(NwsReverbPlan), C.c_int, C.c_int]),
     "nws_forward": (C.c_int, [C.POINTER(NwsWeights), C.POINTER(NwsForwardAux), _fp, _fp, C.c_int, C.c_int, C.c_int,
                               C.c_float, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
+    "nws_forward_control_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "nws_forward_control": (C.c_int, [C.POINTER(NwsWeights), _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_size_t, _fp]),
+    "nws_forward_audio": (C.c_int, [C.POINTER(NwsWeights), C.POINTER(NwsForwardAux), _fp, C.c_int, C.c_int, C.c_float,
+                                    _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
     "nws_debug_exciter_newt": (C.c_int, [C.c_int, C.POINTER(NwsWeights), _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_float,
                                          _fp, _fp]),
     "nws_debug_sin": (C.c_int, [C.c_int, _fp, _fp, C.c_int64, C.c_int, _fp]),

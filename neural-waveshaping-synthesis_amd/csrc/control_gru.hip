@@ -132,6 +132,188 @@ __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const
   if (hT != nullptr && kh == 0) hT[(size_t)b * kH + unit] = h_prev;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Batched form (nws_control_gru_batched; the throughput pipeline uses it): 16 utterances per workgroup, the recurrent product on the matrix cores.
+//   gates (384 x 16) = W_hh (384 x 128) * H (128 x 16 utterances)   per step,
+// v_mfma_f32_16x16x32_f16 with the two-term fp16 split on both operands (three MFMAs per product, fp32 accumulate).
+// 8 waves: wave (w, sub) owns hidden units [32w + 16 sub, +16) for all three gates: 3 tiles x 4 K-steps, W_hh fragments
+// (hi and lo, 96 VGPRs) resident in registers for the whole sequence; two waves share a SIMD, so one wave's gate math
+// (VALU + transcendental unit) overlaps the other's MFMAs.  The h exchange goes through LDS as fp16 hi/lo rows per
+// utterance (B-fragment order is 8 consecutive units per lane: one ds_read_b128 each).
+// Every gate's weights and biases carry the constant its nonlinearity multiplies the argument with anyway (-log2 e for the
+// sigmoids, 2 log2 e for tanh), so the accumulators feed v_exp_f32 directly.  (The lo parts of small weights fall into the
+// fp16 subnormals, quantised at 6e-8 absolute: over a 128-term row that is ~6e-8 on a pre-activation, the size of the fp32
+// rounding noise of the row sum itself.)  The two waves sharing a SIMD run at different priorities so that one's gate math
+// overlaps the other's MFMAs instead of both phases colliding.
+// Why it exists: the per-utterance kernel above spends ~600 wave-instructions per utterance-step (~15 % of the oscillator
+// kernel's VALU work at B = 64) on B workgroups; this one ~1/10 of that per utterance on B/16 workgroups.
+// Measured (MI355X, B = 64, T = 500): alone 0.553 ms against 0.280 ms for the per-utterance kernel (per step 72 MFMAs and
+// the gate math of two waves serialise on each SIMD: VALU-active + MFMA-busy cycles add up to the step time); inside
+// ForwardPipeline, beside the all-CU kernels of other streams, 0.74 ms against 0.38 ms, and the pipelined step comes out
+// the same (0.545 vs 0.536 ms).  So the per-utterance kernel stays the default everywhere; this one is the better citizen
+// when B is large enough for B workgroups to matter (B >= 256) and is kept as an explicit entry point.
+constexpr int kGU = 16;        // utterances per workgroup (MFMA N)
+constexpr int kGChunk = 128;   // control frames staged in LDS at a time
+constexpr int kHRow = 136;     // halfs per utterance row of the h buffers: 272 B stride, conflict-free ds_read_b128
+constexpr float kLog2e = 1.4426950408889634f;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)v;
+  lo = (_Float16)(v - (float)hi);
+}
+
+__global__ __launch_bounds__(512, 1) void control_gru_mfma_kernel(NwsWeights w, const float* __restrict__ control, int B,
+                                                                  int C, int T, const float* __restrict__ h0,
+                                                                  float* __restrict__ gru_out, float* __restrict__ hT,
+                                                                  int upb /* utterances per workgroup, <= kGU */) {
+  const int b0 = blockIdx.x * upb;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the sequence is latency-bound and may share its SIMDs with throughput kernels of other streams: ask for issue priority
+  // (waves w and w+4 share a SIMD: the lower one goes first)
+  if (wave < 4) __builtin_amdgcn_s_setprio(1);
+  const int col = lane & 15;  // A operand: row inside the tile;  B operand / D: utterance
+  const int rg = lane >> 4;   // A/B operand: K quarter (8 values);  D: row group (4 rows)
+  const int ubase = 16 * wave;  // first of this wave's 16 hidden units
+  const int b = b0 + col;     // this lane's utterance (D layout)
+  const bool live = col < upb && b < B;
+
+  __shared__ __attribute__((aligned(16))) _Float16 hhi[2][kGU][kHRow];
+  __shared__ __attribute__((aligned(16))) _Float16 hlo[2][kGU][kHRow];
+  __shared__ float xs[2][kGU][kGChunk];
+
+  const float gscale[3] = {-kLog2e, -kLog2e, 2.0f * kLog2e};
+  // W_hh fragments: tile g = rows g*128 + ubase + [0,16), K-step ks = columns 32 ks + 8 rg + [0,8)
+  f16x8 whi[3][4], wlo[3][4];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const float* src = w.gru_w_hh + (size_t)(g * kH + ubase + col) * kH + 32 * ks + 8 * rg;
+      const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+      const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        _Float16 hi, lo;
+        split_f16(x[e] * gscale[g], hi, lo);
+        whi[g][ks][e] = hi;
+        wlo[g][ks][e] = lo;
+      }
+    }
+  // gate constants of the 4 units this lane owns in the D layout (unit ubase + 4 rg + r), scaled like the weights
+  float wr0[4], wr1[4], br[4], wz0[4], wz1[4], bz[4], wn0[4], wn1[4], bin[4], bhn[4], hprev[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int u = ubase + 4 * rg + r;
+    wr0[r] = gscale[0] * w.gru_w_ih[u * 2 + 0];
+    wr1[r] = gscale[0] * w.gru_w_ih[u * 2 + 1];
+    br[r] = gscale[0] * (w.gru_b_ih[u] + w.gru_b_hh[u]);
+    wz0[r] = gscale[1] * w.gru_w_ih[(kH + u) * 2 + 0];
+    wz1[r] = gscale[1] * w.gru_w_ih[(kH + u) * 2 + 1];
+    bz[r] = gscale[1] * (w.gru_b_ih[kH + u] + w.gru_b_hh[kH + u]);
+    wn0[r] = gscale[2] * w.gru_w_ih[(2 * kH + u) * 2 + 0];
+    wn1[r] = gscale[2] * w.gru_w_ih[(2 * kH + u) * 2 + 1];
+    bin[r] = gscale[2] * w.gru_b_ih[2 * kH + u];
+    bhn[r] = gscale[2] * w.gru_b_hh[2 * kH + u];
+    hprev[r] = (h0 != nullptr && live) ? h0[(size_t)b * kH + u] : 0.0f;
+  }
+  {  // initial state into the exchange buffer (fp16 hi/lo), 4 consecutive units per 8-byte write
+    f16x4 hi4, lo4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      _Float16 hi, lo;
+      split_f16(hprev[r], hi, lo);
+      hi4[r] = hi;
+      lo4[r] = lo;
+    }
+    *reinterpret_cast<f16x4*>(&hhi[0][col][ubase + 4 * rg]) = hi4;
+    *reinterpret_cast<f16x4*>(&hlo[0][col][ubase + 4 * rg]) = lo4;
+  }
+  for (int t0 = 0; t0 < T; t0 += kGChunk) {
+    const int nt = T - t0 < kGChunk ? T - t0 : kGChunk;
+    __syncthreads();  // previous chunk consumed; first pass: initial state published
+    for (int i = tid; i < 2 * kGU * kGChunk; i += 512) {
+      const int ch = i / (kGU * kGChunk), rem = i - ch * (kGU * kGChunk);
+      const int u = rem / kGChunk, tt = rem - u * kGChunk;
+      xs[ch][u][tt] = (u < upb && b0 + u < B && tt < nt) ? control[((size_t)(b0 + u) * C + ch) * T + t0 + tt] : 0.0f;
+    }
+    __syncthreads();
+    for (int tt = 0; tt < nt; ++tt) {
+      const int t = t0 + tt;
+      const int cur = t & 1;
+      // B fragments of h_{t-1}: K-step ks = units 32 ks + 8 rg + [0,8) of utterance `col`
+      f16x8 bhi[4], blo[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bhi[ks] = *reinterpret_cast<const f16x8*>(&hhi[cur][col][32 * ks + 8 * rg]);
+        blo[ks] = *reinterpret_cast<const f16x8*>(&hlo[cur][col][32 * ks + 8 * rg]);
+      }
+      const float x0 = xs[0][col][tt], x1 = xs[1][col][tt];
+      // accumulators start from the input-side terms (r, z: both biases; n: only b_hn, its input side stays apart)
+      f32x4v ar, az, an;
+      float inn[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ar[r] = fmaf(wr1[r], x1, fmaf(wr0[r], x0, br[r]));
+        az[r] = fmaf(wz1[r], x1, fmaf(wz0[r], x0, bz[r]));
+        an[r] = bhn[r];
+        inn[r] = fmaf(wn1[r], x1, fmaf(wn0[r], x0, bin[r]));
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        ar = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[0][ks], bhi[ks], ar, 0, 0, 0);
+        az = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[1][ks], bhi[ks], az, 0, 0, 0);
+        an = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[2][ks], bhi[ks], an, 0, 0, 0);
+        ar = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[0][ks], blo[ks], ar, 0, 0, 0);
+        az = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[1][ks], blo[ks], az, 0, 0, 0);
+        an = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[2][ks], blo[ks], an, 0, 0, 0);
+        ar = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[0][ks], bhi[ks], ar, 0, 0, 0);
+        az = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[1][ks], bhi[ks], az, 0, 0, 0);
+        an = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[2][ks], bhi[ks], an, 0, 0, 0);
+      }
+      float hn[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // ar = -log2(e) a_r: r = 1/(1 + 2^ar);  likewise z;  an = 2 log2(e) (W_hn h + b_hn), inn = 2 log2(e) (W_in x + b_in):
+        // tanh(a) = 1 - 2 / (1 + 2^(2 log2(e) a)), saturating correctly when the exponential over- or underflows
+        const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ar[r]));
+        const float zz = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(az[r]));
+        const float nn = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(rr, an[r], inn[r]))), 1.0f);
+        hn[r] = (hprev[r] - nn) * zz + nn;
+        hprev[r] = hn[r];
+      }
+      const float4 hv = make_float4(hn[0], hn[1], hn[2], hn[3]);
+      f16x4 hi4, lo4;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {  // hi by v_cvt_pk_f16_f32, lo by one v_fma_mix{lo,hi}_f16 each (exact residual, rounded once)
+        const f32x2 v = {hn[2 * p], hn[2 * p + 1]};
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        const f16x2 h2 = __builtin_convertvector(v, f16x2);
+        const unsigned hp = __builtin_bit_cast(unsigned, h2);
+        unsigned lp;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lp) : "v"(hp), "v"(v.x));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lp) : "v"(hp), "v"(v.y));
+        const f16x2 l2 = __builtin_bit_cast(f16x2, lp);
+        hi4[2 * p] = h2.x;
+        hi4[2 * p + 1] = h2.y;
+        lo4[2 * p] = l2.x;
+        lo4[2 * p + 1] = l2.y;
+      }
+      const int u0 = ubase + 4 * rg;
+      *reinterpret_cast<f16x4*>(&hhi[cur ^ 1][col][u0]) = hi4;
+      *reinterpret_cast<f16x4*>(&hlo[cur ^ 1][col][u0]) = lo4;
+      if (live) *reinterpret_cast<float4*>(&gru_out[((size_t)b * T + t) * kH + u0]) = hv;
+      lds_barrier();
+    }
+  }
+  if (hT != nullptr && live) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hT[(size_t)b * kH + ubase + 4 * rg + r] = hprev[r];
+  }
+}
+
 }  // namespace
 
 extern "C" int nws_control_gru_state(const NwsWeights* w, const float* control, int B, int C, int T, const float* h0,
@@ -139,6 +321,18 @@ extern "C" int nws_control_gru_state(const NwsWeights* w, const float* control, 
   if (!w || !w->gru_w_ih || !w->gru_w_hh || !w->gru_b_ih || !w->gru_b_hh || !control || !gru_out) return NWS_ERR_BAD_ARG;
   if (B <= 0 || T <= 0 || C < 2) return NWS_ERR_BAD_ARG;
   control_gru_kernel<<<B, 256, 0, (hipStream_t)stream>>>(*w, control, C, T, h0, gru_out, hT);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+extern "C" int nws_control_gru_batched(const NwsWeights* w, const float* control, int B, int C, int T, const float* h0,
+                                       float* gru_out, float* hT, void* stream) {
+  if (!w || !w->gru_w_ih || !w->gru_w_hh || !w->gru_b_ih || !w->gru_b_hh || !control || !gru_out) return NWS_ERR_BAD_ARG;
+  if (B <= 0 || T <= 0 || C < 2) return NWS_ERR_BAD_ARG;
+  // (fewer utterances per workgroup -- half-empty MFMA tiles, one workgroup on each XCD for B = 64 -- measured no
+  // different beside the all-CU kernels of other streams: 0.544 vs 0.548 ms per pipelined step)
+  const int upb = kGU;
+  control_gru_mfma_kernel<<<(B + upb - 1) / upb, 512, 0, (hipStream_t)stream>>>(*w, control, B, C, T, h0, gru_out, hT, upb);
   NWS_CHECK_LAUNCH();
   return NWS_OK;
 }

@@ -1,5 +1,7 @@
 // Whole NeuralWaveshaping.forward (models/neural_waveshaping.py:74-90) as one enqueue on one stream:
-//   phase carries -> GRU -> frame MLPs -> fused exciter+NEWT -> FIR noise (+ branch sum) -> reverb.
+//   phase carries -> GRU -> frame MLPs -> fused exciter+NEWT -> FIR noise (+ branch sum) -> reverb,
+// or as two halves (control: carries + GRU; audio: the rest) so that a throughput pipeline can run the latency-bound
+// recurrence of the next batch on a side stream under the all-CU kernels of the current one.
 // Scratch comes from the caller's workspace; nothing is allocated or synchronised here, so the whole
 // call can be captured into a hipGraph (streaming mode, scripts/time_buffer_sizes.py counterpart).
 #include "nws_common.h"
@@ -57,28 +59,38 @@ size_t nws_forward_workspace_bytes(const NwsReverbPlan* plan, int B, int T) {
   return total;
 }
 
-int nws_forward(const NwsWeights* w, const NwsForwardAux* aux, const float* f0, const float* control, int B, int C,
-                int T, float sample_rate, const float* phase_u, const float* rand_phase, const float* noise, float* out,
-                void* workspace,
-                size_t workspace_bytes, void* stream) {
-  if (!w || !aux || !aux->plan || !aux->fir_design || !aux->reverb_tables || !aux->reverb_spectrum) return NWS_ERR_BAD_ARG;
-  if (!f0 || !control || !phase_u || !rand_phase || !noise || !out || !workspace) return NWS_ERR_BAD_ARG;
-  if (B <= 0 || T < 2 || C < 2) return NWS_ERR_BAD_ARG;
-  const size_t N = (size_t)T * NWS_HOP;
-  if ((long long)N > aux->plan->L) return NWS_ERR_BAD_ARG;
-  Carve cv{static_cast<char*>(workspace), workspace_bytes};
-  double* carry = static_cast<double*>(cv.take((size_t)B * (N / 32) * sizeof(double)));
-  float* gru_out = static_cast<float*>(cv.take((size_t)B * T * NWS_HIDDEN * sizeof(float)));
-  float* film = static_cast<float*>(cv.take((size_t)B * T * NWS_FILM_CH * sizeof(float)));
-  float* fir = static_cast<float*>(cv.take((size_t)B * T * NWS_FIR_LEN * sizeof(float)));
-  float* newt_out = static_cast<float*>(cv.take((size_t)B * N * sizeof(float)));
-  float* pre = static_cast<float*>(cv.take((size_t)B * N * sizeof(float)));
-  const size_t rv_bytes = nws_reverb_workspace_bytes(aux->plan, B);
-  void* rv_ws = cv.take(rv_bytes);
-  if (!cv.ok) return NWS_ERR_WORKSPACE;
+}  // extern "C"
 
-  hipStream_t st = (hipStream_t)stream;
-  int rc = NWS_OK;
+namespace {
+
+struct Arena {
+  double* carry;
+  float *gru_out, *film, *fir, *newt_out, *pre;
+  void* rv_ws;
+  size_t rv_bytes;
+  bool ok;
+};
+
+// One layout for nws_forward, nws_forward_control (writes the head: carries, gru_out) and nws_forward_audio (reads the
+// head, uses the rest).
+Arena carve_arena(const NwsReverbPlan* plan, void* workspace, size_t bytes, int B, int T, bool head_only) {
+  const size_t N = (size_t)T * NWS_HOP;
+  Carve cv{static_cast<char*>(workspace), bytes};
+  Arena a{};
+  a.carry = static_cast<double*>(cv.take((size_t)B * (N / 32) * sizeof(double)));
+  a.gru_out = static_cast<float*>(cv.take((size_t)B * T * NWS_HIDDEN * sizeof(float)));
+  if (!head_only) {
+    a.film = static_cast<float*>(cv.take((size_t)B * T * NWS_FILM_CH * sizeof(float)));
+    a.fir = static_cast<float*>(cv.take((size_t)B * T * NWS_FIR_LEN * sizeof(float)));
+    a.newt_out = static_cast<float*>(cv.take((size_t)B * N * sizeof(float)));
+    a.pre = static_cast<float*>(cv.take((size_t)B * N * sizeof(float)));
+    a.rv_bytes = nws_reverb_workspace_bytes(plan, B);
+    a.rv_ws = cv.take(a.rv_bytes);
+  }
+  a.ok = cv.ok;
+  return a;
+}
+
 #define NWS_STAGE(idx, call)                                   \
   do {                                                         \
     hipEvent_t* e__ = prof_events(idx);                        \
@@ -87,15 +99,81 @@ int nws_forward(const NwsWeights* w, const NwsForwardAux* aux, const float* f0, 
     if (e__) (void)hipEventRecord(e__[1], st);                 \
     if (rc != NWS_OK) return rc;                               \
   } while (0)
-  NWS_STAGE(0, nws_phase_carry(f0, nullptr, B, T, carry, stream));
-  NWS_STAGE(1, nws_control_gru(w, control, B, C, T, gru_out, stream));
-  NWS_STAGE(2, nws_frame_mlps(w, gru_out, aux->fir_design, B, T, nullptr, film, nullptr, fir, stream));
-  NWS_STAGE(3, nws_exciter_newt(w, f0, nullptr, carry, phase_u, rand_phase, film, B, T, sample_rate, nullptr, newt_out, stream));
-  NWS_STAGE(4, nws_fir_noise(fir, noise, newt_out, B, T, pre, stream));
-  NWS_STAGE(5, nws_reverb(aux->plan, aux->reverb_tables, aux->reverb_spectrum, pre, B, (int)N, out, rv_ws, rv_bytes, stream));
-#undef NWS_STAGE
+
+int control_half(const NwsWeights* w, const float* f0, const float* control, int B, int C, int T, int batched_gru,
+                 const Arena& a, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int rc = NWS_OK;
+  NWS_STAGE(0, nws_phase_carry(f0, nullptr, B, T, a.carry, stream));
+  if (batched_gru)
+    NWS_STAGE(1, nws_control_gru_batched(w, control, B, C, T, nullptr, a.gru_out, nullptr, stream));
+  else
+    NWS_STAGE(1, nws_control_gru(w, control, B, C, T, a.gru_out, stream));
+  return NWS_OK;
+}
+
+int audio_half(const NwsWeights* w, const NwsForwardAux* aux, const float* f0, int B, int T, float sample_rate,
+               const float* phase_u, const float* rand_phase, const float* noise, float* out, const Arena& a, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int rc = NWS_OK;
+  const size_t N = (size_t)T * NWS_HOP;
+  NWS_STAGE(2, nws_frame_mlps(w, a.gru_out, aux->fir_design, B, T, nullptr, a.film, nullptr, a.fir, stream));
+  NWS_STAGE(3, nws_exciter_newt(w, f0, nullptr, a.carry, phase_u, rand_phase, a.film, B, T, sample_rate, nullptr, a.newt_out, stream));
+  NWS_STAGE(4, nws_fir_noise(a.fir, noise, a.newt_out, B, T, a.pre, stream));
+  NWS_STAGE(5, nws_reverb(aux->plan, aux->reverb_tables, aux->reverb_spectrum, a.pre, B, (int)N, out, a.rv_ws, a.rv_bytes, stream));
   if (g_prof.ev != nullptr && g_prof.used < g_prof.slots) ++g_prof.used;
   return NWS_OK;
+}
+#undef NWS_STAGE
+
+bool aux_ok(const NwsForwardAux* aux) {
+  return aux && aux->plan && aux->fir_design && aux->reverb_tables && aux->reverb_spectrum;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t nws_forward_control_bytes(int B, int T) {
+  if (B <= 0 || T <= 0) return 0;
+  const size_t N = (size_t)T * NWS_HOP;
+  return aligned((size_t)B * (N / 32) * sizeof(double)) + aligned((size_t)B * T * NWS_HIDDEN * sizeof(float));
+}
+
+int nws_forward(const NwsWeights* w, const NwsForwardAux* aux, const float* f0, const float* control, int B, int C,
+                int T, float sample_rate, const float* phase_u, const float* rand_phase, const float* noise, float* out,
+                void* workspace, size_t workspace_bytes, void* stream) {
+  if (!w || !aux_ok(aux)) return NWS_ERR_BAD_ARG;
+  if (!f0 || !control || !phase_u || !rand_phase || !noise || !out || !workspace) return NWS_ERR_BAD_ARG;
+  if (B <= 0 || T < 2 || C < 2) return NWS_ERR_BAD_ARG;
+  if ((long long)T * NWS_HOP > aux->plan->L) return NWS_ERR_BAD_ARG;
+  const Arena a = carve_arena(aux->plan, workspace, workspace_bytes, B, T, false);
+  if (!a.ok) return NWS_ERR_WORKSPACE;
+  // one stream, one call: the per-utterance recurrence (64 CUs for 64 utterances) has the shorter latency
+  const int rc = control_half(w, f0, control, B, C, T, 0, a, stream);
+  if (rc != NWS_OK) return rc;
+  return audio_half(w, aux, f0, B, T, sample_rate, phase_u, rand_phase, noise, out, a, stream);
+}
+
+int nws_forward_control(const NwsWeights* w, const float* f0, const float* control, int B, int C, int T, int batched_gru,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+  if (!w || !f0 || !control || !workspace) return NWS_ERR_BAD_ARG;
+  if (B <= 0 || T < 2 || C < 2) return NWS_ERR_BAD_ARG;
+  const Arena a = carve_arena(nullptr, workspace, workspace_bytes, B, T, true);
+  if (!a.ok) return NWS_ERR_WORKSPACE;
+  return control_half(w, f0, control, B, C, T, batched_gru, a, stream);
+}
+
+int nws_forward_audio(const NwsWeights* w, const NwsForwardAux* aux, const float* f0, int B, int T, float sample_rate,
+                      const float* phase_u, const float* rand_phase, const float* noise, float* out, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  if (!w || !aux_ok(aux)) return NWS_ERR_BAD_ARG;
+  if (!f0 || !phase_u || !rand_phase || !noise || !out || !workspace) return NWS_ERR_BAD_ARG;
+  if (B <= 0 || T < 2) return NWS_ERR_BAD_ARG;
+  if ((long long)T * NWS_HOP > aux->plan->L) return NWS_ERR_BAD_ARG;
+  const Arena a = carve_arena(aux->plan, workspace, workspace_bytes, B, T, false);
+  if (!a.ok) return NWS_ERR_WORKSPACE;
+  return audio_half(w, aux, f0, B, T, sample_rate, phase_u, rand_phase, noise, out, a, stream);
 }
 
 int nws_profile_begin(int slots, unsigned stage_mask) {

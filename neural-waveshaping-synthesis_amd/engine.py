@@ -233,11 +233,15 @@ class Engine:
                                           ptr(out), stream_ptr()), "nws_exciter_newt")
         return exc, out
 
-    def control_gru(self, control):
+    def control_gru(self, control, batched=False):
         w, _, dev = self.weights()
         B, Cc, T = control.shape
         out = torch.empty((B, T, _lib.HIDDEN), dtype=torch.float32, device=dev)
-        check(_lib.lib().nws_control_gru(C.byref(w), ptr(control), B, Cc, T, ptr(out), stream_ptr()), "nws_control_gru")
+        if batched:
+            check(_lib.lib().nws_control_gru_batched(C.byref(w), ptr(control), B, Cc, T, None, ptr(out), None,
+                                                     stream_ptr()), "nws_control_gru_batched")
+        else:
+            check(_lib.lib().nws_control_gru(C.byref(w), ptr(control), B, Cc, T, ptr(out), stream_ptr()), "nws_control_gru")
         return out
 
     def frame_mlps(self, gru_out, want_emb=False, want_H=False):
@@ -282,6 +286,36 @@ class Engine:
         return y
 
     # ---- the whole forward: ONE C-ABI call --------------------------------------------------------
+    # ---- the forward in two halves (throughput pipeline, pipeline.py) ------------------------------------------------
+    def new_workspace(self, B, T):
+        plan, _, _ = self.reverb_aux(T * _lib.HOP)
+        _, _, dev = self.weights()
+        return torch.empty(_lib.lib().nws_forward_workspace_bytes(C.byref(plan), B, T), dtype=torch.uint8, device=dev)
+
+    def forward_control(self, f0, control, ws, batched_gru=True):
+        """phase carries + GRU into the head of `ws`, on the current stream"""
+        w, _, _ = self.weights()
+        B, Cc, T = control.shape
+        check(_lib.lib().nws_forward_control(C.byref(w), ptr(f0), ptr(control), B, Cc, T, 1 if batched_gru else 0, ptr(ws),
+                                             ws.numel(), stream_ptr()), "nws_forward_control")
+
+    def forward_audio(self, f0, B, T, phase_u, noise, ws, out=None):
+        """frame MLPs .. reverb from the head of `ws` (forward_control must have completed in stream order / by event)"""
+        w, _, dev = self.weights()
+        N = T * _lib.HOP
+        plan, tables, spec = self.reverb_aux(N)
+        if out is None:
+            out = torch.empty((B, N), dtype=torch.float32, device=dev)
+        aux = NwsForwardAux()
+        aux.fir_design = ptr(self.fir_design())
+        aux.plan = C.pointer(plan)
+        aux.reverb_tables = ptr(tables)
+        aux.reverb_spectrum = ptr(spec)
+        check(_lib.lib().nws_forward_audio(C.byref(w), C.byref(aux), ptr(f0), B, T, float(self._model_ref.sample_rate),
+                                           ptr(phase_u), ptr(self.rand_phase()), ptr(noise), ptr(out), ptr(ws), ws.numel(),
+                                           stream_ptr()), "nws_forward_audio")
+        return out
+
     def forward(self, f0, control, phase_u, noise, out=None):
         w, _, dev = self.weights()
         B, Cc, T = control.shape

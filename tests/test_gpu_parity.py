@@ -148,6 +148,91 @@ def test_gru_and_frame_mlps(models, oracle, weights):
     assert maxabs(emb.cpu().numpy(), g["embedding"]) <= 1e-5
 
 
+def test_forward_pipeline_matches_plain_forward(models, oracle):
+    """ForwardPipeline (control half on side streams, batched GRU, ring of workspaces) must return what model() returns for
+    the same inputs and draws, batch after batch, including a shape change in mid-stream; one batch is also held against
+    the oracle."""
+    import nws_amd
+    _, fast = models
+    g = torch.Generator().manual_seed(31)
+    jobs = []
+    for k, (B, T) in enumerate([(20, 40), (20, 40), (20, 40), (20, 40), (20, 40), (3, 17), (3, 17), (33, 24)]):
+        f0 = (100 + 600 * torch.rand(B, 1, 1, generator=g)) * (1 + 0.01 * torch.randn(B, 1, T, generator=g))
+        control = torch.randn(B, 2, T, generator=g)
+        pu, nz = torch.rand(101, generator=g), torch.rand(128 * T - 1, generator=g)
+        jobs.append((f0.cuda(), control.cuda(), pu.cuda(), nz.cuda()))
+    torch.cuda.synchronize()
+    refs = [fast(f0, c, phase_u=pu, noise=nz).cpu().numpy() for f0, c, pu, nz in jobs]
+    f0, c, pu, nz = jobs[0]
+    ref_orc = oracle[1](f0.cpu(), c.cpu(), pu.cpu(), nz.cpu()).numpy()
+    for batched, kw in ((False, dict(depth=3, audio_streams=2, control_streams=1)),
+                        (True, dict(depth=2, audio_streams=1, control_streams=2))):
+        pipe = nws_amd.ForwardPipeline(fast, batched_gru=batched, **kw)
+        outs = [pipe.submit(f0, c, phase_u=pu, noise=nz) for f0, c, pu, nz in jobs]
+        pipe.join_current_stream()
+        got = [o.cpu().numpy() for o in outs]
+        worst = max(rms(y - r) / max(rms(r), 1e-9) for y, r in zip(got, refs))
+        e_orc = rms(got[0] - ref_orc)
+        record("forward_pipeline_" + ("batched_gru" if batched else "default"), worst_rel_rms_vs_plain_forward=worst,
+               rms_err_vs_oracle=e_orc)
+        # default: the very same kernels -> identical;  batched GRU: two fp32-class recurrences differ in rounding
+        assert worst <= (2e-5 if batched else 0.0), (batched, worst)
+        assert e_orc <= 1e-4
+    # default RNG path: draws come from the device generator in submit order
+    torch.manual_seed(123)
+    a1 = pipe.submit(jobs[0][0], jobs[0][1])
+    pipe.synchronize()
+    torch.manual_seed(123)
+    a2 = pipe.submit(jobs[0][0], jobs[0][1])
+    pipe.synchronize()
+    assert torch.equal(a1, a2)
+
+
+@pytest.mark.parametrize("B,T", [(40, 300), (16, 7), (64, 500)])
+def test_gru_batched_mfma_path(models, weights, B, T):
+    """nws_control_gru_batched runs the recurrence as a GEMM per step on the matrix cores (16 utterances per workgroup, fp16
+    two-term split).  Held to the same yard-stick as the per-utterance kernel: a float64 GRU, error class of torch's own fp32
+    GRU; plus the carried-state form (two halves == one pass)."""
+    import ctypes as C
+    import nws_amd
+    _lib = nws_amd._lib
+    check, ptr, stream_ptr = _lib.check, _lib.ptr, _lib.stream_ptr
+    m, _ = models
+    eng = m._engine
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    control = torch.randn(B, 3, T, generator=g) * torch.linspace(0.2, 3.0, B).view(B, 1, 1)
+    got = eng.control_gru(control.cuda(), batched=True).cpu().numpy()
+    small = eng.control_gru(control.cuda()).cpu().numpy()
+    g64 = _gru_float64(weights, control.numpy())
+    gru_t = torch.nn.GRU(2, 128, batch_first=True)
+    with torch.no_grad():
+        for name in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+            getattr(gru_t, name).copy_(torch.from_numpy(weights["embedding.gru." + name]))
+        ref32 = gru_t(control[:, :2].transpose(1, 2))[0].numpy()
+    e64, e_small64, e_ref64 = maxabs(got, g64), maxabs(small, g64), maxabs(ref32, g64)
+    record(f"gru_mfma_B{B}_T{T}", vs_f64=e64, per_utterance_kernel_vs_f64=e_small64, torch_vs_f64=e_ref64,
+           vs_per_utterance_kernel=maxabs(got, small))
+    assert e64 <= max(5e-6, 3.0 * e_ref64), (e64, e_ref64)
+    # carried state: two halves through nws_control_gru_state == one pass
+    w, _, dev_ = eng.weights()
+    Ta = T // 2 + 1
+    h = torch.zeros(B, 128, device="cuda")
+    outs = []
+    for a, b_ in ((0, Ta), (Ta, T)):
+        if b_ <= a:
+            continue
+        c = control[:, :, a:b_].contiguous().cuda()
+        o = torch.empty(B, b_ - a, 128, device="cuda")
+        hn = torch.empty_like(h)
+        check(_lib.lib().nws_control_gru_batched(C.byref(w), ptr(c), B, 3, b_ - a, ptr(h), ptr(o), ptr(hn), stream_ptr()),
+              "nws_control_gru_batched")
+        outs.append(o)
+        h = hn
+    two = torch.cat(outs, dim=1).cpu().numpy()
+    assert maxabs(two, got) <= 1e-6
+    assert maxabs(h.cpu().numpy(), got[:, -1]) <= 1e-6
+
+
 def test_frame_mlps_fp32_fallback_kernel(models, oracle):
     """The exact-fp32 MFMA kernel (used when weight norms could overflow the fp16 two-term split) stays correct."""
     m = build_model(False)
