@@ -7,7 +7,13 @@
     model.newt = nws.FastNEWT(model.newt)
     audio = model(f0, control)
 """
-from . import ginlite as gin  # noqa: F401
+import os as _os
+
+# ForwardPipeline runs 3+ streams beside the caller's own (and RCCL's); HIP folds streams onto 4 hardware queues by default
+# and streams sharing a queue serialise.  Only effective if the HIP runtime has not started yet; harmless otherwise.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from . import ginlite as gin  # noqa: F401,E402
 from ._lib import LIB_PATH, NwsError  # noqa: F401
 from .models.neural_waveshaping import ControlModule, NeuralWaveshaping, ensure_default_config, _DEFAULT_GIN as DEFAULT_GIN  # noqa: F401,E501
 from .models.modules.dynamic import FiLM, TimeDistributedLayerNorm, TimeDistributedMLP  # noqa: F401
