@@ -31,7 +31,10 @@ sys.path.insert(0, ROOT)
 # algorithmic work of the dominant kernel (exciter_newt_kernel) per utterance of T=500 frames, SURVEY.md §8(d):
 #   harmonic mixer 2*64*101 flop/sample + 101 sin/sample (1 flop each) + FiLM lerp/FiLM/LUT/mix ~ 24 flop per (sample, shaper)
 FLOP_PER_SAMPLE_EXCITER_NEWT = 2 * 64 * 101 + 101 * 5 + 64 * 24
-PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= the fp32 vector peak)
+PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
+# matrix-core work the kernel actually issues: 3 fp16 MFMAs (hi*hi, hi*lo, lo*hi) of 64 shapers x 112 K slots per sample
+MFMA_F16_FLOP_PER_SAMPLE_EXECUTED = 3 * 2 * 64 * 112
 
 
 def parse():
@@ -276,13 +279,19 @@ def main():
         ms_per_step = elapsed / a.steps * 1e3
         flops = FLOP_PER_SAMPLE_EXCITER_NEWT * B * N
         achieved = flops / (k_ms * 1e-3) / 1e12
-        traffic = None   # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
+        traffic, valu_issue = None, None   # from the committed rocprofv3 PMC passes (profiles/r01/pmc_traffic.json)
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
             if tr["batch_per_gpu"] == B and tr["frames"] == T and not a.exact:
                 traffic = tr["hbm_bytes_per_launch"]
+                if tr.get("valu_active_quad_cycles_per_wave") and tr.get("gui_active_cycles"):
+                    # VALU-busy share of the kernel: (waves x VALU-active cycles per wave) / (SIMDs x kernel cycles)
+                    busy = tr["waves"] * tr["valu_active_quad_cycles_per_wave"] * 4.0 / (1024.0 * tr["gui_active_cycles"])
+                    valu_issue = {"insts_per_wave": tr["valu_insts_per_wave"], "trans_per_wave": tr["trans_insts_per_wave"],
+                                  "busy_frac_of_kernel_cycles": round(busy, 3), "source": "rocprofv3 --pmc, one stream"}
         except Exception:
             pass
+        mfma_exec = MFMA_F16_FLOP_PER_SAMPLE_EXECUTED * B * N / (k_ms * 1e-3) / 1e12
         out = {
             "metric": "audio_samples_per_sec", "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
@@ -300,6 +309,13 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "exciter_newt_kernel", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "kernel_ms": k_ms, "flop_per_launch": flops, "gru_ms_in_timed_region": gru_ms_live,
+                         "note": "achieved = algorithmic fp32 flop per launch / live kernel time, peak = fp32 matrix (= vector) "
+                                 "peak as the path computes in f32.  The 101->64 contraction runs as three fp16 MFMAs per fp32 "
+                                 "product on the fp16 matrix pipe (16x the fp32 MFMA rate), which is how frac can pass 1; the "
+                                 "kernel is bound by VALU issue (sines, table index math), see valu_issue and DESIGN.md 3.2",
+                         "mfma_f16_executed": {"achieved": mfma_exec, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                               "frac": mfma_exec / PEAK_F16_MFMA_TFLOPS},
+                         "valu_issue": valu_issue,
                          # the same kernel with nothing else in flight (diagnostic pass, one stream): steps of the timed
                          # region overlap on --streams HIP streams, which stretches each individual launch
                          "kernel_ms_isolated": extra.get("stage_ms", {}).get("exciter_newt"),

@@ -1,0 +1,76 @@
+#!/usr/bin/env python
+"""Condense gpurun_out/prof_<round>/ (tools/collect_profiles.sh) into the small files kept under profiles/<round>/:
+   rocprofv3_kernel_stats_*.csv (copied), pmc_digest.txt, pmc_traffic.json, rocprofv3_summary.txt."""
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"\(.*", "", name)
+    return re.sub(r"^void ", "", name)[:24]
+
+
+def counters(root, sub):
+    agg = defaultdict(lambda: defaultdict(list))
+    for path in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(path)):
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {n: sum(v) / len(v) for n, v in c.items()} for k, c in agg.items()}
+
+
+def main(root):
+    out = {}
+    for sub in ("pmc_sq", "pmc_mfma", "pmc_l2", "pmc_fetch", "pmc_write"):
+        for k, c in counters(root, sub).items():
+            out.setdefault(k, {}).update(c)
+    lines = ["# rocprofv3 --pmc digest, per-dispatch averages at B=64, T=500, one stream, whole forwards (separate passes: "
+             "pmc_sq, pmc_mfma, pmc_l2, pmc_fetch, pmc_write).",
+             "# SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are quad-cycles summed over waves, except SQ_VALU_MFMA_BUSY_CYCLES (cycles).",
+             "# FETCH_SIZE / WRITE_SIZE in KB as reported (gfx950 x2 correction for wide coalesced reads NOT applied here)."]
+    for k in sorted(out):
+        m = out[k]
+        w = m.get("SQ_WAVES", 0) or 1
+        g = lambda n: m.get(n, float("nan"))  # noqa: E731
+        wc = g("SQ_WAVE_CYCLES") or 1
+        lines.append(
+            f"{k:24s} waves {w:7.0f} | per wave: VALU {g('SQ_INSTS_VALU') / w:6.0f} MFMA {g('SQ_INSTS_MFMA') / w:4.0f} "
+            f"TRANS {g('SQ_INSTS_VALU_TRANS_F32') / w:5.0f} wave-quad-cycles {wc / w:8.0f} | of wave-cycles: valu "
+            f"{g('SQ_ACTIVE_INST_VALU') / wc:.2f} lds {g('SQ_ACTIVE_INST_LDS') / wc:.2f} wait_any {g('SQ_WAIT_ANY') / wc:.2f} "
+            f"wait_inst {g('SQ_WAIT_INST_ANY') / wc:.2f} | MFMA busy cyc/wave {g('SQ_VALU_MFMA_BUSY_CYCLES') / w:7.0f} | "
+            f"MOPS f16 {g('SQ_INSTS_VALU_MFMA_MOPS_F16'):.3g} f32 {g('SQ_INSTS_VALU_MFMA_MOPS_F32'):.3g} | LDS bank-conflict/"
+            f"active {g('SQ_LDS_BANK_CONFLICT') / (g('SQ_LDS_IDX_ACTIVE') or 1):.3f} | L2 hit "
+            f"{g('TCC_HIT_sum') / ((g('TCC_HIT_sum') + g('TCC_MISS_sum')) or 1):.3f} | FETCH_KB {g('FETCH_SIZE'):8.0f} "
+            f"WRITE_KB {g('WRITE_SIZE'):8.0f} | GUI_ACTIVE {g('GRBM_GUI_ACTIVE'):.3g}")
+    open(os.path.join(root, "pmc_digest.txt"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    ex = next((v for k, v in out.items() if k.startswith("exciter_newt_kernel")), None)
+    if ex and "FETCH_SIZE" in ex and "WRITE_SIZE" in ex:
+        w = ex.get("SQ_WAVES", 0) or 1
+        traffic = {
+            "source": "pmc_digest.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, B=64 T=500)",
+            "kernel": "exciter_newt_kernel", "batch_per_gpu": 64, "frames": 500,
+            "fetch_kb": ex["FETCH_SIZE"], "write_kb": ex["WRITE_SIZE"],
+            "correction": "FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md "
+                          "§HBM); WRITE_SIZE as reported",
+            "hbm_bytes_per_launch": (2.0 * ex["FETCH_SIZE"] + ex["WRITE_SIZE"]) * 1024.0,
+            "valu_insts_per_wave": ex.get("SQ_INSTS_VALU", 0) / w, "mfma_insts_per_wave": ex.get("SQ_INSTS_MFMA", 0) / w,
+            "trans_insts_per_wave": ex.get("SQ_INSTS_VALU_TRANS_F32", 0) / w, "waves": w,
+            "valu_active_quad_cycles_per_wave": ex.get("SQ_ACTIVE_INST_VALU", 0) / w,
+            "wave_quad_cycles_per_wave": ex.get("SQ_WAVE_CYCLES", 0) / w,
+            "gui_active_cycles": ex.get("GRBM_GUI_ACTIVE"),
+        }
+        json.dump(traffic, open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)
+    for tag in ("default", "1stream"):
+        for path in glob.glob(os.path.join(root, "trace_" + tag, "**", "*kernel_stats.csv"), recursive=True):
+            shutil.copy(path, os.path.join(root, f"rocprofv3_kernel_stats_{tag}.csv"))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
