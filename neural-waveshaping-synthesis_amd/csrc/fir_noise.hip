@@ -145,11 +145,34 @@ struct NoiseMfmaLds {
   _Float16 hhi[kUtt][kRowHalfs];   // taps of the frame being accumulated, times the utterance's power-of-two scale
   _Float16 hlo[kUtt][kRowHalfs];
   float unscale[kUtt];             // 1 / (tap scale * noise scale) per utterance
+  float win[3 * kHop];             // padded noise [128 (t-1), 128 (t-1) + 384), times the noise scale: frames t-1 and t
 };
 
-__device__ __forceinline__ void split16(float v, _Float16& hi, _Float16& lo) {
-  hi = (_Float16)v;
-  lo = (_Float16)(v - (float)hi);
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// (hi, lo) fp16 split of two values: v_cvt_pk_f16_f32 for hi, one v_fma_mix{lo,hi}_f16 per lo (exact residual rounded once)
+__device__ __forceinline__ void split16x2(float a, float b, f16x2& hi, f16x2& lo) {
+  hi = __builtin_convertvector(f32x2{a, b}, f16x2);
+  const unsigned hp = __builtin_bit_cast(unsigned, hi);
+  unsigned lp;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lp) : "v"(hp), "v"(a));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lp) : "v"(hp), "v"(b));
+  lo = __builtin_bit_cast(f16x2, lp);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+// maximum of non-negative values over the wave, valid in lane 63 (DPP: no LDS round trips; 0 is the identity)
+__device__ __forceinline__ float wave_max_to_lane63(float v) {
+  v = fmaxf(v, dpp_f32<0xb1, 0xf>(v));   // quad_perm [1,0,3,2]
+  v = fmaxf(v, dpp_f32<0x4e, 0xf>(v));   // quad_perm [2,3,0,1]
+  v = fmaxf(v, dpp_f32<0x141, 0xf>(v));  // row_half_mirror
+  v = fmaxf(v, dpp_f32<0x140, 0xf>(v));  // row_mirror
+  v = fmaxf(v, dpp_f32<0x142, 0xa>(v));  // row_bcast15 -> rows 1, 3
+  v = fmaxf(v, dpp_f32<0x143, 0xc>(v));  // row_bcast31 -> rows 2, 3
+  return v;
 }
 
 __global__ __launch_bounds__(256, 3) void fir_noise_mfma_kernel(const float* __restrict__ fir, const float* __restrict__ noise,
@@ -175,14 +198,10 @@ __global__ __launch_bounds__(256, 3) void fir_noise_mfma_kernel(const float* __r
   load_rows(t, cur);
   load_rows(t - 1, prv);
 
-  // reversed noise frames, eight shifted copies each.  frame 0: R[u] = f_t[(-u) & 255]; frame 1: R[u] = f_{t-1}[(128-u) & 255]
-  for (int e = tid; e < 2 * 8 * kCopyHalfs; e += 256) {
-    const int fr = e / (8 * kCopyHalfs), rem = e - fr * (8 * kCopyHalfs);
-    const int c = rem / kCopyHalfs, v = rem - c * kCopyHalfs;
-    const int u = (v + c) & 255;
-    const int i = fr == 0 ? kHop * t + ((-u) & 255) : kHop * (t - 1) + ((kHop - u) & 255);
-    const float val = (i >= 0 && i < N + kL - 1) ? padded_noise(noise, len, origin, i) : 0.0f;
-    split16(val * kNoiseScale, L.rhi[fr][c][v], L.rlo[fr][c][v]);
+  // the 384 noise samples both frames are cut from, once (reflect padding resolved here), pre-scaled
+  for (int e = tid; e < 3 * kHop; e += 256) {
+    const int i = kHop * (t - 1) + e;
+    L.win[e] = (i >= 0 && i < N + kL - 1) ? padded_noise(noise, len, origin, i) * kNoiseScale : 0.0f;
   }
 
   // one power-of-two scale per utterance (both frames): largest |tap| -> [2^14, 2^15).  Keeps hi AND lo of every tap that
@@ -192,26 +211,43 @@ __global__ __launch_bounds__(256, 3) void fir_noise_mfma_kernel(const float* __r
   for (int it = 0; it < 8; ++it) {
     float mx = fmaxf(fmaxf(fmaxf(fabsf(cur[it].x), fabsf(cur[it].y)), fmaxf(fabsf(cur[it].z), fabsf(cur[it].w))),
                      fmaxf(fmaxf(fabsf(prv[it].x), fabsf(prv[it].y)), fmaxf(fabsf(prv[it].z), fabsf(prv[it].w))));
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    int ex = (int)((__float_as_uint(mx) >> 23) & 0xff);  // biased exponent of the row maximum
+    mx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_max_to_lane63(mx)), 63));
+    int ex = (int)((__float_as_uint(mx) >> 23) & 0xff);  // biased exponent of the row maximum (wave-uniform)
     ex = ex < 16 ? 16 : (ex > 250 ? 250 : ex);
     scale[it] = __uint_as_float((unsigned)(268 - ex) << 23);          // 2^(14 - e)
     if (lane == 0) L.unscale[wave + 4 * it] = __uint_as_float((unsigned)(ex - 14) << 23) * (1.0f / kNoiseScale);  // 2^(e - 14) / 2^10
+  }
+  __syncthreads();  // win complete
+
+  // reversed noise frames, eight shifted copies each: frame 0: R[u] = f_t[(-u) & 255] = win[128 + ((-u) & 255)];
+  // frame 1: R[u] = f_{t-1}[(128 - u) & 255] = win[(128 - u) & 255].  One thread fills 8 consecutive v (one 16-byte chunk).
+  for (int ch = tid; ch < 2 * 8 * (kCopyHalfs / 8); ch += 256) {
+    const int fr = ch / (8 * (kCopyHalfs / 8)), rem = ch - fr * (8 * (kCopyHalfs / 8));
+    const int c = rem / (kCopyHalfs / 8), v0 = 8 * (rem - c * (kCopyHalfs / 8));
+    f16x8 h8, l8;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int u0 = (v0 + 2 * q + c) & 255, u1 = (v0 + 2 * q + 1 + c) & 255;
+      const float a = fr == 0 ? L.win[kHop + ((-u0) & 255)] : L.win[(kHop - u0) & 255];
+      const float bb = fr == 0 ? L.win[kHop + ((-u1) & 255)] : L.win[(kHop - u1) & 255];
+      f16x2 hi, lo;
+      split16x2(a, bb, hi, lo);
+      h8[2 * q] = hi.x;
+      h8[2 * q + 1] = hi.y;
+      l8[2 * q] = lo.x;
+      l8[2 * q + 1] = lo.y;
+    }
+    *reinterpret_cast<f16x8*>(&L.rhi[fr][c][v0]) = h8;
+    *reinterpret_cast<f16x8*>(&L.rlo[fr][c][v0]) = l8;
   }
   auto stage_rows = [&](const float4 (&v)[8]) {
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int r = wave + 4 * it;
-      const float x[4] = {v[it].x * scale[it], v[it].y * scale[it], v[it].z * scale[it], v[it].w * scale[it]};
-      f16x4 h, l;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        _Float16 hq, lq;
-        split16(x[q], hq, lq);
-        h[q] = hq;
-        l[q] = lq;
-      }
+      f16x2 h01, l01, h23, l23;
+      split16x2(v[it].x * scale[it], v[it].y * scale[it], h01, l01);
+      split16x2(v[it].z * scale[it], v[it].w * scale[it], h23, l23);
+      const f16x4 h = {h01.x, h01.y, h23.x, h23.y}, l = {l01.x, l01.y, l23.x, l23.y};
       *reinterpret_cast<f16x4*>(&L.hhi[r][4 * lane]) = h;
       *reinterpret_cast<f16x4*>(&L.hlo[r][4 * lane]) = l;
     }
