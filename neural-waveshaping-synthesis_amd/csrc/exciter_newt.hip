@@ -338,8 +338,8 @@ struct ExcLds {
   // upsampling (shaping.py:69) is ONE packed FMA per parameter: p(n) = fa + w1(n) * fd.  Types: 0 g_idx, 1 b_idx,
   // 2 out_w * g_norm (the 64->1 mixer weight folded in; its bias part  sum_s out_w[s] b_norm[s]  is the per-frame scalar bsum).
   // SoA: 4 consecutive shapers = one ds_read_b128 = two packed-fp32 operands.
-  float fa[2][3][kS];
-  float fd[2][3][kS];
+  float fa[3][3][kS];   // slots: frame pairs (jb-1, jb), (jb, jb+1) [, (jb+1, jb+2) when the workgroup covers two hops]
+  float fd[3][3][kS];
   float bsum[4];
   // K slot c = 16ks + 8half + e: slot 0 is the mixer BIAS (its "sine" is the constant 1), slot c >= 1 is harmonic c
   float shift[kKPad];           // phase shift of slot c (0 for slot 0 and the padding slots 102..111)
@@ -427,8 +427,13 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 //   1: sin() replaced by its argument   2: LUT gather skipped   3: whole FiLM/shaper tail skipped   4: MFMAs skipped
 // second launch-bound = minimum waves per SIMD: without it hipcc hoists all 32 LUT gathers of the tail, takes 256
 // VGPRs and drops the kernel to 1 wave/SIMD (measured 2x slower); 4 waves/SIMD = 128 VGPRs, LDS allows 5 blocks/CU
-template <int MODE, int DBG = 0>
-__global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 5) void exciter_newt_kernel(NwsWeights w, const float* __restrict__ f0,
+// HPB = hops (128-sample tiles) per workgroup = 4 HPB waves.  Two hops share one copy of the 28 KB fragment table and one
+// set of phase shifts: 33 KB of LDS per 8 waves instead of 31.5 KB per 4 -> 6 waves per SIMD instead of 5 (0.322 -> 0.304 ms).
+// The bound of 7 waves/SIMD (72 VGPRs) is deliberate: at 8 (64 VGPRs) hipcc spills 24 B/lane to scratch, which is slower
+// (0.328 ms) AND made this kernel return wrong tiles when instances of it ran on two streams at once (ForwardPipeline; 4 of 6
+// runs) -- keep every kernel of the pipelined path free of scratch.
+template <int MODE, int DBG = 0, int HPB = 1>
+__global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (HPB == 2 ? 7 : 5)) void exciter_newt_kernel(NwsWeights w, const float* __restrict__ f0,
                                                            const float* __restrict__ f0_up,
                                                            const double* __restrict__ carry,
                                                            const float* __restrict__ phase_u,
@@ -445,9 +450,12 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 5) void exciter_newt_
   const int wave = tid >> 6;
   const int half = lane >> 5;
   const int col = lane & 31;
-  const int j = blockIdx.x;  // hop
+  const int jb = blockIdx.x * HPB;        // first hop of the workgroup
+  const int j = jb + (wave >> 2);          // this wave's hop
+  const int w4 = wave & 3;                 // quarter of the hop
   const int b = blockIdx.y;
   const int N = T * NWS_HOP;
+  constexpr int kThreads = 256 * HPB;
 
   // ---- stage the workgroup constants in LDS ----
   if (w.mixer_frags != nullptr) {
@@ -456,39 +464,50 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 5) void exciter_newt_
     // whi and wlo are contiguous; the workgroup barrier below drains the DMA (vmcnt) before anybody reads.
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    // wave w copies pieces 7w .. 7w+6; the instruction's immediate offset (< 4 KB) moves the global and the LDS address
-    // together, so two address set-ups serve seven loads
-    const char* src = static_cast<const char*>(w.mixer_frags) + wave * 7168 + lane * 16;
-    char* dst = reinterpret_cast<char*>(L.whi) + wave * 7168;
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 1024, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 2048, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 3072, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(src + 4096), (lptr_t)(dst + 4096), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(src + 4096), (lptr_t)(dst + 4096), 16, 1024, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)(src + 4096), (lptr_t)(dst + 4096), 16, 2048, 0);
+    // the instruction's immediate offset (< 4 KB) moves the global and the LDS address together: one address set-up serves
+    // four loads.  4 waves: pieces 7w .. 7w+6;  8 waves: pieces 4w .. 4w+3 (w < 7)
+    if (HPB == 1) {
+      const char* src = static_cast<const char*>(w.mixer_frags) + wave * 7168 + lane * 16;
+      char* dst = reinterpret_cast<char*>(L.whi) + wave * 7168;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 1024, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 2048, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 3072, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + 4096), (lptr_t)(dst + 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + 4096), (lptr_t)(dst + 4096), 16, 1024, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + 4096), (lptr_t)(dst + 4096), 16, 2048, 0);
+    } else if (wave < 7) {
+      const char* src = static_cast<const char*>(w.mixer_frags) + wave * 4096 + lane * 16;
+      char* dst = reinterpret_cast<char*>(L.whi) + wave * 4096;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 1024, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 2048, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 3072, 0);
+    }
   } else {
     _Float16* whi = reinterpret_cast<_Float16*>(L.whi);
     _Float16* wlo = reinterpret_cast<_Float16*>(L.wlo);
-    for (int e = tid; e < kS * kKPad; e += 256) {
+    for (int e = tid; e < kS * kKPad; e += kThreads) {
       const int s = e / kKPad, kk = e - s * kKPad;
       const float wv = mixer_slot_weight(w.mixer_w, w.mixer_b, s, kk);
       const int frag = (((kk >> 4) * 2 + (s >> 5)) * 2 + ((kk >> 3) & 1)) * 32 + (s & 31);
       split_f16(wv, whi[frag * 8 + (kk & 7)], wlo[frag * 8 + (kk & 7)]);
     }
   }
-  // waves 0/1: FiLM slot 0/1 (one shaper per lane);  wave 2: bsum[0..1];  wave 3: bsum[2], phase shifts, harmonic numbers
+  // FiLM slots (one shaper per lane), bias sums, phase shifts and harmonic numbers, spread over the waves:
+  //   4 waves: 0/1 slots 0/1, 2 bsum[0..1], 3 bsum[2] + shifts;   8 waves: 0..2 slots, 3..6 bsum[0..3], 7 shifts
+  constexpr int kSlots = HPB + 1;
   if (MODE != kModeExciterOnly) {
     const float* fb = film + (size_t)b * T * NWS_FILM_CH;
     auto frame_of = [&](int q) {
-      const int f = j - 1 + q;
+      const int f = jb - 1 + q;
       return f < 0 ? 0 : (f > T - 1 ? T - 1 : f);
     };
     auto bias_sum = [&](int q) {  // sum_s out_w[s] * b_norm[frame q][s]
       const float v = wave_sum_to_lane63(w.newt_out_w[lane] * fb[(size_t)frame_of(q) * NWS_FILM_CH + 3 * kS + lane]);
       if (lane == 63) L.bsum[q] = v;
     };
-    if (wave < 2) {
+    if (wave < kSlots) {
       const float* r0 = fb + (size_t)frame_of(wave) * NWS_FILM_CH + lane;
       const float* r1 = fb + (size_t)frame_of(wave + 1) * NWS_FILM_CH + lane;
       const float ow = w.newt_out_w[lane];
@@ -500,14 +519,18 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 5) void exciter_newt_
         L.fa[wave][ty][lane] = (MODE == kModeLutPairsDiv6 && ty == 1) ? v0 - w.lut_min : v0;
         L.fd[wave][ty][lane] = v1 - v0;
       }
-    } else if (wave == 2) {
-      bias_sum(0);
-      bias_sum(1);
-    } else {
-      bias_sum(2);
+    } else if (HPB == 1) {
+      if (wave == 2) {
+        bias_sum(0);
+        bias_sum(1);
+      } else {
+        bias_sum(2);
+      }
+    } else if (wave < 7) {
+      bias_sum(wave - 3);
     }
   }
-  if (wave == 3) {
+  if (wave == 4 * HPB - 1) {
     // _create_phase_shift (generators.py:54-56): fl(fl(u * rand_phase) - fl32(pi)) for harmonic c = slot c
     auto shift_of = [&](int c) { return c >= 1 && c <= kK ? phase_u[c - 1] * rand_phase[c - 1] - kPi : 0.0f; };
     L.shift[lane] = shift_of(lane);
@@ -517,10 +540,12 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 5) void exciter_newt_
       L.kf[64 + lane] = (float)(64 + lane);
     }
   }
-  if (MODE == kModeExact) load_shaper_lds(SH, w, tid, 256);
+  if (MODE == kModeExact) load_shaper_lds(SH, w, tid, kThreads);
 
   // ---- per-sample phase: fp64 prefix sum -> fp32 rounding chain of the reference ----
-  const int n = j * kTile + wave * 32 + col;
+  // (a second hop past the end of an odd-length utterance only helped with the staging above)
+  const bool hop_live = HPB == 1 || j < T;
+  const int n = (hop_live ? j : jb) * kTile + w4 * 32 + col;
   const NwsLerp lc = nws_lerp_coeff(n, T);
   float f0n;
   if (f0_up != nullptr) {
@@ -546,6 +571,7 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 5) void exciter_newt_
   const float nyquist = sample_rate * 0.5f;
 
   __syncthreads();
+  if (!hop_live) return;
 
   // ---- 101 harmonics -> 64 shapers on the matrix cores (fp16 two-term split, fp32 accumulate) ----
   // K-step ks covers harmonics 16ks+1 .. 16ks+16; lane (col, half) evaluates the 8 sines of harmonics
@@ -658,7 +684,7 @@ __global__ __launch_bounds__(256, MODE == kModeExact ? 2 : 5) void exciter_newt_
   }
 
   // ---- FiLM -> shaper -> FiLM -> 64->1 mix, all in registers ----
-  const int q0 = lc.i0 - (j - 1);  // 0 or 1: slot of the left frame; fd[q0] is zero where the right frame is clamped
+  const int q0 = lc.i0 - (jb - 1);  // slot of the left frame; fd[q0] is zero where the right frame is clamped
   LutParams LP;
   LutFast LF;
   if (MODE == kModeLutPairsDiv6) LF = make_lut_fast(w);
@@ -946,8 +972,8 @@ int nws_exciter_newt(const NwsWeights* w, const float* f0, const float* f0_up, c
       if (w->lut_size < 2 || !(w->lut_max > w->lut_min)) return NWS_ERR_BAD_ARG;
       const bool pow2 = (w->lut_size & (w->lut_size - 1)) == 0 && w->lut_size <= (1 << 20);
       if (w->lut_pairs != nullptr && w->lut_max - w->lut_min == 6.0f && pow2)
-        exciter_newt_kernel<kModeLutPairsDiv6><<<grid, 256, base, st>>>(*w, f0, f0_up, carry, phase_u, rand_phase,
-                                                                        film, T, sample_rate, exciter_out, newt_out);
+        exciter_newt_kernel<kModeLutPairsDiv6, 0, 2><<<dim3((T + 1) / 2, B), 512, base, st>>>(
+            *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out);
       else if (w->lut_pairs != nullptr)
         exciter_newt_kernel<kModeLutPairs><<<grid, 256, base, st>>>(*w, f0, f0_up, carry, phase_u, rand_phase, film,
                                                                     T, sample_rate, exciter_out, newt_out);

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void fir_noise_kernel(const float* __restrict_
 //  * D rows are utterances, columns samples: each accumulator register stores 2 x 128 B contiguous segments.
 constexpr int kUtt = 32;
 constexpr int kCopyHalfs = 272;
-constexpr int kRowHalfs = 264;
+constexpr int kRowHalfs = 136;       // half a tap row (128 taps) + pad: 272 B stride, conflict-free ds_read_b128
 constexpr float kNoiseScale = 1024.0f;  // noise (U[0,1) in the reference; anything within +-32 is fine) times 2^10
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -142,8 +142,8 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 struct NoiseMfmaLds {
   _Float16 rhi[2][8][kCopyHalfs];  // [frame t | frame t-1 advanced by 128][shift c][v] = R[(v + c) & 255]
   _Float16 rlo[2][8][kCopyHalfs];
-  _Float16 hhi[kUtt][kRowHalfs];   // taps of the frame being accumulated, times the utterance's power-of-two scale
-  _Float16 hlo[kUtt][kRowHalfs];
+  _Float16 hhi[kUtt][kRowHalfs];   // HALF the taps (128) of the frame being accumulated, times the utterance's scale:
+  _Float16 hlo[kUtt][kRowHalfs];   // staging half rows keeps the block at 36 KB of LDS = 4 workgroups per CU
   float unscale[kUtt];             // 1 / (tap scale * noise scale) per utterance
   float win[3 * kHop];             // padded noise [128 (t-1), 128 (t-1) + 384), times the noise scale: frames t-1 and t
 };
@@ -175,7 +175,7 @@ __device__ __forceinline__ float wave_max_to_lane63(float v) {
   return v;
 }
 
-__global__ __launch_bounds__(256, 3) void fir_noise_mfma_kernel(const float* __restrict__ fir, const float* __restrict__ noise,
+__global__ __launch_bounds__(256, 4) void fir_noise_mfma_kernel(const float* __restrict__ fir, const float* __restrict__ noise,
                                                                 const float* __restrict__ add_in, int B, int T, int len,
                                                                 int origin, float* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) NoiseMfmaLds L;
@@ -240,7 +240,8 @@ __global__ __launch_bounds__(256, 3) void fir_noise_mfma_kernel(const float* __r
     *reinterpret_cast<f16x8*>(&L.rhi[fr][c][v0]) = h8;
     *reinterpret_cast<f16x8*>(&L.rlo[fr][c][v0]) = l8;
   }
-  auto stage_rows = [&](const float4 (&v)[8]) {
+  auto stage_rows = [&](const float4 (&v)[8], const int khalf) {  // taps [128 khalf, 128 khalf + 128): lanes 32 khalf .. +31
+    if ((lane >> 5) != khalf) return;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int r = wave + 4 * it;
@@ -248,24 +249,24 @@ __global__ __launch_bounds__(256, 3) void fir_noise_mfma_kernel(const float* __r
       split16x2(v[it].x * scale[it], v[it].y * scale[it], h01, l01);
       split16x2(v[it].z * scale[it], v[it].w * scale[it], h23, l23);
       const f16x4 h = {h01.x, h01.y, h23.x, h23.y}, l = {l01.x, l01.y, l23.x, l23.y};
-      *reinterpret_cast<f16x4*>(&L.hhi[r][4 * lane]) = h;
-      *reinterpret_cast<f16x4*>(&L.hlo[r][4 * lane]) = l;
+      *reinterpret_cast<f16x4*>(&L.hhi[r][4 * (lane & 31)]) = h;
+      *reinterpret_cast<f16x4*>(&L.hlo[r][4 * (lane & 31)]) = l;
     }
   };
-  stage_rows(cur);
+  stage_rows(cur, 0);
   __syncthreads();
 
   f32x16 acc;
   const int j = 32 * wave + col;  // output sample inside the hop
   const int c = (-j) & 7;
-  auto accumulate = [&](const int fr, auto first_tag) {
+  auto accumulate = [&](const int fr, const int khalf, auto first_tag) {
     constexpr bool kFirst = decltype(first_tag)::value;
     const _Float16* rh = &L.rhi[fr][c][0];
     const _Float16* rl = &L.rlo[fr][c][0];
 #pragma unroll 4
-    for (int ks = 0; ks < kL / 16; ++ks) {
-      const int k = 16 * ks + 8 * kh;
-      const int s8 = ((k - j) & 255) & ~7;
+    for (int ks = 0; ks < kL / 32; ++ks) {
+      const int k = 16 * ks + 8 * kh;                       // tap inside the staged half
+      const int s8 = ((kL / 2 * khalf + k - j) & 255) & ~7;
       const f16x8 ahi = *reinterpret_cast<const f16x8*>(&L.hhi[col][k]);
       const f16x8 alo = *reinterpret_cast<const f16x8*>(&L.hlo[col][k]);
       const f16x8 bhi = *reinterpret_cast<const f16x8*>(&rh[s8]);
@@ -276,11 +277,19 @@ __global__ __launch_bounds__(256, 3) void fir_noise_mfma_kernel(const float* __r
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc, 0, 0, 0);
     }
   };
-  accumulate(0, std::true_type{});
+  accumulate(0, 0, std::true_type{});
   __syncthreads();
-  stage_rows(prv);
+  stage_rows(cur, 1);
   __syncthreads();
-  accumulate(1, std::false_type{});
+  accumulate(0, 1, std::false_type{});
+  __syncthreads();
+  stage_rows(prv, 0);
+  __syncthreads();
+  accumulate(1, 0, std::false_type{});
+  __syncthreads();
+  stage_rows(prv, 1);
+  __syncthreads();
+  accumulate(1, 1, std::false_type{});
 
   const float ola = t == 0 ? 1.0f : 0.5f;  // overlap-add count: 1 in the first hop, else 2
 #pragma unroll
