@@ -14,7 +14,7 @@ OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libnws_hip.so")
 SOURCES = ["exciter_newt.hip", "control_gru.hip", "frame_mlps.hip", "fir_noise.hip", "reverb_fft.hip", "forward.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=default",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage"]
 
 
 def _hipcc():
@@ -49,8 +49,26 @@ def build(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
-        if verbose and r.stderr.strip():
-            print(r.stderr, file=sys.stderr)
+        # No kernel may use scratch: a 24 B/lane spill made the fused kernel return wrong tiles when two instances ran on
+        # different streams (ForwardPipeline), besides being slower.  The resource remarks make that a build error.
+        name, spilled, rest, skip = None, [], [], 0
+        for line in r.stderr.splitlines():
+            if skip and (line.lstrip().startswith("|") or line.lstrip().split(" ")[0].isdigit()):
+                skip -= 1          # source line + caret that clang prints under every remark
+                continue
+            skip = 0
+            if "remark:" in line:
+                skip = 2
+                if "Function Name:" in line:
+                    name = line.split("Function Name:")[1].split("[-Rpass")[0].strip()
+                elif "ScratchSize [bytes/lane]:" in line and int(line.split("ScratchSize [bytes/lane]:")[1].split()[0]) != 0:
+                    spilled.append(name)
+            else:
+                rest.append(line)
+        if spilled:
+            raise RuntimeError(f"{src}: kernels using scratch memory (spills or stack): {spilled}")
+        if verbose and "\n".join(rest).strip():
+            print("\n".join(rest), file=sys.stderr)
         return obj
 
     with cf.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:

@@ -109,10 +109,6 @@ __device__ __forceinline__ float nws_sin_turns(float x) {  // caller guarantees 
   return __builtin_amdgcn_sinf(t);
 }
 
-__device__ __forceinline__ float nws_sin_turns_checked(float x) {
-  return __builtin_expect(fabsf(x) > 6.0e6f, 0) ? nws_sinf_huge(x) : nws_sin_turns(x);
-}
-
 // Any-magnitude sine without a function call (the oscillator's wave-uniform wide-argument path: phases beyond ~6e6 rad,
 // i.e. minutes of audio or very high F0): the same exact-product reduction to turns carried out in fp64 with a two-term
 // 1/(2 pi) (106 bits), then v_sin_f32.  ~1e-7 absolute up to |x| ~ 1e25; inf/NaN give NaN like sinf.
@@ -125,10 +121,12 @@ __device__ __forceinline__ float nws_sin_wide(float x) {
   return __builtin_amdgcn_sinf((float)t);
 }
 
-__device__ __forceinline__ float nws_sinf_fast(float x) {
-  if (__builtin_expect(fabsf(x) > 6.0e6f, 0)) return nws_sinf_huge(x);
-  return nws_sin_turns(x);
+__device__ __forceinline__ float nws_sin_turns_checked(float x) {
+  return __builtin_expect(fabsf(x) > 6.0e6f, 0) ? nws_sin_wide(x) : nws_sin_turns(x);
 }
+
+// no device function call on any path: a call inside the fused kernel costs ~30 VGPRs of ABI clobbers and a scratch frame
+__device__ __forceinline__ float nws_sinf_fast(float x) { return nws_sin_turns_checked(x); }
 
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
