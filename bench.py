@@ -284,11 +284,12 @@ def main():
             tr = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
             if tr["batch_per_gpu"] == B and tr["frames"] == T and not a.exact:
                 traffic = tr["hbm_bytes_per_launch"]
-                if tr.get("valu_active_quad_cycles_per_wave") and tr.get("gui_active_cycles"):
-                    # VALU-busy share of the kernel: (waves x VALU-active cycles per wave) / (SIMDs x kernel cycles)
-                    busy = tr["waves"] * tr["valu_active_quad_cycles_per_wave"] * 4.0 / (1024.0 * tr["gui_active_cycles"])
-                    valu_issue = {"insts_per_wave": tr["valu_insts_per_wave"], "trans_per_wave": tr["trans_insts_per_wave"],
-                                  "busy_frac_of_kernel_cycles": round(busy, 3), "source": "rocprofv3 --pmc, one stream"}
+                if tr.get("valu_busy_frac"):
+                    # VALU-busy share of the kernel: (waves x VALU-active cycles per wave) / (1024 SIMDs x kernel cycles)
+                    valu_issue = {"insts_per_wave": round(tr["valu_insts_per_wave"], 1),
+                                  "trans_per_wave": round(tr["trans_insts_per_wave"], 1),
+                                  "busy_frac_of_kernel_cycles": round(tr["valu_busy_frac"], 3),
+                                  "source": "rocprofv3 --pmc, one stream (profiles/r01/pmc_traffic.json)"}
         except Exception:
             pass
         mfma_exec = MFMA_F16_FLOP_PER_SAMPLE_EXECUTED * B * N / (k_ms * 1e-3) / 1e12

@@ -66,6 +66,21 @@ def main(root):
             "wave_quad_cycles_per_wave": ex.get("SQ_WAVE_CYCLES", 0) / w,
             "gui_active_cycles": ex.get("GRBM_GUI_ACTIVE"),
         }
+        # VALU-busy share of the kernel: VALU-active cycles summed over waves / (1024 SIMDs x kernel cycles).  Kernel cycles
+        # from GRBM_GUI_ACTIVE; rocprofv3 reports it summed over the 8 XCDs in some passes: normalise with the trace's duration.
+        ns = None
+        for path in glob.glob(os.path.join(root, "trace_1stream", "**", "*kernel_stats.csv"), recursive=True):
+            for r in csv.DictReader(open(path)):
+                if "exciter_newt_kernel" in r["Name"]:
+                    ns = float(r["AverageNs"])
+        gui = ex.get("GRBM_GUI_ACTIVE")
+        if ns and gui:
+            if gui / ns > 4.0:          # > 4 GHz: the counter is a sum over XCDs
+                gui /= 8.0
+            traffic["kernel_avg_ns_one_stream"] = ns
+            traffic["kernel_cycles"] = gui
+            traffic["clock_ghz_during_pass"] = gui / ns
+            traffic["valu_busy_frac"] = w * traffic["valu_active_quad_cycles_per_wave"] * 4.0 / (1024.0 * gui)
         json.dump(traffic, open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)
     for tag in ("default", "1stream"):
         for path in glob.glob(os.path.join(root, "trace_" + tag, "**", "*kernel_stats.csv"), recursive=True):
