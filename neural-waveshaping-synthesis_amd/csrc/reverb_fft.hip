@@ -164,18 +164,31 @@ __global__ __launch_bounds__(256) void col125_fwd_kernel(PlanDev d, const float2
   if (tid < 125) tw125[tid] = tw125_g[tid];
   const float* x0 = 2 * p < B ? x + (size_t)(2 * p) * x_stride : nullptr;
   const float* x1 = 2 * p + 1 < B ? x + (size_t)(2 * p + 1) * x_stride : nullptr;
-  for (int e = tid; e < 125 * 32; e += 256) {
-    const long long n = (long long)d.N2 * (e >> 5) + c0 + (e & 31);
-    const bool in = n < N;
-    bufA[e] = make_float2((in && x0) ? x0[n] : 0.0f, (in && x1) ? x1[n] : 0.0f);
+  // 16 rows per thread, all loads issued before the first LDS write (memory-latency bound: bytes in flight are what counts)
+  {
+    float2 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + 256 * i;
+      const long long n = (long long)d.N2 * (e >> 5) + c0 + (e & 31);
+      const bool in = e < 125 * 32 && n < N;
+      v[i] = make_float2((in && x0) ? x0[n] : 0.0f, (in && x1) ? x1[n] : 0.0f);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (tid + 256 * i < 125 * 32) bufA[tid + 256 * i] = v[i];
   }
   __syncthreads();
   fft125_tile<false>(bufA, bufB, tw125, tid);
-  for (int e = tid; e < 125 * 32; e += 256) {
-    const size_t o = ((size_t)p * 125 + (e >> 5)) * d.N2 + c0 + (e & 31);
-    const float2 v = bufB[e];
-    Ure[o] = v.x;
-    Uim[o] = v.y;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int e = tid + 256 * i;
+    if (e < 125 * 32) {
+      const size_t o = ((size_t)p * 125 + (e >> 5)) * d.N2 + c0 + (e & 31);
+      const float2 v = bufB[e];
+      Ure[o] = v.x;
+      Uim[o] = v.y;
+    }
   }
 }
 
@@ -191,21 +204,42 @@ __global__ __launch_bounds__(256) void col125_inv_kernel(PlanDev d, const float2
   const int p = blockIdx.y;
   const int c0 = blockIdx.x * 32;
   if (tid < 125) tw125[tid] = tw125_g[tid];
-  for (int e = tid; e < 125 * 32; e += 256) {
-    const size_t o = ((size_t)p * 125 + (e >> 5)) * d.N2 + c0 + (e & 31);
-    bufA[e] = make_float2(Ure[o], Uim[o]);
+  {
+    float2 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + 256 * i;
+      const size_t o = ((size_t)p * 125 + (e >> 5)) * d.N2 + c0 + (e & 31);
+      v[i] = e < 125 * 32 ? make_float2(Ure[o], Uim[o]) : make_float2(0.0f, 0.0f);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (tid + 256 * i < 125 * 32) bufA[tid + 256 * i] = v[i];
+  }
+  const int rows_out = (N + d.N2 - 1) / d.N2;
+  const bool has1 = 2 * p + 1 < B;
+  // the dry signal is independent of the transform: fetch it before the FFT so that its latency hides under it
+  float dry0[16], dry1[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int e = tid + 256 * i;
+    const long long n = (long long)d.N2 * (e >> 5) + c0 + (e & 31);
+    const bool in = x != nullptr && e < rows_out * 32 && n < N;
+    const size_t o0 = (size_t)(2 * p) * N + n;
+    dry0[i] = in ? x[o0] : 0.0f;
+    dry1[i] = (in && has1) ? x[o0 + N] : 0.0f;
   }
   __syncthreads();
   fft125_tile<true>(bufA, bufB, tw125, tid);
-  const int rows_out = (N + d.N2 - 1) / d.N2;
-  const bool has1 = 2 * p + 1 < B;
-  for (int e = tid; e < rows_out * 32; e += 256) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int e = tid + 256 * i;
     const long long n = (long long)d.N2 * (e >> 5) + c0 + (e & 31);
-    if (n < N) {
+    if (e < rows_out * 32 && n < N) {
       const float2 v = bufB[e];
       const size_t o0 = (size_t)(2 * p) * N + n;
-      y[o0] = (x != nullptr ? x[o0] : 0.0f) + v.x;
-      if (has1) y[o0 + N] = (x != nullptr ? x[o0 + N] : 0.0f) + v.y;
+      y[o0] = dry0[i] + v.x;
+      if (has1) y[o0 + N] = dry1[i] + v.y;
     }
   }
 }
