@@ -325,12 +325,43 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
 }
 
+// Stockham autosort FFT of one row in LDS.  Two radix-2 stages (p and 2p) are fused into one radix-4 stage: the same
+// butterflies and twiddles, half the LDS round trips and workgroup barriers (N2 = 512: 4 radix-4 + 1 radix-2 stage
+// instead of 9).  rowtw[m] = exp(-2 pi i m / N2), m < N2/2.
 template <bool INVERSE>
 __device__ __forceinline__ float2* stockham(float2* x, float2* y, const float2* __restrict__ rowtw, int N2, int tid,
                                             int nthreads) {
-  const int t = N2 >> 1;
-  for (int p = 1; p < N2; p <<= 1) {
-    const int tw_step = t / p;  // N2 / (2p)
+  const int t = N2 >> 1, q = N2 >> 2;
+  int p = 1;
+  for (; 4 * p <= N2; p <<= 2) {
+    const int step1 = t / p, step2 = q / p;  // N2/(2p), N2/(4p)
+    for (int i = tid; i < q; i += nthreads) {
+      const int k = i & (p - 1);
+      const int base = ((i - k) << 2) + k;
+      float2 w = rowtw[k * step1], w2 = rowtw[k * step2];
+      if (INVERSE) {
+        w.y = -w.y;
+        w2.y = -w2.y;
+      }
+      const float2 a = x[i], bq = x[i + q];
+      const float2 c = cmul(w, x[i + t]), dq = cmul(w, x[i + t + q]);
+      const float2 a0 = make_float2(a.x + c.x, a.y + c.y), a1 = make_float2(a.x - c.x, a.y - c.y);
+      const float2 b0 = cmul(w2, make_float2(bq.x + dq.x, bq.y + dq.y));
+      const float2 b1r = cmul(w2, make_float2(bq.x - dq.x, bq.y - dq.y));
+      // times -i (forward) / +i (inverse)
+      const float2 b1 = INVERSE ? make_float2(-b1r.y, b1r.x) : make_float2(b1r.y, -b1r.x);
+      y[base] = make_float2(a0.x + b0.x, a0.y + b0.y);
+      y[base + 2 * p] = make_float2(a0.x - b0.x, a0.y - b0.y);
+      y[base + p] = make_float2(a1.x + b1.x, a1.y + b1.y);
+      y[base + 3 * p] = make_float2(a1.x - b1.x, a1.y - b1.y);
+    }
+    __syncthreads();
+    float2* tmp = x;
+    x = y;
+    y = tmp;
+  }
+  for (; p < N2; p <<= 1) {  // one radix-2 stage left when log2(N2) is odd
+    const int tw_step = t / p;
     for (int i = tid; i < t; i += nthreads) {
       const int k = i & (p - 1);
       const int j = ((i - k) << 1) + k;
@@ -363,11 +394,22 @@ __global__ __launch_bounds__(256) void row_kernel(PlanDev d, float* __restrict__
   const int p = blockIdx.y;
   const size_t base = ((size_t)p * d.N1 + k1) * d.N2;
   const size_t hbase = (size_t)k1 * d.N2;
-  for (int i = tid; i < d.N2 / 2; i += 256) rowtw[i] = rowtw_g[i];
-  for (int i = tid; i < d.N2; i += 256) {
-    const float2 z = make_float2(Ure[base + i], Uim[base + i]);
-    buf0[i] = cmul(z, tw[hbase + i]);
+  // everything this row needs from memory is requested up front (N2 <= 1024: at most 4 elements per thread): the IR
+  // spectrum is only used between the two transforms, its latency hides under the forward one
+  constexpr int kMaxPer = 4;
+  float2 z[kMaxPer], t4[kMaxPer], h4[kMaxPer];
+#pragma unroll
+  for (int e = 0; e < kMaxPer; ++e) {
+    const int i = tid + 256 * e;
+    const bool in = i < d.N2;
+    z[e] = in ? make_float2(Ure[base + i], Uim[base + i]) : make_float2(0.0f, 0.0f);
+    t4[e] = in ? tw[hbase + i] : make_float2(0.0f, 0.0f);
+    h4[e] = (!SPECTRUM_ONLY && in) ? make_float2(Hre[hbase + i], Him[hbase + i]) : make_float2(0.0f, 0.0f);
   }
+  for (int i = tid; i < d.N2 / 2; i += 256) rowtw[i] = rowtw_g[i];
+#pragma unroll
+  for (int e = 0; e < kMaxPer; ++e)
+    if (tid + 256 * e < d.N2) buf0[tid + 256 * e] = cmul(z[e], t4[e]);
   __syncthreads();
   float2* cur = stockham<false>(buf0, buf1, rowtw, d.N2, tid, 256);
   if (SPECTRUM_ONLY) {
@@ -378,16 +420,21 @@ __global__ __launch_bounds__(256) void row_kernel(PlanDev d, float* __restrict__
     return;
   }
   float2* other = cur == buf0 ? buf1 : buf0;
-  for (int i = tid; i < d.N2; i += 256) cur[i] = cmul(cur[i], make_float2(Hre[hbase + i], Him[hbase + i]));
+#pragma unroll
+  for (int e = 0; e < kMaxPer; ++e)
+    if (tid + 256 * e < d.N2) cur[tid + 256 * e] = cmul(cur[tid + 256 * e], h4[e]);
   __syncthreads();
   cur = stockham<true>(cur, other, rowtw, d.N2, tid, 256);
   const float inv_l = 1.0f / (float)d.L;
-  for (int i = tid; i < d.N2; i += 256) {
-    float2 t = tw[hbase + i];
-    t.y = -t.y;
-    const float2 z = cmul(cur[i], t);
-    Ure[base + i] = z.x * inv_l;
-    Uim[base + i] = z.y * inv_l;
+#pragma unroll
+  for (int e = 0; e < kMaxPer; ++e) {
+    const int i = tid + 256 * e;
+    if (i < d.N2) {
+      const float2 tc = make_float2(t4[e].x, -t4[e].y);
+      const float2 r = cmul(cur[i], tc);
+      Ure[base + i] = r.x * inv_l;
+      Uim[base + i] = r.y * inv_l;
+    }
   }
 }
 
