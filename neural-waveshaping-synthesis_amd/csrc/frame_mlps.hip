@@ -252,23 +252,29 @@ __host__ __device__ constexpr FragMap frag_map(int id) {
 constexpr int kFragTotal = 51200;  // x 16 B = 819200 B
 
 struct MlpLds16 {
-  char emb[2][kXtBytes];  // [hi|lo]
-  char p0[2][kXtBytes];
-  char p1[2][kXtBytes];
-  float stage[4][kFT * kXS];
-  float red[2][4][kFT];
+  char xt[4][2][kXtBytes];     // four activation buffers E, X, Y, Z, each [hi|lo]; dead ones double as store patches
+  float red[2][2][4][kFT];     // [path][mean | M2][wave][frame]
+  float gb[4][NWS_HIDDEN];     // LayerNorm gain / offset of the layer pair in flight: [g_a | beta_a | g_b | beta_b]
 };
 
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// (hi, lo) fp16 split of two values: v_cvt_pk_f16_f32 for hi, one v_fma_mix{lo,hi}_f16 per lo (exact residual rounded once)
+__device__ __forceinline__ void split2(float a, float b, f16x2& hi, f16x2& lo) {
+  hi = __builtin_convertvector(f32x2{a, b}, f16x2);
+  const unsigned hp = __builtin_bit_cast(unsigned, hi);
+  unsigned lp;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lp) : "v"(hp), "v"(a));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lp) : "v"(hp), "v"(b));
+  lo = __builtin_bit_cast(f16x2, lp);
+}
+
 __device__ __forceinline__ void split4_store(char* xt_hi, char* xt_lo, int frame, int ch, float a, float b, float c, float d) {
-  f16x4 h, l;
-  const float v[4] = {a, b, c, d};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    h[i] = (_Float16)v[i];
-    l[i] = (_Float16)(v[i] - (float)h[i]);
-  }
-  *reinterpret_cast<f16x4*>(xt_hi + frame * kRowB + ch * 2) = h;
-  *reinterpret_cast<f16x4*>(xt_lo + frame * kRowB + ch * 2) = l;
+  f16x2 h01, l01, h23, l23;
+  split2(a, b, h01, l01);
+  split2(c, d, h23, l23);
+  *reinterpret_cast<f16x4*>(xt_hi + frame * kRowB + ch * 2) = f16x4{h01.x, h01.y, h23.x, h23.y};
+  *reinterpret_cast<f16x4*>(xt_lo + frame * kRowB + ch * 2) = f16x4{l01.x, l01.y, l23.x, l23.y};
 }
 
 // weight fragments of one M-tile in registers (KS K-steps x (hi, lo) x 8 halfs)
@@ -287,82 +293,182 @@ __device__ __forceinline__ void load_frags(AFrag<KS>& A, const f16x8* __restrict
   }
 }
 
-// acc(32 rows x 32 frames) = A * X  for the XT buffer (hi, lo):  W_hi X_hi + (W_hi X_lo + W_lo X_hi)
+// acc(32 rows x 32 frames) = A * X  for the XT buffer `xt` ([hi|lo]):  W_hi X_hi + (W_hi X_lo + W_lo X_hi)
 template <int KS>
-__device__ __forceinline__ void mma_tile(const AFrag<KS>& A, const char* xt_hi, const char* xt_lo, int lane, f32x16& acc) {
+__device__ __forceinline__ void mma_tile(const AFrag<KS>& A, const char* xt, int lane, f32x16& acc) {
   const int half = lane >> 5, col = lane & 31;
   f32x16 cross;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    acc[r] = 0.0f;
-    cross[r] = 0.0f;
-  }
-  const char* bh = xt_hi + col * kRowB + half * 16;
-  const char* bl = xt_lo + col * kRowB + half * 16;
+  const char* bh = xt + col * kRowB + half * 16;
+  const char* bl = bh + kXtBytes;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     const f16x8 xh = *reinterpret_cast<const f16x8*>(bh + ks * 32);
     const f16x8 xl = *reinterpret_cast<const f16x8*>(bl + ks * 32);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.hi[ks], xh, acc, 0, 0, 0);
-    cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.hi[ks], xl, cross, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.hi[ks], xh, ks == 0 ? f32x16{} : acc, 0, 0, 0);
+    cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.hi[ks], xl, ks == 0 ? f32x16{} : cross, 0, 0, 0);
     cross = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.lo[ks], xh, cross, 0, 0, 0);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] += cross[r];
 }
 
+// two independent tiles at once (different weights, same or different inputs): four accumulator chains interleaved, so no
+// MFMA waits on its predecessor
+template <int KS>
+__device__ __forceinline__ void mma_tile2(const AFrag<KS>& A, const char* xa, f32x16& acc_a, const AFrag<KS>& B,
+                                          const char* xb, f32x16& acc_b, int lane) {
+  const int half = lane >> 5, col = lane & 31;
+  f32x16 cross_a, cross_b;
+  const char* ah = xa + col * kRowB + half * 16;
+  const char* al = ah + kXtBytes;
+  const char* bh = xb + col * kRowB + half * 16;
+  const char* bl = bh + kXtBytes;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const f16x8 ph = *reinterpret_cast<const f16x8*>(ah + ks * 32);
+    const f16x8 pl = *reinterpret_cast<const f16x8*>(al + ks * 32);
+    const f16x8 qh = *reinterpret_cast<const f16x8*>(bh + ks * 32);
+    const f16x8 ql = *reinterpret_cast<const f16x8*>(bl + ks * 32);
+    acc_a = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.hi[ks], ph, ks == 0 ? f32x16{} : acc_a, 0, 0, 0);
+    acc_b = __builtin_amdgcn_mfma_f32_32x32x16_f16(B.hi[ks], qh, ks == 0 ? f32x16{} : acc_b, 0, 0, 0);
+    cross_a = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.hi[ks], pl, ks == 0 ? f32x16{} : cross_a, 0, 0, 0);
+    cross_b = __builtin_amdgcn_mfma_f32_32x32x16_f16(B.hi[ks], ql, ks == 0 ? f32x16{} : cross_b, 0, 0, 0);
+    cross_a = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.lo[ks], ph, cross_a, 0, 0, 0);
+    cross_b = __builtin_amdgcn_mfma_f32_32x32x16_f16(B.lo[ks], qh, cross_b, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    acc_a[r] += cross_a[r];
+    acc_b[r] += cross_b[r];
+  }
+}
+
 // write a 32-channel x 32-frame tile held in the D layout into an XT buffer (4 consecutive channels per store)
-__device__ __forceinline__ void store_tile_xt(char* xt_hi, char* xt_lo, int c0, const float v[16], int lane) {
+__device__ __forceinline__ void store_tile_xt(char* xt, int c0, const float v[16], int lane) {
   const int half = lane >> 5, col = lane & 31;
 #pragma unroll
   for (int g = 0; g < 4; ++g)
-    split4_store(xt_hi, xt_lo, col, c0 + 8 * g + 4 * half, v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+    split4_store(xt, xt + kXtBytes, col, c0 + 8 * g + 4 * half, v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
 }
 
-// bias + LayerNorm(channels) + LeakyReLU on the accumulator tile of wave `wave`, result -> XT buffer `out`
-__device__ __forceinline__ void ln_epilogue(MlpLds16& L, const f32x16& acc, const float* bias, const float* ln_g,
-                                            const float* ln_b, char* out_hi, char* out_lo, int wave, int lane) {
-  const int half = lane >> 5, col = lane & 31;
-  float v[16];
+// the 16 per-lane entries (channels 32 wave + frag_row(r, half)) of a per-channel parameter vector
+__device__ __forceinline__ void load_lane_params(float (&p)[16], const float* __restrict__ vec, int wave, int lane) {
+  const int half = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) p[r] = vec[32 * wave + frag_row(r, half)];
+}
+
+// per-wave LayerNorm partials over its 32 channels of frame `col`: mean_w and M2_w = sum (v - mean_w)^2, both exact to
+// fp32 rounding whatever the offset of the data (no E[x^2] - mean^2 cancellation)
+__device__ __forceinline__ void ln_partials(const float (&v)[16], float& mean_w, float& m2_w) {
   float s = 0.0f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    v[r] = acc[r] + bias[32 * wave + frag_row(r, half)];
-    s += v[r];
-  }
+  for (int r = 0; r < 16; ++r) s += v[r];
   s += nws_swap_halves(s);
-  if (half == 0) L.red[0][wave][col] = s;
-  __syncthreads();
-  const float mean = ((L.red[0][0][col] + L.red[0][1][col]) + (L.red[0][2][col] + L.red[0][3][col])) * (1.0f / NWS_HIDDEN);
+  mean_w = s * (1.0f / 32.0f);
   float q = 0.0f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const float d = v[r] - mean;
+    const float d = v[r] - mean_w;
     q = fmaf(d, d, q);
   }
-  q += nws_swap_halves(q);
-  if (half == 0) L.red[1][wave][col] = q;
-  __syncthreads();
-  const float var = ((L.red[1][0][col] + L.red[1][1][col]) + (L.red[1][2][col] + L.red[1][3][col])) * (1.0f / NWS_HIDDEN);
-  const float rstd = 1.0f / sqrtf(var + kLnEps);
+  m2_w = q + nws_swap_halves(q);
+}
+
+// the four waves' partials -> mean and 1/std of the 128 channels (Chan's merge: M2 = sum M2_w + 32 sum (mean_w - mean)^2)
+__device__ __forceinline__ void ln_merge(const float (*red)[4][kFT], int col, float& mean, float& rstd) {
+  const float m0 = red[0][0][col], m1 = red[0][1][col], m2 = red[0][2][col], m3 = red[0][3][col];
+  mean = ((m0 + m1) + (m2 + m3)) * 0.25f;
+  const float d0 = m0 - mean, d1 = m1 - mean, d2 = m2 - mean, d3 = m3 - mean;
+  const float between = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  const float within = (red[1][0][col] + red[1][1][col]) + (red[1][2][col] + red[1][3][col]);
+  const float var = fmaf(32.0f, between, within) * (1.0f / NWS_HIDDEN);
+  rstd = 1.0f / sqrtf(var + kLnEps);
+}
+
+// gain / offset of the lane's 16 channels from LDS (4 consecutive channels per ds_read_b128)
+__device__ __forceinline__ void ln_finish(float (&v)[16], float mean, float rstd, const float* g, const float* bt, int wave,
+                                          int lane) {
+  const int half = lane >> 5;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = 32 * wave + 8 * q + 4 * half;
+    const float4 g4 = *reinterpret_cast<const float4*>(g + c), b4 = *reinterpret_cast<const float4*>(bt + c);
+    const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float y = (v[4 * q + i] - mean) * rstd * gg[i] + bb[i];
+      v[4 * q + i] = fmaxf(y, 0.01f * y);  // LeakyReLU(0.01)
+    }
+  }
+}
+
+// One hidden-layer PAIR (newt.mlp layer l | h_generator layer l).  The order of the global loads is the point: VMEM loads
+// return in order, so a parameter load issued behind the next layer's 32 fragment loads would make the whole epilogue wait
+// for those.  Biases are therefore requested before the MFMAs (they arrive under them); the gains / offsets (2 values per
+// thread) right after the MFMAs, on their way to LDS; and only then the next pair's fragments, whose registers became free
+// when the MFMAs were issued: the fragments stream in under the statistics exchange, the normalisation and the barriers.
+template <int FA_NEXT, int FB_NEXT>
+__device__ __forceinline__ void hidden_pair(MlpLds16& L, const f16x8* __restrict__ F, AFrag<8>& A0, AFrag<8>& A1,
+                                            const char* in_a, const char* in_b, char* out_a, char* out_b,
+                                            const float* bias_a, const float* g_a, const float* bt_a, const float* bias_b,
+                                            const float* g_b, const float* bt_b, int mt_next_a, int mt_next_b, int wave,
+                                            int lane) {
+  const int half = lane >> 5, col = lane & 31;
+  const int tid = 64 * wave + lane;
+  float va[16], vb[16];
+  load_lane_params(va, bias_a, wave, lane);
+  load_lane_params(vb, bias_b, wave, lane);
+  f32x16 acc_a, acc_b;
+  mma_tile2<8>(A0, in_a, acc_a, A1, in_b, acc_b, lane);
+  // thread t fetches gb[t >> 7][t & 127] and gb[2 + (t >> 7)][t & 127]
+  const float p0 = ((tid >> 7) == 0 ? g_a : bt_a)[tid & 127];
+  const float p1 = ((tid >> 7) == 0 ? g_b : bt_b)[tid & 127];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int c = 32 * wave + frag_row(r, half);
-    v[r] = nws_leaky_relu((v[r] - mean) * rstd * ln_g[c] + ln_b[c]);
+    va[r] += acc_a[r];
+    vb[r] += acc_b[r];
   }
-  store_tile_xt(out_hi, out_lo, 32 * wave, v, lane);
+  load_frags<8>(A0, F + frag_map(FA_NEXT).base, mt_next_a, lane);
+  load_frags<8>(A1, F + frag_map(FB_NEXT).base, mt_next_b, lane);
+  L.gb[tid >> 7][tid & 127] = p0;
+  L.gb[2 + (tid >> 7)][tid & 127] = p1;
+  float mw_a, m2_a, mw_b, m2_b;
+  ln_partials(va, mw_a, m2_a);
+  ln_partials(vb, mw_b, m2_b);
+  if (half == 0) {
+    L.red[0][0][wave][col] = mw_a;
+    L.red[0][1][wave][col] = m2_a;
+    L.red[1][0][wave][col] = mw_b;
+    L.red[1][1][wave][col] = m2_b;
+  }
+  __syncthreads();
+  float mean, rstd;
+  ln_merge(L.red[0], col, mean, rstd);
+  ln_finish(va, mean, rstd, L.gb[0], L.gb[1], wave, lane);
+  store_tile_xt(out_a, 32 * wave, va, lane);
+  ln_merge(L.red[1], col, mean, rstd);
+  ln_finish(vb, mean, rstd, L.gb[2], L.gb[3], wave, lane);
+  store_tile_xt(out_b, 32 * wave, vb, lane);
   __syncthreads();
 }
 
-// The layer sequence is static, so the weight fragments are software-pipelined by hand: while layer l's epilogue
-// (LayerNorm: two workgroup barriers and an LDS exchange) runs, layer l+1's 16 KB of fragments are already in flight
-// from L2 into the other register set (A0 / A1 alternate; a barrier is a memory fence to hipcc, so loads written
-// after it would only be issued once every wave has arrived).
+// newt.mlp and h_generator are independent after the embedding: their layers are issued as PAIRS.  Each wave runs four
+// accumulator chains per layer pair, the LayerNorm statistics of both paths travel in one exchange, and the weight
+// fragments of the next pair are requested as soon as the current pair's MFMAs have been issued (their registers are
+// free from then on), so they arrive under the epilogue.  Buffers: E (embedding, later hgen L2), X, Y, Z.
+//   proj: X(gru) -> E          L1: E -> X | E -> Y          L2: X -> Z | Y -> E          L3: Z -> X | E -> Y
+//   out : X -> film (2 tiles) | Y -> H -> Z        fir: Z -> fir (2 tiles)
+// 9 workgroup barriers per 32 frames (the one-path-at-a-time version of this kernel: 22) at the same 80 KB of LDS.
 __global__ __launch_bounds__(256, 2) void frame_mlps16_kernel(NwsWeights w, const float* __restrict__ gru_out, int T,
                                                               float* __restrict__ emb_out, float* __restrict__ film_out,
                                                               float* __restrict__ H_out, float* __restrict__ fir_out) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   MlpLds16& L = *reinterpret_cast<MlpLds16*>(smem_raw);
+  char* const E = L.xt[0][0];
+  char* const X = L.xt[1][0];
+  char* const Y = L.xt[2][0];
+  char* const Z = L.xt[3][0];
   const f16x8* F = reinterpret_cast<const f16x8*>(w.mlp_frags);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
@@ -370,119 +476,109 @@ __global__ __launch_bounds__(256, 2) void frame_mlps16_kernel(NwsWeights w, cons
   const int t0 = blockIdx.x * kFT;
   const int frames_valid = T - t0 < kFT ? T - t0 : kFT;
   AFrag<8> A0, A1;
-  AFrag<9> A9;
-  f32x16 acc;
+  f32x16 acc_a, acc_b;
 
   load_frags<8>(A0, F + frag_map(0).base, wave, lane);  // proj
-  // ---- gru_out tile -> XT p0 (4 channels per thread per pass) ----
+  // ---- gru_out tile -> X (4 channels per thread per pass) ----
   for (int e = tid; e < kFT * (NWS_HIDDEN / 4); e += 256) {
     const int f = e >> 5, c4 = (e & 31) * 4;
     float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (f < frames_valid) v = *reinterpret_cast<const float4*>(&gru_out[((size_t)b * T + t0 + f) * NWS_HIDDEN + c4]);
-    split4_store(L.p0[0], L.p0[1], f, c4, v.x, v.y, v.z, v.w);
+    split4_store(X, X + kXtBytes, f, c4, v.x, v.y, v.z, v.w);
   }
-  // zero the K padding (channels 128..143) of p1, which will hold H for the FIR-design contraction
+  // zero the K padding (channels 128..143) of Z, which will hold H for the FIR-design contraction
   for (int e = tid; e < kFT * 2 * 2; e += 256) {
     const int f = e >> 2, part = e & 3;
-    *reinterpret_cast<float4*>(L.p1[part >> 1] + f * kRowB + 256 + (part & 1) * 16) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    *reinterpret_cast<float4*>(Z + (part >> 1) * kXtBytes + f * kRowB + 256 + (part & 1) * 16) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
   __syncthreads();
 
-  // ---- emb = proj(gru_out) ----
-  mma_tile<8>(A0, L.p0[0], L.p0[1], lane, acc);
-  load_frags<8>(A1, F + frag_map(1).base, wave, lane);  // newt hidden 0
+  // ---- emb = proj(gru_out) -> E ----
   {
     float v[16];
+    load_lane_params(v, w.proj_b, wave, lane);  // requested before the fragments of the first pair (in-order returns)
+    mma_tile<8>(A0, X, lane, acc_a);
+    load_frags<8>(A0, F + frag_map(1).base, wave, lane);  // newt hidden 0
+    load_frags<8>(A1, F + frag_map(5).base, wave, lane);  // hgen hidden 0
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] += acc_a[r];
+    store_tile_xt(E, 32 * wave, v, lane);
+    if (emb_out != nullptr && col < frames_valid) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) emb_out[((size_t)b * NWS_HIDDEN + 32 * wave + frag_row(r, half)) * T + t0 + col] = v[r];
+    }
+  }
+  __syncthreads();
+
+  // ---- three hidden layer pairs (each requests the fragments of the one that follows) ----
+  hidden_pair<2, 6>(L, F, A0, A1, E, E, X, Y, w.newt_mlp_b[0], w.newt_ln_g[0], w.newt_ln_b[0], w.hgen_b[0], w.hgen_ln_g[0],
+                    w.hgen_ln_b[0], wave, wave, wave, lane);
+  hidden_pair<3, 7>(L, F, A0, A1, X, Y, Z, E, w.newt_mlp_b[1], w.newt_ln_g[1], w.newt_ln_b[1], w.hgen_b[1], w.hgen_ln_g[1],
+                    w.hgen_ln_b[1], wave, wave, wave, lane);
+  hidden_pair<4, 8>(L, F, A0, A1, Z, E, X, Y, w.newt_mlp_b[2], w.newt_ln_g[2], w.newt_ln_b[2], w.hgen_b[2], w.hgen_ln_g[2],
+                    w.hgen_ln_b[2], wave, wave, wave, lane);
+
+  // ---- output layers: film (256 channels = M-tiles w, w+4) from X; H (129 = M-tiles 0..3 + row 128 by wave 0) from Y ----
+  float* patch = reinterpret_cast<float*>(E) + wave * (kFT * kXS);  // E is dead: per-wave transposition patch
+  AFrag<9> A9a, A9b;
+  {
+    float v[16], vh[16];
+    load_lane_params(v, w.newt_mlp_b[3], wave, lane);       // output biases requested before the fragment prefetch
+    load_lane_params(vh, w.hgen_b[3], wave, lane);
+    const float b128 = w.hgen_b[3][128];
+    mma_tile2<8>(A0, X, acc_a, A1, Y, acc_b, lane);
+    load_frags<8>(A0, F + frag_map(4).base, wave + 4, lane);  // newt out, M-tile wave+4
+    if (wave == 0) load_frags<8>(A1, F + frag_map(8).base, 4, lane);  // hgen out, M-tile 4 = row 128
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int c = 32 * wave + frag_row(r, half);
-      v[r] = acc[r] + w.proj_b[c];
-      if (emb_out != nullptr && col < frames_valid) emb_out[((size_t)b * NWS_HIDDEN + c) * T + t0 + col] = v[r];
+      v[r] += acc_a[r];
+      vh[r] += acc_b[r];
     }
-    store_tile_xt(L.emb[0], L.emb[1], 32 * wave, v, lane);
-  }
-  __syncthreads();
-
-  // ---- film = newt.mlp(emb) ----
-  mma_tile<8>(A1, L.emb[0], L.emb[1], lane, acc);
-  load_frags<8>(A0, F + frag_map(2).base, wave, lane);
-  ln_epilogue(L, acc, w.newt_mlp_b[0], w.newt_ln_g[0], w.newt_ln_b[0], L.p0[0], L.p0[1], wave, lane);
-  mma_tile<8>(A0, L.p0[0], L.p0[1], lane, acc);
-  load_frags<8>(A1, F + frag_map(3).base, wave, lane);
-  ln_epilogue(L, acc, w.newt_mlp_b[1], w.newt_ln_g[1], w.newt_ln_b[1], L.p1[0], L.p1[1], wave, lane);
-  mma_tile<8>(A1, L.p1[0], L.p1[1], lane, acc);
-  load_frags<8>(A0, F + frag_map(4).base, wave, lane);      // newt out, M-tile wave
-  ln_epilogue(L, acc, w.newt_mlp_b[2], w.newt_ln_g[2], w.newt_ln_b[2], L.p0[0], L.p0[1], wave, lane);
-  {
-    float v[16];
-    mma_tile<8>(A0, L.p0[0], L.p0[1], lane, acc);
-    load_frags<8>(A1, F + frag_map(4).base, wave + 4, lane);  // newt out, M-tile wave+4
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = acc[r] + w.newt_mlp_b[3][32 * wave + frag_row(r, half)];
-    store_tile_frame_major(L.stage[wave], v, lane, film_out + ((size_t)b * T + t0) * NWS_FILM_CH + 32 * wave, NWS_FILM_CH,
+    store_tile_frame_major(patch, v, lane, film_out + ((size_t)b * T + t0) * NWS_FILM_CH + 32 * wave, NWS_FILM_CH,
                            frames_valid);
-    mma_tile<8>(A1, L.p0[0], L.p0[1], lane, acc);
-    load_frags<8>(A0, F + frag_map(5).base, wave, lane);      // hgen hidden 0
+    store_tile_xt(Z, 32 * wave, vh, lane);  // H -> Z channels 0..127 (129..143 stay zero: zero weights, zero bias)
+    if (H_out != nullptr && col < frames_valid) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = acc[r] + w.newt_mlp_b[3][32 * (wave + 4) + frag_row(r, half)];
-    store_tile_frame_major(L.stage[wave], v, lane, film_out + ((size_t)b * T + t0) * NWS_FILM_CH + 32 * (wave + 4),
-                           NWS_FILM_CH, frames_valid);
-  }
-  __syncthreads();
-
-  // ---- H = h_generator(emb) ----
-  mma_tile<8>(A0, L.emb[0], L.emb[1], lane, acc);
-  load_frags<8>(A1, F + frag_map(6).base, wave, lane);
-  ln_epilogue(L, acc, w.hgen_b[0], w.hgen_ln_g[0], w.hgen_ln_b[0], L.p0[0], L.p0[1], wave, lane);
-  mma_tile<8>(A1, L.p0[0], L.p0[1], lane, acc);
-  load_frags<8>(A0, F + frag_map(7).base, wave, lane);
-  ln_epilogue(L, acc, w.hgen_b[1], w.hgen_ln_g[1], w.hgen_ln_b[1], L.p1[0], L.p1[1], wave, lane);
-  mma_tile<8>(A0, L.p1[0], L.p1[1], lane, acc);
-  load_frags<8>(A1, F + frag_map(8).base, wave, lane);      // hgen out, M-tile wave
-  ln_epilogue(L, acc, w.hgen_b[2], w.hgen_ln_g[2], w.hgen_ln_b[2], L.p0[0], L.p0[1], wave, lane);
-  // 129 outputs: M-tiles 0..3 by the four waves, M-tile 4 (row 128 only) by wave 0; H -> p1 channels 0..128,
-  // channels 129..143 stay zero (zero weights, zero bias)
-  {
-    float v[16];
-    mma_tile<8>(A1, L.p0[0], L.p0[1], lane, acc);
-    load_frags<9>(A9, F + frag_map(9).base, wave, lane);     // FIR design, M-tile wave
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int c = 32 * wave + frag_row(r, half);
-      v[r] = acc[r] + w.hgen_b[3][c];
-      if (H_out != nullptr && col < frames_valid) H_out[((size_t)b * T + t0 + col) * NWS_N_BANDS + c] = v[r];
+      for (int r = 0; r < 16; ++r) H_out[((size_t)b * T + t0 + col) * NWS_N_BANDS + 32 * wave + frag_row(r, half)] = vh[r];
     }
-    store_tile_xt(L.p1[0], L.p1[1], 32 * wave, v, lane);
+    load_lane_params(v, w.newt_mlp_b[3], wave + 4, lane);   // behind the tile w+4 fragments, which the MFMAs below wait for anyway
     if (wave == 0) {
-      load_frags<8>(A0, F + frag_map(8).base, 4, lane);      // M-tile 4 = row 128 (not prefetched: register budget)
-      mma_tile<8>(A0, L.p0[0], L.p0[1], lane, acc);
+      mma_tile2<8>(A0, X, acc_a, A1, Y, acc_b, lane);
+    } else {
+      mma_tile<8>(A0, X, lane, acc_a);
+    }
+    load_frags<9>(A9a, F + frag_map(9).base, wave, lane);      // FIR design, M-tiles wave and wave+4
+    load_frags<9>(A9b, F + frag_map(9).base, wave + 4, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] += acc_a[r];
+    store_tile_frame_major(patch, v, lane, film_out + ((size_t)b * T + t0) * NWS_FILM_CH + 32 * (wave + 4), NWS_FILM_CH,
+                           frames_valid);
+    if (wave == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = 128 + frag_row(r, half);
-        v[r] = c < NWS_N_BANDS ? acc[r] + w.hgen_b[3][c] : 0.0f;
+        v[r] = c < NWS_N_BANDS ? acc_b[r] + b128 : 0.0f;   // only row 128 is real
         if (H_out != nullptr && c < NWS_N_BANDS && col < frames_valid) H_out[((size_t)b * T + t0 + col) * NWS_N_BANDS + c] = v[r];
       }
 #pragma unroll
       for (int g = 0; g < 2; ++g)  // rows 128..143 only: the XT row holds 144 channels
-        split4_store(L.p1[0], L.p1[1], col, 128 + 8 * g + 4 * half, v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+        split4_store(Z, Z + kXtBytes, col, 128 + 8 * g + 4 * half, v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
     }
   }
   __syncthreads();
 
-  // ---- fir = D * H  (256 taps, K = 144 padded) ----
+  // ---- fir = D * H  (256 taps = M-tiles w and w+4, K = 144 padded) ----
   {
     float v[16];
-    mma_tile<9>(A9, L.p1[0], L.p1[1], lane, acc);
-    load_frags<9>(A9, F + frag_map(9).base, wave + 4, lane);
+    mma_tile2<9>(A9a, Z, acc_a, A9b, Z, acc_b, lane);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = acc[r];
-    store_tile_frame_major(L.stage[wave], v, lane, fir_out + ((size_t)b * T + t0) * NWS_FIR_LEN + 32 * wave, NWS_FIR_LEN,
+    for (int r = 0; r < 16; ++r) v[r] = acc_a[r];
+    store_tile_frame_major(patch, v, lane, fir_out + ((size_t)b * T + t0) * NWS_FIR_LEN + 32 * wave, NWS_FIR_LEN,
                            frames_valid);
-    mma_tile<9>(A9, L.p1[0], L.p1[1], lane, acc);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = acc[r];
-    store_tile_frame_major(L.stage[wave], v, lane, fir_out + ((size_t)b * T + t0) * NWS_FIR_LEN + 32 * (wave + 4),
-                           NWS_FIR_LEN, frames_valid);
+    for (int r = 0; r < 16; ++r) v[r] = acc_b[r];
+    store_tile_frame_major(patch, v, lane, fir_out + ((size_t)b * T + t0) * NWS_FIR_LEN + 32 * (wave + 4), NWS_FIR_LEN,
+                           frames_valid);
   }
 }
 
