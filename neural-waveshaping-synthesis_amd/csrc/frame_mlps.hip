@@ -22,6 +22,7 @@ namespace {
 
 constexpr int kFT = 32;         // frames per workgroup
 constexpr int kXS = 33;         // LDS row stride (floats)
+constexpr int kPS = 36;         // output patch row stride (floats): 16-byte aligned rows for the vector read-back
 constexpr int kRows = 132;      // rows per activation buffer (129 FIR bands padded to 132)
 constexpr int kDK = 132;        // padded K of the FIR design matrix (row stride of D)
 constexpr float kLnEps = 1e-5f;
@@ -30,7 +31,7 @@ struct MlpLds {
   float emb[kRows * kXS];
   float p0[kRows * kXS];
   float p1[kRows * kXS];
-  float stage[4][kFT * kXS];
+  float stage[4][kFT * kPS];
   float red[2][4][kFT];
 };
 
@@ -113,18 +114,21 @@ __device__ __forceinline__ void hidden_layer(MlpLds& L, const float* W, const fl
 
 // write one 32-channel x 32-frame accumulator tile to a frame-major (.., T, ld) tensor with full
 // 128 B segments: through this wave's private LDS patch, 2 frames x 32 channels per store.
+// 32 channels x 32 frames held in the D layout -> dst[frame][channel] (row stride ld): transposed through a per-wave LDS
+// patch so that every global store instruction writes eight full 128 B frame segments (one dwordx4 per lane)
 __device__ __forceinline__ void store_tile_frame_major(float* patch, const float v[16], int lane, float* dst /* frame t0, channel c0 */,
                                                        int ld, int frames_valid) {
   const int half = lane >> 5, col = lane & 31;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) patch[col * kXS + frag_row(r, half)] = v[r];
+  for (int g = 0; g < 4; ++g)  // 4 consecutive channels of frame `col`
+    *reinterpret_cast<float4*>(&patch[col * kPS + 8 * g + 4 * half]) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-  for (int it = 0; it < 16; ++it) {
-    const int f = 2 * it + half;
-    if (f < frames_valid) dst[(size_t)f * ld + col] = patch[f * kXS + col];
+  for (int it = 0; it < 4; ++it) {
+    const int f = 8 * it + (lane >> 3), c4 = 4 * (lane & 7);
+    if (f < frames_valid) *reinterpret_cast<float4*>(&dst[(size_t)f * ld + c4]) = *reinterpret_cast<const float4*>(&patch[f * kPS + c4]);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -519,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void frame_mlps16_kernel(NwsWeights w, cons
                     w.hgen_ln_b[2], wave, wave, wave, lane);
 
   // ---- output layers: film (256 channels = M-tiles w, w+4) from X; H (129 = M-tiles 0..3 + row 128 by wave 0) from Y ----
-  float* patch = reinterpret_cast<float*>(E) + wave * (kFT * kXS);  // E is dead: per-wave transposition patch
+  float* patch = reinterpret_cast<float*>(E) + wave * (kFT * kPS);  // E is dead: per-wave transposition patch
   AFrag<9> A9a, A9b;
   {
     float v[16], vh[16];
