@@ -249,6 +249,22 @@ int nws_forward_audio(const NwsWeights* w, const NwsForwardAux* aux, const float
                       const float* phase_u, const float* rand_phase, const float* noise, float* out, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/*
+ * Perceptual-loudness feature, the step before the synthesis path:
+ * neural_waveshaping_synthesis/data/utils/loudness_extraction.py:10-67 (extract_perceptual_loudness) with the shipped
+ * configuration gin/data/urmp_4second_crepe.gin:11-14 = mean over bins of
+ * amplitude_to_db(|stft(audio, n_fft, hop, hann, center/reflect)|, ref=max, amin, top_db), optionally (L + 80) / 80.
+ * audio (B, N) fp32 -> out (B, 1 + N / hop).  `dft` is the constant windowed-DFT operand for n_fft (build once).
+ * n_fft: power of two in [64, 2048]; 1 <= hop <= n_fft; N > n_fft / 2.  The reference's optional interpolate_fn is a
+ * host callable on the returned frames and stays on the Python side.
+ */
+size_t nws_loudness_dft_bytes(int n_fft);
+int nws_loudness_dft_matrix(int n_fft, float* dft_out, void* stream);
+int nws_loudness_frames(int N, int hop);
+size_t nws_loudness_workspace_bytes(int B, int N, int n_fft, int hop);
+int nws_loudness(const float* audio, int B, int N, int n_fft, int hop, const float* dft, float amin, float top_db,
+                 int normalise, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Diagnostics only: ablation variants of the fused kernel for timing (1 no sin, 2 no LUT gather, 3 no shaper tail,
  * 4 no MFMA; 0 = product kernel).  Outputs of variants != 0 are meaningless. */
 int nws_debug_exciter_newt(int variant, const NwsWeights* w, const float* f0, const double* carry, const float* phase_u,

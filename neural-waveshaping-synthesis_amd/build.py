@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libnws_hip.so")
-SOURCES = ["exciter_newt.hip", "control_gru.hip", "frame_mlps.hip", "fir_noise.hip", "reverb_fft.hip", "forward.hip"]
+SOURCES = ["exciter_newt.hip", "control_gru.hip", "frame_mlps.hip", "fir_noise.hip", "reverb_fft.hip", "forward.hip",
+           "loudness.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=default",
          "-Wall", "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage"]
 

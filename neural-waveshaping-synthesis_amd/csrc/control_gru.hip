@@ -49,6 +49,9 @@ __device__ __forceinline__ float fast_tanh(float x) {
 __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const float* __restrict__ control, int C,
                                                              int T, const float* __restrict__ h0,
                                                              float* __restrict__ gru_out, float* __restrict__ hT) {
+  // latency-bound and usually sharing its SIMDs with throughput kernels of other streams (ForwardPipeline): ask for issue
+  // priority, the recurrence is the critical path of the pipelined step
+  __builtin_amdgcn_s_setprio(3);
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63;

@@ -43,6 +43,7 @@ __host__ __device__ constexpr bool is_lut(int mode) {
 __global__ __launch_bounds__(1024) void phase_carry_kernel(const float* __restrict__ f0,
                                                            const float* __restrict__ f0_up, int T,
                                                            double* __restrict__ carry) {
+  __builtin_amdgcn_s_setprio(3);  // one workgroup per utterance on the control stream: latency matters, throughput does not
   const int b = blockIdx.x;
   const int N = T * NWS_HOP;
   const int nchunks = N / 32;
