@@ -140,6 +140,10 @@ int nws_control_gru(const NwsWeights* w, const float* control, int B, int C, int
  * stateful streaming; the reference's forward is the h0 = 0 case */
 int nws_control_gru_state(const NwsWeights* w, const float* control, int B, int C, int T, const float* h0, float* gru_out,
                           float* hT, void* stream);
+/* nws_control_gru + nws_phase_carry in ONE launch (each GRU workgroup first computes its utterance's carries): the
+ * control-rate half of a forward; f0 (B,T) Hz, carry_out (B, 4T) doubles */
+int nws_control_gru_carry(const NwsWeights* w, const float* control, const float* f0, int B, int C, int T, float* gru_out,
+                          double* carry_out, void* stream);
 /* the same recurrence, 16 utterances per workgroup on the matrix cores (fp16 two-term split, fp32 accumulate): ~2x the
  * latency of the per-utterance kernel above but ~1/10 of its VALU work per utterance and 1/16 of its workgroups -- the
  * form to run beside throughput kernels of other streams (nws_forward_control, batched_gru = 1).  Any B >= 1. */

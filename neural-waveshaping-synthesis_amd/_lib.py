@@ -59,6 +59,7 @@ _PROTOTYPES = {
                                    _fp, _fp, _fp]),
     "nws_control_gru": (C.c_int, [C.POINTER(NwsWeights), _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "nws_control_gru_state": (C.c_int, [C.POINTER(NwsWeights), _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
+    "nws_control_gru_carry": (C.c_int, [C.POINTER(NwsWeights), _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),
     "nws_control_gru_batched": (C.c_int, [C.POINTER(NwsWeights), _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
     "nws_frame_mlps": (C.c_int, [C.POINTER(NwsWeights), _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp]),
     "nws_mlp_frags": (C.c_int, [C.POINTER(NwsWeights), _fp, _fp, _fp]),

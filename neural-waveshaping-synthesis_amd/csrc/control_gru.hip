@@ -48,7 +48,8 @@ __device__ __forceinline__ float fast_tanh(float x) {
 
 __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const float* __restrict__ control, int C,
                                                              int T, const float* __restrict__ h0,
-                                                             float* __restrict__ gru_out, float* __restrict__ hT) {
+                                                             float* __restrict__ gru_out, float* __restrict__ hT,
+                                                             const float* __restrict__ f0, double* __restrict__ carry) {
   // latency-bound and usually sharing its SIMDs with throughput kernels of other streams (ForwardPipeline): ask for issue
   // priority, the recurrence is the critical path of the pipelined step
   __builtin_amdgcn_s_setprio(3);
@@ -60,7 +61,10 @@ __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const
   const int unit = 32 * wave + (lane & 31);
 
   __shared__ __attribute__((aligned(16))) float h_lds[2][kH];
-  __shared__ float x_lds[2][kXChunk];  // control[:, 0:2] of the current chunk of frames
+  __shared__ __attribute__((aligned(16))) float x_lds[2][kXChunk];  // control[:, 0:2] of the current chunk of frames
+  // fused control-rate prologue of a forward: this utterance's oscillator phase carries (nws_control_gru_carry).  ~8 us here
+  // instead of a separate 64-workgroup launch in front of the recurrence on the control stream (70 us under load)
+  if (carry != nullptr) nws_phase_carry_block<4>(f0, nullptr, T, carry, b, tid, reinterpret_cast<double*>(&x_lds[0][0]));
 
   // wreg[g][c] = W_hh[g*128 + unit][64 kh + c]
   f32x2 wreg[3][32];
@@ -323,7 +327,17 @@ extern "C" int nws_control_gru_state(const NwsWeights* w, const float* control, 
                                      float* gru_out, float* hT, void* stream) {
   if (!w || !w->gru_w_ih || !w->gru_w_hh || !w->gru_b_ih || !w->gru_b_hh || !control || !gru_out) return NWS_ERR_BAD_ARG;
   if (B <= 0 || T <= 0 || C < 2) return NWS_ERR_BAD_ARG;
-  control_gru_kernel<<<B, 256, 0, (hipStream_t)stream>>>(*w, control, C, T, h0, gru_out, hT);
+  control_gru_kernel<<<B, 256, 0, (hipStream_t)stream>>>(*w, control, C, T, h0, gru_out, hT, nullptr, nullptr);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+extern "C" int nws_control_gru_carry(const NwsWeights* w, const float* control, const float* f0, int B, int C, int T,
+                                     float* gru_out, double* carry_out, void* stream) {
+  if (!w || !w->gru_w_ih || !w->gru_w_hh || !w->gru_b_ih || !w->gru_b_hh || !control || !gru_out || !f0 || !carry_out)
+    return NWS_ERR_BAD_ARG;
+  if (B <= 0 || T <= 0 || C < 2) return NWS_ERR_BAD_ARG;
+  control_gru_kernel<<<B, 256, 0, (hipStream_t)stream>>>(*w, control, C, T, nullptr, gru_out, nullptr, f0, carry_out);
   NWS_CHECK_LAUNCH();
   return NWS_OK;
 }

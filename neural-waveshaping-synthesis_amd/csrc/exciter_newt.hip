@@ -44,58 +44,8 @@ __global__ __launch_bounds__(1024) void phase_carry_kernel(const float* __restri
                                                            const float* __restrict__ f0_up, int T,
                                                            double* __restrict__ carry) {
   __builtin_amdgcn_s_setprio(3);  // one workgroup per utterance on the control stream: latency matters, throughput does not
-  const int b = blockIdx.x;
-  const int N = T * NWS_HOP;
-  const int nchunks = N / 32;
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
   __shared__ double wave_tot[16];
-  double running = 0.0;
-  for (int base = 0; base < nchunks; base += 1024) {
-    const int c = base + threadIdx.x;
-    double s = 0.0;
-    if (c < nchunks) {
-      const int n0 = c * 32;
-      if (f0_up != nullptr) {
-        const float4* p = reinterpret_cast<const float4*>(f0_up + (size_t)b * N + n0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float4 v = p[i];
-          s += (double)v.x;
-          s += (double)v.y;
-          s += (double)v.z;
-          s += (double)v.w;
-        }
-      } else {
-        const float* x = f0 + (size_t)b * T;
-#pragma unroll 8
-        for (int i = 0; i < 32; ++i) {
-          const NwsLerp L = nws_lerp_coeff(n0 + i, T);
-          s += (double)nws_lerp(x[L.i0], x[L.i1], L.w0, L.w1);
-        }
-      }
-    }
-    double v = s;  // inclusive scan over the wave
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const double t = __shfl_up(v, off, 64);
-      if (lane >= off) v += t;
-    }
-    if (lane == 63) wave_tot[wave] = v;
-    double excl = __shfl_up(v, 1, 64);
-    if (lane == 0) excl = 0.0;
-    __syncthreads();
-    double wp = 0.0, total = 0.0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const double t = wave_tot[i];
-      if (i < wave) wp += t;
-      total += t;
-    }
-    if (c < nchunks) carry[(size_t)b * nchunks + c] = running + wp + excl;
-    running += total;
-    __syncthreads();
-  }
+  nws_phase_carry_block<16>(f0, f0_up, T, carry, blockIdx.x, threadIdx.x, wave_tot);
 }
 
 // ---------------------------------------------------------------------------------------------

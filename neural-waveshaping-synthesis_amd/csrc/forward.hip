@@ -104,11 +104,15 @@ int control_half(const NwsWeights* w, const float* f0, const float* control, int
                  const Arena& a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   int rc = NWS_OK;
-  NWS_STAGE(0, nws_phase_carry(f0, nullptr, B, T, a.carry, stream));
-  if (batched_gru)
+  if (batched_gru) {
+    NWS_STAGE(0, nws_phase_carry(f0, nullptr, B, T, a.carry, stream));
     NWS_STAGE(1, nws_control_gru_batched(w, control, B, C, T, nullptr, a.gru_out, nullptr, stream));
-  else
-    NWS_STAGE(1, nws_control_gru(w, control, B, C, T, a.gru_out, stream));
+  } else {
+    // one launch: every GRU workgroup first leaves its utterance's phase carries (stage 0 has no launch of its own: its
+    // profiling bracket is recorded empty)
+    NWS_STAGE(0, NWS_OK);
+    NWS_STAGE(1, nws_control_gru_carry(w, control, f0, B, C, T, a.gru_out, a.carry, stream));
+  }
   return NWS_OK;
 }
 

@@ -131,6 +131,64 @@ __device__ __forceinline__ float nws_sinf_fast(float x) { return nws_sin_turns_c
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
 
+// Phase-carry pass of one utterance by one workgroup of NWAVES waves (phase_carry_kernel, and the prologue of the GRU kernel
+// when the two control-rate launches of a forward are fused): carry[c] = sum_{n < 32 c} f0_up[n] in float64.  The sums are
+// exact (fp32 addends, < 2^53 of dynamic range), so the order of summation does not matter.
+template <int NWAVES>
+__device__ __forceinline__ void nws_phase_carry_block(const float* __restrict__ f0, const float* __restrict__ f0_up, int T,
+                                                      double* __restrict__ carry, int b, int tid, double* wave_tot) {
+  const int N = T * NWS_HOP;
+  const int nchunks = N / 32;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  double running = 0.0;
+  for (int base = 0; base < nchunks; base += 64 * NWAVES) {
+    const int c = base + tid;
+    double s = 0.0;
+    if (c < nchunks) {
+      const int n0 = c * 32;
+      if (f0_up != nullptr) {
+        const float4* p = reinterpret_cast<const float4*>(f0_up + (size_t)b * N + n0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float4 v = p[i];
+          s += (double)v.x;
+          s += (double)v.y;
+          s += (double)v.z;
+          s += (double)v.w;
+        }
+      } else {
+        const float* x = f0 + (size_t)b * T;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {
+          const NwsLerp L = nws_lerp_coeff(n0 + i, T);
+          s += (double)nws_lerp(x[L.i0], x[L.i1], L.w0, L.w1);
+        }
+      }
+    }
+    double v = s;  // inclusive scan over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const double t = __shfl_up(v, off, 64);
+      if (lane >= off) v += t;
+    }
+    if (lane == 63) wave_tot[wave] = v;
+    double excl = __shfl_up(v, 1, 64);
+    if (lane == 0) excl = 0.0;
+    __syncthreads();
+    double wp = 0.0, total = 0.0;
+#pragma unroll
+    for (int i = 0; i < NWAVES; ++i) {
+      const double t = wave_tot[i];
+      if (i < wave) wp += t;
+      total += t;
+    }
+    if (c < nchunks) carry[(size_t)b * nchunks + c] = running + wp + excl;
+    running += total;
+    __syncthreads();
+  }
+}
+
 // 32-lane-half exchange (lane l <-> lane l^32)
 __device__ __forceinline__ float nws_swap_halves(float v) { return __shfl_xor(v, 32, 64); }
 

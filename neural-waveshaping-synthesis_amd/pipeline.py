@@ -81,14 +81,16 @@ class ForwardPipeline:
             cs.wait_event(ready)
             if slot.used:
                 cs.wait_event(slot.ev_audio)        # the previous tenant of this workspace has been consumed
-            self.eng.forward_control(f0, control, slot.ws, batched_gru=batched)
-            slot.ev_control.record(cs)
-        with torch.cuda.stream(au):
-            au.wait_event(ready)
+            # the two hidden draws of forward(), in the reference's order, on the side stream: two more small launches that
+            # the audio streams do not have to carry (the generator advances in submit order either way)
             pu = torch.rand_like(m.osc.rand_phase) if phase_u is None else phase_u      # RNG draw #1 (generators.py:55)
             pu = _req(pu.reshape(-1), "phase_u", _lib.N_HARMONICS)
             nz = torch.rand(m.control_hop * T - 1, device=self.dev) if noise is None else noise   # RNG draw #2 (:30)
             nz = _req(nz, "noise", m.control_hop * T - 1)
+            self.eng.forward_control(f0, control, slot.ws, batched_gru=batched)
+            slot.ev_control.record(cs)
+        with torch.cuda.stream(au):
+            au.wait_event(ready)
             au.wait_event(slot.ev_control)
             out = self.eng.forward_audio(f0, B, T, pu, nz, slot.ws, out=out)
             slot.ev_audio.record(au)

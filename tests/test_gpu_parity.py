@@ -72,6 +72,26 @@ def test_phase_carry_matches_double_cumsum(models, oracle):
     assert np.array_equal(carry2, ref)
 
 
+def test_fused_gru_and_carry_launch(models):
+    """nws_control_gru_carry = nws_control_gru + nws_phase_carry in one launch: identical bits."""
+    import ctypes as C
+    import nws_amd
+    _lib = nws_amd._lib
+    m, _ = models
+    eng = m._engine
+    w, _, _ = eng.weights()
+    g = torch.Generator().manual_seed(3)
+    for B, T in ((1, 2), (3, 37), (5, 1100)):
+        f0 = (100 + 900 * torch.rand(B, 1, T, generator=g)).cuda()
+        control = torch.randn(B, 3, T, generator=g).cuda()
+        gru = torch.empty(B, T, 128, device="cuda")
+        carry = torch.empty(B, 4 * T, dtype=torch.float64, device="cuda")
+        _lib.check(_lib.lib().nws_control_gru_carry(C.byref(w), _lib.ptr(control), _lib.ptr(f0), B, 3, T, _lib.ptr(gru),
+                                                    _lib.ptr(carry), _lib.stream_ptr()), "nws_control_gru_carry")
+        assert torch.equal(gru, eng.control_gru(control))
+        assert torch.equal(carry, eng.phase_carry(f0=f0[:, 0].contiguous()))
+
+
 def test_exciter_stage(models, oracle):
     m, _ = models
     worst = {}
