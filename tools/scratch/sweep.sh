@@ -1,2 +1,4 @@
-python bench.py --steps 30 --warmup 5 --no-cpu-baseline --batch1-iters 100 --pipeline 0 --streams 1 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d[\"stage_ms\"], d[\"batch1\"])"
-for i in 1 2; do python bench.py --steps 80 --warmup 8 --no-cpu-baseline --batch1-iters 0 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d[\"ms_per_step\"], d[\"roofline\"][\"gru_ms_in_timed_region\"])"; done
+for c in 1 2; do for s in 2 3; do
+echo -n "control=$c audio=$s "
+python bench.py --steps 100 --warmup 10 --no-cpu-baseline --batch1-iters 0 --control-streams $c --streams $s | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d[\"ms_per_step\"])"
+done; done
