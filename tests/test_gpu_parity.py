@@ -508,10 +508,12 @@ def test_exciter_wide_phase_path(models, oracle):
     assert maxabs(got, ref) <= 2e-5
 
 
-@pytest.mark.parametrize("B,T", [(3, 501), (1, 1000), (5, 33), (2, 250)])
+@pytest.mark.parametrize("B,T", [(3, 501), (1, 1000), (5, 33), (2, 250), (2, 251), (1, 2000)])
 def test_e2e_odd_shapes_against_oracle(models, oracle, B, T):
     """Shapes off the beaten path: T=501 -> L=64128=501x128 (general-N1 MFMA DFT), T=1000 -> L=128000=125x1024,
-    odd batch (one half-empty reverb pair), partial 32-frame MLP tiles, N<32000 (zero-padded to L=32000)."""
+    odd batch (one half-empty reverb pair), partial 32-frame MLP tiles, N<32000 (zero-padded to L=32000), T=251 -> the
+    first length past the IR (L=32128=251x128, prime N1, odd hop count for the two-hops-per-workgroup oscillator),
+    T=2000 -> 16 s, L=256000=250x1024."""
     exact, fast = models
     g = torch.Generator().manual_seed(1000 * B + T)
     f0 = (80 + 1500 * torch.rand(B, 1, 1, generator=g)) * (1 + 0.02 * torch.randn(B, 1, T, generator=g))
