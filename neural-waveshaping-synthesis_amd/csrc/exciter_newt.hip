@@ -311,8 +311,10 @@ __device__ __forceinline__ float dpp_f32(float v) {
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_f64(double v) {
   const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xf, false);
-  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+  // all rows enabled: lanes without a source read zero by bound_ctrl, no zero-initialised destination needed
+  constexpr bool kBound = ROW_MASK == 0xf;
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xf, kBound);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, kBound);
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 // inclusive prefix sum inside each 32-lane half: row_shr 1/2/4/8 (zeros shifted in) scan the 16-lane rows, row_bcast15
