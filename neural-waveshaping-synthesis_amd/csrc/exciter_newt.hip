@@ -523,6 +523,9 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (HPB == 2 ? 7 :
   }
   const float nyquist = sample_rate * 0.5f;
 
+  // the fragment table travels by LDS-DMA, which only the issuing wave's VM counter tracks: every wave drains its own
+  // before the barrier (hipcc happens to place such a wait here anyway, for the carry load; this makes it a guarantee)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (!hop_live) return;
 
