@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU (weak scaling: fixed per-GPU work)")
     ap.add_argument("--frames", type=int, default=500, help="control frames per utterance (500 = 4 s @ 16 kHz)")
     ap.add_argument("--exact", action="store_true", help="exact sin-MLP shapers instead of the FastNEWT LUT")
+    ap.add_argument("--inputs", choices=("rand", "realistic"), default="rand",
+                    help="rand: torch.rand F0/control exactly like scripts/time_forward_pass.py (sub-1 Hz 'F0': all 101 harmonics "
+                         "live, the worst case for the oscillator); realistic: per-utterance F0 ~ U[100, 1000] Hz with 5.5 Hz "
+                         "vibrato, control ~ N(0,1) (SURVEY 8(d) config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=60)
     ap.add_argument("--batch1-iters", type=int, default=200)
@@ -54,7 +58,7 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=1,
                     help="1: ForwardPipeline (control half = carries + GRU of batch i+1 on a side stream under the audio "
                          "half of batch i, --streams audio streams); 0: whole forwards round-robin on --streams streams")
-    ap.add_argument("--control-streams", type=int, default=1)
+    ap.add_argument("--control-streams", type=int, default=2)
     ap.add_argument("--gru", choices=("batched", "per-utterance"), default="per-utterance",
                     help="GRU kernel of the pipeline's control half (the plain forward always uses per-utterance)")
     return ap.parse_args()
@@ -124,8 +128,14 @@ def main():
     B, T = a.batch, a.frames
     N = 128 * T
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
-    f0 = torch.rand(B, 1, T, device=dev, generator=g)         # time_forward_pass.py:34-40
-    control = torch.rand(B, 2, T, device=dev, generator=g)    # time_forward_pass.py:27-33
+    if a.inputs == "rand":
+        f0 = torch.rand(B, 1, T, device=dev, generator=g)         # time_forward_pass.py:34-40
+        control = torch.rand(B, 2, T, device=dev, generator=g)    # time_forward_pass.py:27-33
+    else:
+        tt = torch.arange(T, device=dev, dtype=torch.float32) * (128.0 / 16000.0)
+        base = 100.0 + 900.0 * torch.rand(B, 1, 1, device=dev, generator=g)
+        f0 = (base * (1.0 + 0.01 * torch.sin(2 * np.pi * 5.5 * tt).view(1, 1, T))).contiguous()
+        control = torch.randn(B, 2, T, device=dev, generator=g)
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, a.streams))]
     shared_gen = par.make_shared_generator(dev) if distributed else None   # same draws on every rank, no broadcast
@@ -298,7 +308,8 @@ def main():
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"NEWT forward, vn checkpoint, {'exact sin-MLP shapers' if a.exact else 'FastNEWT LUT'}, "
-                                   f"batch {B}/GPU x {T} frames (4 s @ 16 kHz), torch.rand F0/control, "
+                                   f"batch {B}/GPU x {T} frames (4 s @ 16 kHz), "
+                                   f"{'torch.rand F0/control' if a.inputs == 'rand' else 'F0 ~ U[100,1000] Hz with vibrato, control ~ N(0,1)'}, "
                                    f"RNG draws on device{', RCCL all-gather of waveforms' if distributed else ''}",
                        "batch_per_gpu": B, "frames": T, "samples_per_utterance": N, "parallelism": f"batch-shard x{world}",
                        "streams": len(streams),

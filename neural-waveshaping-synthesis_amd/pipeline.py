@@ -35,7 +35,7 @@ class _Slot:
 
 
 class ForwardPipeline:
-    def __init__(self, model, depth: int = 4, audio_streams: int = 2, control_streams: int = 1, batched_gru: bool = False):
+    def __init__(self, model, depth: int = 4, audio_streams: int = 2, control_streams: int = 2, batched_gru: bool = False):
         if depth < 2 or audio_streams < 1 or control_streams < 1:
             raise ValueError("need depth >= 2 and at least one stream of each kind")
         self.model = model
