@@ -52,15 +52,16 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=60)
     ap.add_argument("--batch1-iters", type=int, default=200)
-    ap.add_argument("--streams", type=int, default=2,
-                    help="HIP streams the steps are issued on round-robin (independent forwards overlap: the GRU of "
-                         "step i+1 only occupies B CUs while step i's sample-rate kernels fill the rest)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="audio streams of the pipeline (or, with --pipeline 0, streams that whole forwards are issued on "
+                         "round-robin).  More than one audio stream is ~6 %% faster but produced wrong reverb output in soak "
+                         "tests on this stack (pipeline.py), so the default is one")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="1: ForwardPipeline (control half = carries + GRU of batch i+1 on a side stream under the audio "
                          "half of batch i, --streams audio streams); 0: whole forwards round-robin on --streams streams")
-    ap.add_argument("--control-streams", type=int, default=0,
-                    help="side streams for the control half; 0 = auto: 2 on one GPU, 1 beside RCCL (measured with the all-gather "
-                         "in the loop: 0.51 ms/step with one, 0.62 with two -- RCCL brings streams of its own)")
+    ap.add_argument("--control-streams", type=int, default=1,
+                    help="side streams for the control half (two were no faster with one audio stream, and slower beside RCCL: "
+                         "0.62 vs 0.51 ms/step with the all-gather in the loop)")
     ap.add_argument("--gru", choices=("batched", "per-utterance"), default="per-utterance",
                     help="GRU kernel of the pipeline's control half (the plain forward always uses per-utterance)")
     return ap.parse_args()
@@ -146,7 +147,8 @@ def main():
     if use_pipe:
         pmod = importlib.import_module("neural-waveshaping-synthesis_amd.pipeline")
         pipe = pmod.ForwardPipeline(model, depth=2 * len(streams) + 2, audio_streams=len(streams),
-                                    control_streams=a.control_streams if a.control_streams > 0 else (1 if distributed else 2), batched_gru=a.gru == "batched")
+                                    allow_concurrent_audio=len(streams) > 1,
+                                    control_streams=max(1, a.control_streams), batched_gru=a.gru == "batched")
         streams = pipe.audio
     nbuf = len(pipe.slots) if use_pipe else len(streams)
     full = [torch.empty((B * world, N), dtype=torch.float32, device=dev) for _ in range(nbuf)] if distributed else None

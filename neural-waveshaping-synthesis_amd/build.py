@@ -50,8 +50,8 @@ def build(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
-        # No kernel may use scratch: a 24 B/lane spill made the fused kernel return wrong tiles when two instances ran on
-        # different streams (ForwardPipeline), besides being slower.  The resource remarks make that a build error.
+        # No kernel may use scratch (spills or a device-call stack frame): every occurrence so far was a register-allocation
+        # accident that cost speed.  The resource remarks make it a build error.
         name, spilled, rest, skip = None, [], [], 0
         for line in r.stderr.splitlines():
             if skip and (line.lstrip().startswith("|") or line.lstrip().split(" ")[0].isdigit()):

@@ -383,8 +383,8 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 // HPB = hops (128-sample tiles) per workgroup = 4 HPB waves.  Two hops share one copy of the 28 KB fragment table and one
 // set of phase shifts: 33 KB of LDS per 8 waves instead of 31.5 KB per 4 -> 6 waves per SIMD instead of 5 (0.322 -> 0.304 ms).
 // The bound of 7 waves/SIMD (72 VGPRs) is deliberate: at 8 (64 VGPRs) hipcc spills 24 B/lane to scratch, which is slower
-// (0.328 ms) AND made this kernel return wrong tiles when instances of it ran on two streams at once (ForwardPipeline; 4 of 6
-// runs) -- keep every kernel of the pipelined path free of scratch.
+// (0.328 ms).  (Wrong results seen with that build under two overlapping audio streams were first blamed on the scratch;
+// the multi-stream problem turned out to be independent of it, see pipeline.py.  The build still rejects scratch.)
 template <int MODE, int DBG = 0, int HPB = 1>
 __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (HPB == 2 ? 7 : 5)) void exciter_newt_kernel(NwsWeights w, const float* __restrict__ f0,
                                                            const float* __restrict__ f0_up,

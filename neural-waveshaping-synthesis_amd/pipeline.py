@@ -5,15 +5,32 @@ reverb.  Everything but the GRU fills all 256 CUs; the GRU is a 500-step recurre
 batch size (B workgroups).  Whole forwards issued round-robin on several streams fall into lock-step (all streams in their
 GRU at once, then all in their oscillator).  `ForwardPipeline` instead issues the *control half* (carries + GRU) of batch
 i+1 on a side stream while the *audio half* of batch i occupies the GPU, with events for the hand-over and a small ring of
-workspaces: 0.618 -> 0.536 ms per 64 x 4 s batch on MI355X.  The kernels and their results are exactly those of `model(f0, control)`; only
-the issue order across batches changes.
+workspaces: 0.62 -> 0.53 ms per 64 x 4 s batch on MI355X.  The kernels and their results are exactly those of
+`model(f0, control)`; only the issue order across batches changes.
 
     pipe = ForwardPipeline(model)
     outs = [pipe.submit(f0_i, control_i) for ...]     # asynchronous; draws the reference's two RNG vectors per batch
     pipe.synchronize()                                 # or pipe.join_current_stream() to stay asynchronous
 
-Inputs must be valid in the submitting thread's current stream at submit() time (an event is recorded there and both
+Inputs must be valid in the submitting thread's current stream at submit() time (an event is recorded there and the
 internal streams wait for it).
+
+ONE audio stream, on purpose.  Alternating the audio halves over two streams is another 6 % faster (0.50 ms) but is NOT
+safe on this stack (ROCm 7.2 / MI355X): with two audio streams that are both released by events of a third stream, the
+reverb of the earlier batch came out wrong in up to half of the batches (rows in pairs = whole two-utterance transforms,
+errors ~1e-2) whenever the later batch's frame-MLP or noise kernel overlapped it.  What was established (MI355X, soak runs
+of 128-240 batches compared bit for bit with `model()`):
+  * every configuration with ONE audio stream (1 or 2 control streams, any depth): 0 mismatches, with or without random
+    skews injected into the streams;
+  * every configuration with TWO audio streams: mismatches under some timing (4-50 %), with 4, 8 or 16 hardware queues;
+    none with GPU_MAX_HW_QUEUES <= 2 (which serialises the streams);
+  * the same three-stream / two-event pattern written with bare torch streams around the C-ABI calls reproduces it;
+    two streams without events, or the same kernels overlapped pairwise at kernel level, do not; a chain of plain torch
+    ops under the same stream / event pattern does not either;
+  * all intermediate buffers of the damaged batch (carries, GRU, FiLM, FIR, NEWT, pre-reverb) are bit-identical to the
+    sequential run: only the reverb's three short kernels are hit; serialising them with no-op kernels or events between
+    them does not help, padding the workspaces does not help, stream priorities do not matter.
+The cause was not found; the safe pattern is the default and `audio_streams > 1` has to be asked for explicitly.
 """
 from __future__ import annotations
 
@@ -35,9 +52,13 @@ class _Slot:
 
 
 class ForwardPipeline:
-    def __init__(self, model, depth: int = 4, audio_streams: int = 2, control_streams: int = 2, batched_gru: bool = False):
+    def __init__(self, model, depth: int = 3, audio_streams: int = 1, control_streams: int = 1, batched_gru: bool = False,
+                 allow_concurrent_audio: bool = False):
         if depth < 2 or audio_streams < 1 or control_streams < 1:
             raise ValueError("need depth >= 2 and at least one stream of each kind")
+        if audio_streams > 1 and not allow_concurrent_audio:
+            raise ValueError("audio_streams > 1 gave wrong reverb output in soak tests on this stack (see the module docstring); "
+                             "pass allow_concurrent_audio=True to use it anyway")
         self.model = model
         self.eng = model._engine
         _, _, dev = self.eng.weights()

@@ -185,7 +185,8 @@ def test_forward_pipeline_matches_plain_forward(models, oracle):
     refs = [fast(f0, c, phase_u=pu, noise=nz).cpu().numpy() for f0, c, pu, nz in jobs]
     f0, c, pu, nz = jobs[0]
     ref_orc = oracle[1](f0.cpu(), c.cpu(), pu.cpu(), nz.cpu()).numpy()
-    for batched, kw in ((False, dict(depth=3, audio_streams=2, control_streams=1)),
+    for batched, kw in ((False, dict()),                                              # defaults: one audio, one control stream
+                        (False, dict(depth=4, audio_streams=1, control_streams=2)),
                         (True, dict(depth=2, audio_streams=1, control_streams=2))):
         pipe = nws_amd.ForwardPipeline(fast, batched_gru=batched, **kw)
         outs = [pipe.submit(f0, c, phase_u=pu, noise=nz) for f0, c, pu, nz in jobs]
@@ -198,6 +199,8 @@ def test_forward_pipeline_matches_plain_forward(models, oracle):
         # default: the very same kernels -> identical;  batched GRU: two fp32-class recurrences differ in rounding
         assert worst <= (2e-5 if batched else 0.0), (batched, worst)
         assert e_orc <= 1e-4
+    with pytest.raises(ValueError):
+        nws_amd.ForwardPipeline(fast, audio_streams=2)      # not safe on this stack: has to be asked for explicitly
     # default RNG path: draws come from the device generator in submit order
     torch.manual_seed(123)
     a1 = pipe.submit(jobs[0][0], jobs[0][1])
@@ -206,6 +209,49 @@ def test_forward_pipeline_matches_plain_forward(models, oracle):
     a2 = pipe.submit(jobs[0][0], jobs[0][1])
     pipe.synchronize()
     assert torch.equal(a1, a2)
+
+
+def test_forward_pipeline_soak_bench_shape_with_skews(models):
+    """The bench's own shape (64 x 500), 3 x 16 distinct batches through the default pipeline, with extra work injected into
+    the streams at random to shift their relative timing: every output must be bit-identical to model()'s.  (This is the
+    check that exposed the two-audio-stream problem described in pipeline.py.)"""
+    import ctypes as C
+    import random
+    import nws_amd
+    _lib = nws_amd._lib
+    _, fast = models
+    eng = fast._engine
+    w, _, _ = eng.weights()
+    B, T = 64, 500
+    g = torch.Generator(device="cuda").manual_seed(0)
+    jobs = []
+    for _ in range(16):
+        f0 = (100 + 900 * torch.rand(B, 1, 1, device="cuda", generator=g)) * (1 + 0.01 * torch.randn(B, 1, T, device="cuda", generator=g))
+        jobs.append((f0, torch.randn(B, 2, T, device="cuda", generator=g), torch.rand(101, device="cuda", generator=g),
+                     torch.rand(128 * T - 1, device="cuda", generator=g)))
+    refs = [fast(f0, c, phase_u=pu, noise=nz) for f0, c, pu, nz in jobs]
+    torch.cuda.synchronize()
+    scratch = torch.empty(B, T, 128, device="cuda")
+
+    def skew(stream, n):
+        with torch.cuda.stream(stream):
+            for _ in range(n):
+                _lib.check(_lib.lib().nws_control_gru(C.byref(w), _lib.ptr(jobs[0][1]), B, 2, T, _lib.ptr(scratch),
+                                                      _lib.stream_ptr()), "nws_control_gru")
+    rng = random.Random(1)
+    bad = 0
+    for kw in (dict(), dict(depth=4, control_streams=2)):
+        pipe = nws_amd.ForwardPipeline(fast, **kw)
+        for rep in range(3):
+            outs = []
+            for f0, c, pu, nz in jobs:
+                if rep and rng.random() < 0.5:
+                    skew(rng.choice(pipe.control + pipe.audio), rng.choice([1, 1, 2]))
+                outs.append(pipe.submit(f0, c, phase_u=pu, noise=nz))
+            pipe.synchronize()
+            bad += sum(0 if torch.equal(o, r) else 1 for o, r in zip(outs, refs))
+    record("forward_pipeline_soak", batches=2 * 3 * len(jobs), mismatching=bad)
+    assert bad == 0
 
 
 @pytest.mark.parametrize("B,T", [(40, 300), (16, 7), (64, 500)])
