@@ -229,6 +229,39 @@ def main():
             assert torch.isfinite(last).all() and float(last[B * (world - 1):].abs().max()) > 0.0
 
         extra = {}
+        if use_pipe:
+            # self-check outside the timed region: the issue pattern of the timed loop (pipeline, and the all-gather when
+            # distributed) must return bit for bit what a plain forward returns for the same draws
+            _lib.lib().nws_profile_end()
+            gchk = torch.Generator(device=dev).manual_seed(4242 + rank)
+            draws = [(torch.rand(101, device=dev, generator=gchk), torch.rand(N - 1, device=dev, generator=gchk))
+                     for _ in range(12)]
+            torch.cuda.synchronize()
+            ys, pend = [], None
+            for i, (pu_c, nz_c) in enumerate(draws):
+                y = pipe.submit(f0, control, phase_u=pu_c, noise=nz_c)
+                ys.append(y)
+                if distributed:
+                    with torch.cuda.stream(pipe.audio[i % len(pipe.audio)]):
+                        if pend is not None:
+                            pend.wait()
+                        pend = dist.all_gather_into_tensor(full[i % nbuf], y, async_op=True)
+            if pend is not None:
+                pend.wait()
+            pipe.synchronize()
+            torch.cuda.synchronize()
+            wrong = 0
+            for y, (pu_c, nz_c) in zip(ys, draws):
+                wrong += 0 if torch.equal(y, model(f0, control, phase_u=pu_c, noise=nz_c)) else 1
+            torch.cuda.synchronize()
+            extra["pipeline_selfcheck"] = {"batches": len(ys), "mismatching": wrong}
+            if wrong:   # reported, not raised: the line must still come out, with the evidence in it
+                print(f"bench.py: pipeline self-check FAILED on rank {rank}: {wrong} of {len(ys)} batches differ from the plain "
+                      f"forward", file=sys.stderr)
+            if distributed:   # every rank's verdict
+                tw = torch.tensor([wrong], dtype=torch.float64, device="cpu" if share_gpu else dev)
+                dist.all_reduce(tw, op=dist.ReduceOp.SUM)
+                extra["pipeline_selfcheck"]["mismatching_all_ranks"] = int(tw.item())
         if rank == 0:
             # per-stage breakdown (diagnostic, outside the timed region)
             _lib.check(_lib.lib().nws_profile_begin(10, 0x3F))
