@@ -13,9 +13,19 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libnws_hip.so")
 SOURCES = ["exciter_newt.hip", "control_gru.hip", "frame_mlps.hip", "fir_noise.hip", "reverb_fft.hip", "forward.hip",
-           "loudness.hip"]
+           "loudness.hip", "coexec_probe.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=default",
-         "-Wall", "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage"]
+         "-Wall", "-Wno-unused-function", "-Wno-pass-failed", "-Rpass-analysis=kernel-resource-usage"]
+# -fno-slp-vectorize: the SLP vectoriser turns scalar fp32 code into packed instructions with operand swizzles of its own
+# choosing, among them the form that misbehaves beside another kernel's f16 MFMAs (see check_packed_swizzles below);
+# packed arithmetic is written explicitly (f32x2) where it pays.  Two files keep the vectoriser (the guard checks every
+# file anyway): fir_noise.hip, whose MFMA kernel sits at its register budget and only gets the harmless low-broadcast form
+# from it, and control_gru.hip, whose batched MFMA kernel was validated with it (its horizontal sums are scalar by hand).
+KEEP_SLP = ("fir_noise.hip", "control_gru.hip")
+EXTRA_FLAGS = {src: ["-fno-slp-vectorize"] for src in SOURCES if src not in KEEP_SLP}
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+# kernels that contain the hazardous form on purpose (the probe that demonstrates it)
+SWIZZLE_ALLOW = ("pk_probe_kernel",)
 
 
 def _hipcc():
@@ -26,7 +36,7 @@ def _hipcc():
 
 
 def _stamp():
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256((" ".join(FLAGS) + repr(sorted(EXTRA_FLAGS.items()))).encode())
     for f in sorted(os.listdir(CSRC)):
         p = os.path.join(CSRC, f)
         if os.path.isfile(p):
@@ -34,6 +44,41 @@ def _stamp():
             h.update(open(p, "rb").read())
     h.update(open(os.path.join(HERE, "..", "include", "nws_hip.h"), "rb").read())
     return h.hexdigest()
+
+
+def device_disassembly(obj):
+    """gfx950 ISA of the device code embedded in a host object built by hipcc."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "dev.co")
+        r = subprocess.run([os.path.join(LLVM_BIN, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", obj,
+                            os.path.join(td, "host.o")], capture_output=True, text=True)
+        if r.returncode != 0:
+            if "not found" in r.stderr:      # a host-only translation unit (no kernels)
+                return ""
+            raise RuntimeError(f"llvm-objcopy failed on {obj}: {r.stderr}")
+        subprocess.run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True, capture_output=True)
+        return subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", co], check=True, capture_output=True,
+                              text=True).stdout
+
+
+def check_packed_swizzles(obj):
+    """MI355X co-execution hazard guard (csrc/coexec_probe.hip).
+
+    v_pk_{add,mul,fma}_f32 with op_sel[1] = 1 (low lane <- high half of src1) returns wrong values while another kernel
+    runs K=16/32 f16 MFMAs on the same CU.  Returns [(kernel, instruction), ...] for every occurrence outside the probe."""
+    import re
+    found, kernel = [], None
+    for line in device_disassembly(obj).splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            kernel = m.group(1)
+            continue
+        m = re.search(r"\b(v_pk_(?:add|mul|fma)_f32)\b.*?op_sel:\[\d,(\d)", line)
+        if m and m.group(2) == "1" and not any(a in (kernel or "") for a in SWIZZLE_ALLOW):
+            found.append((kernel, " ".join(line.split("//")[0].split())))
+    return found
 
 
 def build(force=False, verbose=True):
@@ -46,7 +91,7 @@ def build(force=False, verbose=True):
 
     def compile_one(src):
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
@@ -68,6 +113,11 @@ def build(force=False, verbose=True):
                 rest.append(line)
         if spilled:
             raise RuntimeError(f"{src}: kernels using scratch memory (spills or stack): {spilled}")
+        swz = check_packed_swizzles(obj)
+        if swz:
+            lines = "\n".join(f"  {k}: {i}" for k, i in swz[:12])
+            raise RuntimeError(f"{src}: packed fp32 instructions with a swizzled src1 low lane (co-execution hazard, see "
+                               f"check_packed_swizzles):\n{lines}")
         if verbose and "\n".join(rest).strip():
             print("\n".join(rest), file=sys.stderr)
         return obj

@@ -1,0 +1,124 @@
+// Diagnostic kernels for the MI355X co-execution hazard that shaped ForwardPipeline.
+//
+// Observation (ROCm 7.2 image, torch 2.10+rocm7.0 runtime, MI355X): a packed fp32 VALU instruction
+//   v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32  with op_sel[1] = 1
+// (the LOW result lane reads the HIGH half of src1: a swapped or high-broadcast second operand) sporadically returns a
+// wrong value while a DIFFERENT kernel - another stream, same compute unit - issues the K=16/K=32 half-precision MFMAs
+// v_mfma_f32_32x32x16_f16 / v_mfma_f32_16x16x32_f16.  Not affected: the same packed instructions without that swizzle
+// (plain, src0 or src2 swizzles, op_sel_hi-only broadcasts, neg modifiers), scalar VALU, LDS contents, barriers; not a
+// trigger: v_mfma_f32_32x32x8f16, v_mfma_f32_32x32x2f32, dense VALU.  The reverb's FFT butterflies ("times -i" is a swapped
+// second operand) were the victims of the frame-MLP / noise kernels of the next batch.
+//
+//   nws_coexec_pk_probe    evaluates eight packed forms with explicit instructions and checks each against scalar
+//                          arithmetic on the same operands; report[k] counts wrong results of form k.
+//   nws_coexec_mfma_load   a bare MFMA loop of the chosen flavour to run beside it on another stream.
+// tools/coexec_probe.py prints the matrix; tests/test_gpu_coexec.py keeps the probe honest and checks the product path.
+#include "nws_common.h"
+
+namespace {
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float sfma(float a, float b, float c) {
+  float d;
+  asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ float smul(float a, float b) {
+  float d;
+  asm volatile("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ float sadd(float a, float b) {
+  float d;
+  asm volatile("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
+__global__ __launch_bounds__(256) void pk_probe_kernel(int iters, unsigned* __restrict__ report) {
+  const int tid = threadIdx.x;
+  unsigned bad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float2 a = make_float2(0.37f + 0.001f * (float)tid, -1.21f + 0.002f * (float)(blockIdx.x & 63));
+  float2 b = make_float2(1.0009f, 0.9991f), c = make_float2(0.125f, -0.375f);
+  for (int it = 0; it < iters; ++it) {
+    float2 d;
+    // 0..3: forms that were never seen to fail
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    bad[0] += ((d.x != sfma(a.x, b.x, c.x)) || (d.y != sfma(a.y, b.y, c.y))) ? 1u : 0u;
+    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(d) : "v"(a), "v"(c));  // src0 swapped
+    bad[1] += ((d.x != sadd(a.y, c.x)) || (d.y != sadd(a.x, c.y))) ? 1u : 0u;
+    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(c));               // src1 low broadcast
+    bad[2] += ((d.x != sadd(a.x, c.x)) || (d.y != sadd(a.y, c.x))) ? 1u : 0u;
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0] neg_lo:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    bad[3] += ((d.x != sfma(a.x, b.x, -c.y)) || (d.y != sfma(a.y, b.y, c.x))) ? 1u : 0u;                           // src2 swapped
+    // 4..7: op_sel[1] = 1
+    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(c));  // src1 swapped
+    bad[4] += ((d.x != sadd(a.x, c.y)) || (d.y != sadd(a.y, c.x))) ? 1u : 0u;
+    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(d) : "v"(a), "v"(c));                   // src1 high broadcast
+    bad[5] += ((d.x != sadd(a.x, c.y)) || (d.y != sadd(a.y, c.y))) ? 1u : 0u;
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+    bad[6] += ((d.x != smul(a.x, b.y)) || (d.y != smul(a.y, b.x))) ? 1u : 0u;
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    bad[7] += ((d.x != sfma(a.x, b.y, c.x)) || (d.y != sfma(a.y, b.x, c.y))) ? 1u : 0u;
+    // next operands (kept in a sane range)
+    a = make_float2(sfma(a.x, 0.9993f, smul(0.0007f, d.y)), sfma(a.y, 0.9989f, smul(-0.0003f, d.x)));
+    b = make_float2(sfma(b.x, 0.99f, 0.0101f), sfma(b.y, 0.99f, 0.0099f));
+  }
+  for (int k = 0; k < 8; ++k)
+    if (bad[k]) atomicAdd(&report[k], bad[k]);
+}
+
+// KIND 0: v_mfma_f32_32x32x16_f16   1: v_mfma_f32_16x16x32_f16   2: v_mfma_f32_32x32x8f16   3: v_mfma_f32_32x32x2f32
+template <int KIND>
+__global__ __launch_bounds__(256, 4) void mfma_load_kernel(int iters, float* __restrict__ sink) {
+  const int lane = threadIdx.x & 63;
+  f32x16 acc = {};
+  f16x8 a, b;
+  for (int q = 0; q < 8; ++q) {
+    a[q] = (_Float16)(0.01f * (float)(lane + q));
+    b[q] = (_Float16)(0.02f * (float)(q + 1));
+  }
+  for (int it = 0; it < iters; ++it) {
+    if (KIND == 0) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+    } else if (KIND == 1) {
+      f32x4 c4 = {acc[0], acc[1], acc[2], acc[3]};
+      c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c4, 0, 0, 0);
+      c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c4, 0, 0, 0);
+      acc[0] = c4[0]; acc[1] = c4[1]; acc[2] = c4[2]; acc[3] = c4[3];
+    } else if (KIND == 2) {
+      const f16x4 a4 = {a[0], a[1], a[2], a[3]}, b4 = {b[0], b[1], b[2], b[3]};
+      acc = __builtin_amdgcn_mfma_f32_32x32x8f16(a4, b4, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x8f16(a4, b4, acc, 0, 0, 0);
+    } else {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32((float)a[0], (float)b[0], acc, 0, 0, 0);
+    }
+  }
+  float t = 0.0f;
+  for (int r = 0; r < 16; ++r) t += acc[r];
+  if (t == 12345.678f) sink[threadIdx.x] = t;  // never true: keeps the loop alive
+}
+}  // namespace
+
+extern "C" {
+
+int nws_coexec_pk_probe(int blocks, int iters, unsigned* report, void* stream) {
+  if (blocks <= 0 || iters <= 0 || !report) return NWS_ERR_BAD_ARG;
+  pk_probe_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(iters, report);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+int nws_coexec_mfma_load(int kind, int blocks, int iters, float* sink, void* stream) {
+  if (kind < 0 || kind > 3 || blocks <= 0 || iters <= 0 || !sink) return NWS_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (kind == 0) mfma_load_kernel<0><<<blocks, 256, 0, st>>>(iters, sink);
+  else if (kind == 1) mfma_load_kernel<1><<<blocks, 256, 0, st>>>(iters, sink);
+  else if (kind == 2) mfma_load_kernel<2><<<blocks, 256, 0, st>>>(iters, sink);
+  else mfma_load_kernel<3><<<blocks, 256, 0, st>>>(iters, sink);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+}  // extern "C"

@@ -120,9 +120,10 @@ __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const
         bz = __builtin_elementwise_fma(wreg[1][2 * q + 1], h23, bz);
         bn = __builtin_elementwise_fma(wreg[2][2 * q + 1], h23, bn);
       }
-      const float sr = sum_halves((ar.x + ar.y) + (br.x + br.y));
-      const float sz = sum_halves((az.x + az.y) + (bz.x + bz.y));
-      const float sn = sum_halves((an.x + an.y) + (bn.x + bn.y));
+      // horizontal sums kept scalar: "a.x + a.y" on a register pair becomes a packed add with a swizzled src1 otherwise
+      const float sr = sum_halves(nws_add_scalar(ar.x, ar.y) + nws_add_scalar(br.x, br.y));
+      const float sz = sum_halves(nws_add_scalar(az.x, az.y) + nws_add_scalar(bz.x, bz.y));
+      const float sn = sum_halves(nws_add_scalar(an.x, an.y) + nws_add_scalar(bn.x, bn.y));
       // both K-halves now hold the full sums; both evaluate the gates (no divergence), half 0 stores
       const float r = fast_sigmoid(ir + sr);
       const float z = fast_sigmoid(iz + sz);

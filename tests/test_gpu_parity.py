@@ -187,6 +187,7 @@ def test_forward_pipeline_matches_plain_forward(models, oracle):
     ref_orc = oracle[1](f0.cpu(), c.cpu(), pu.cpu(), nz.cpu()).numpy()
     for batched, kw in ((False, dict()),                                              # defaults: one audio, one control stream
                         (False, dict(depth=4, audio_streams=1, control_streams=2)),
+                        (False, dict(depth=4, audio_streams=2, control_streams=1)),
                         (True, dict(depth=2, audio_streams=1, control_streams=2))):
         pipe = nws_amd.ForwardPipeline(fast, batched_gru=batched, **kw)
         outs = [pipe.submit(f0, c, phase_u=pu, noise=nz) for f0, c, pu, nz in jobs]
@@ -200,7 +201,7 @@ def test_forward_pipeline_matches_plain_forward(models, oracle):
         assert worst <= (2e-5 if batched else 0.0), (batched, worst)
         assert e_orc <= 1e-4
     with pytest.raises(ValueError):
-        nws_amd.ForwardPipeline(fast, audio_streams=2)      # not safe on this stack: has to be asked for explicitly
+        nws_amd.ForwardPipeline(fast, depth=1)
     # default RNG path: draws come from the device generator in submit order
     torch.manual_seed(123)
     a1 = pipe.submit(jobs[0][0], jobs[0][1])
