@@ -40,8 +40,8 @@ MFMA_F16_FLOP_PER_SAMPLE_EXECUTED = 3 * 2 * 64 * 112
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU (weak scaling: fixed per-GPU work)")
     ap.add_argument("--frames", type=int, default=500, help="control frames per utterance (500 = 4 s @ 16 kHz)")
     ap.add_argument("--exact", action="store_true", help="exact sin-MLP shapers instead of the FastNEWT LUT")
@@ -52,10 +52,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=60)
     ap.add_argument("--batch1-iters", type=int, default=200)
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=2,
                     help="audio streams of the pipeline (or, with --pipeline 0, streams that whole forwards are issued on "
-                         "round-robin).  More than one audio stream is ~6 %% faster but produced wrong reverb output in soak "
-                         "tests on this stack (pipeline.py), so the default is one")
+                         "round-robin).  Two overlap the tail of batch i with the head of batch i+1 (~7 %%); this is the "
+                         "configuration that exposed the packed-fp32 / MFMA co-execution hazard the build now guards against "
+                         "(DESIGN.md 5.2) - the self-check below compares it with the plain forward bit for bit")
+    ap.add_argument("--depth", type=int, default=0, help="workspaces in flight (0: streams + 2)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="1: ForwardPipeline (control half = carries + GRU of batch i+1 on a side stream under the audio "
                          "half of batch i, --streams audio streams); 0: whole forwards round-robin on --streams streams")
@@ -146,9 +148,8 @@ def main():
     pipe = None
     if use_pipe:
         pmod = importlib.import_module("neural-waveshaping-synthesis_amd.pipeline")
-        pipe = pmod.ForwardPipeline(model, depth=2 * len(streams) + 2, audio_streams=len(streams),
-                                    allow_concurrent_audio=len(streams) > 1,
-                                    control_streams=max(1, a.control_streams), batched_gru=a.gru == "batched")
+        pipe = pmod.ForwardPipeline(model, depth=a.depth if a.depth > 0 else len(streams) + 2,
+                                    audio_streams=len(streams), control_streams=max(1, a.control_streams), batched_gru=a.gru == "batched")
         streams = pipe.audio
     nbuf = len(pipe.slots) if use_pipe else len(streams)
     full = [torch.empty((B * world, N), dtype=torch.float32, device=dev) for _ in range(nbuf)] if distributed else None
@@ -190,9 +191,13 @@ def main():
         for s in streams:
             torch.cuda.current_stream().wait_stream(s)
 
+    # Allocator priming, before the W warmup steps and untimed like them: every stream's caching-allocator pool and every
+    # workspace of the ring has to have been through one full cycle, or the first 2 * depth timed steps contain hipMallocs
+    # (measured: 1.2 ms/step instead of 0.47 for K = 50, W = 5 with 6 workspaces in flight).
+    priming = 2 * nbuf + 2
     with torch.no_grad():
         pending = None
-        for i in range(a.warmup):
+        for i in range(priming + a.warmup):
             pending = step(i, pending)
         if pending is not None:
             pending.wait()
@@ -342,7 +347,7 @@ def main():
         mfma_exec = MFMA_F16_FLOP_PER_SAMPLE_EXECUTED * B * N / (k_ms * 1e-3) / 1e12
         out = {
             "metric": "audio_samples_per_sec", "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "warmup": a.warmup, "priming_steps": priming, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"NEWT forward, vn checkpoint, {'exact sin-MLP shapers' if a.exact else 'FastNEWT LUT'}, "
                                    f"batch {B}/GPU x {T} frames (4 s @ 16 kHz), "

@@ -67,7 +67,9 @@ def check_packed_swizzles(obj):
     """MI355X co-execution hazard guard (csrc/coexec_probe.hip).
 
     v_pk_{add,mul,fma}_f32 with op_sel[1] = 1 (low lane <- high half of src1) returns wrong values while another kernel
-    runs K=16/32 f16 MFMAs on the same CU.  Returns [(kernel, instruction), ...] for every occurrence outside the probe."""
+    runs K=16/32 f16 MFMAs on the same CU.  The check is wider than what was measured: ANY vector instruction with
+    op_sel[1] = 1 is refused (packed f16, v_fma_mix*, dot products were not probed; no product kernel needs the form).
+    Returns [(kernel, instruction), ...] for every occurrence outside the probe."""
     import re
     found, kernel = [], None
     for line in device_disassembly(obj).splitlines():
@@ -75,7 +77,7 @@ def check_packed_swizzles(obj):
         if m:
             kernel = m.group(1)
             continue
-        m = re.search(r"\b(v_pk_(?:add|mul|fma)_f32)\b.*?op_sel:\[\d,(\d)", line)
+        m = re.search(r"\b(v_\w+)\b.*?op_sel:\[\d,(\d)", line)
         if m and m.group(2) == "1" and not any(a in (kernel or "") for a in SWIZZLE_ALLOW):
             found.append((kernel, " ".join(line.split("//")[0].split())))
     return found

@@ -5,7 +5,7 @@ reverb.  Everything but the GRU fills all 256 CUs; the GRU is a 500-step recurre
 batch size (B workgroups).  Whole forwards issued round-robin on several streams fall into lock-step (all streams in their
 GRU at once, then all in their oscillator).  `ForwardPipeline` instead issues the *control half* (carries + GRU) of batch
 i+1 on a side stream while the *audio half* of batch i occupies the GPU, with events for the hand-over and a small ring of
-workspaces: 0.62 -> 0.53 ms per 64 x 4 s batch on MI355X.  The kernels and their results are exactly those of
+workspaces: 0.76 ms (plain forwards) -> 0.51 (one audio stream) -> 0.46 ms (two) per 64 x 4 s batch on MI355X.  The kernels and their results are exactly those of
 `model(f0, control)`; only the issue order across batches changes.
 
     pipe = ForwardPipeline(model)
@@ -44,7 +44,7 @@ class _Slot:
 
 
 class ForwardPipeline:
-    def __init__(self, model, depth: int = 3, audio_streams: int = 1, control_streams: int = 1, batched_gru: bool = False,
+    def __init__(self, model, depth: int = 4, audio_streams: int = 2, control_streams: int = 1, batched_gru: bool = False,
                  allow_concurrent_audio: bool = False):
         if depth < 2 or audio_streams < 1 or control_streams < 1:
             raise ValueError("need depth >= 2 and at least one stream of each kind")
@@ -107,9 +107,11 @@ class ForwardPipeline:
             slot.ev_audio.record(au)
         slot.used = True
         slot.keep = (f0, control, pu, nz)        # inputs stay alive until the slot is reused
+        # outputs are only remembered for join_current_stream(): one ring's worth, so that the caching allocator sees a
+        # steady set of blocks after depth + 1 submissions instead of a sawtooth of live 4 * B * T * 128-byte waveforms
         self._outstanding.append((out, slot.ev_audio))
-        if len(self._outstanding) > 4 * len(self.slots):
-            self._outstanding = self._outstanding[-len(self.slots):]
+        if len(self._outstanding) > len(self.slots):
+            del self._outstanding[:-len(self.slots)]
         return out
 
     def join_current_stream(self):

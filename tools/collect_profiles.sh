@@ -12,8 +12,8 @@ BENCH="python $R/bench.py --no-cpu-baseline --batch1-iters 0"
 # 1. the default bench line (with cpu baseline, batch-1 and streaming extras)
 (cd $R && python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err")
 # 2. kernel traces + stats: default issue (pipeline, 2 audio streams) and one stream, no pipeline (undisturbed kernels)
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_default" -o bench -- $BENCH --steps 50 --warmup 5 > "$OUT/trace_default.log" 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_1stream" -o bench -- $BENCH --steps 50 --warmup 5 --pipeline 0 --streams 1 > "$OUT/trace_1stream.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_default" -o bench -- $BENCH --steps 200 --warmup 20 > "$OUT/trace_default.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_1stream" -o bench -- $BENCH --steps 200 --warmup 20 --pipeline 0 --streams 1 > "$OUT/trace_1stream.log" 2>&1
 # 3. counters, one stream, separate passes (never together with trace domains other than the kernel trace)
 P="$BENCH --steps 5 --warmup 2 --pipeline 0 --streams 1"
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o bench -- $P > /dev/null 2>&1
@@ -24,3 +24,9 @@ timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-fo
 cd $R
 python tools/pmc_digest.py "$OUT" > "$OUT/digest.log" 2>&1
 tail -30 "$OUT/digest.log"
+# 4. the co-execution hazard matrix (csrc/coexec_probe.hip)
+python tools/coexec_probe.py --json "$OUT/coexec_matrix.json" > "$OUT/coexec_matrix.txt" 2>&1
+tail -12 "$OUT/coexec_matrix.txt"
+# 5. parity report of the GPU suite
+python -m pytest tests -m gpu -q > "$OUT/pytest_gpu.log" 2>&1; tail -3 "$OUT/pytest_gpu.log"
+cp gpurun_out/parity_report.json "$OUT/parity_report.json" 2>/dev/null
