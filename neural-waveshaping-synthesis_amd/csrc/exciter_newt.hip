@@ -60,18 +60,14 @@ struct ShaperLds {
   float w6[512], b6[64];
 };
 
-// packed fast sine without range test: only for arguments bounded by construction (|sum_i w_i h_i + b| with |h_i| <= 1,
-// i.e. by the layer's weight norms, orders of magnitude below the 6e6 limit of the reduction)
-__device__ __forceinline__ f32x2 sin_pair_bounded(f32x2 x) {
-  const f32x2 c_hi = splat2(0.15915493667125702f), c_lo = splat2(6.4206382432985265e-09f);
-  const f32x2 p = x * c_hi;
-  const f32x2 e = fma2(x, c_hi, -p);
-  const f32x2 r = {rintf(p.x), rintf(p.y)};
-  const f32x2 t = (p - r) + fma2(x, c_lo, e);
-  return f32x2{__builtin_amdgcn_sinf(t.x), __builtin_amdgcn_sinf(t.y)};
-}
+// In-kernel exact shaper, fast form.  The weights of all four layers are staged in LDS pre-multiplied by 1/(2 pi)
+// (load_shaper_lds<true>), so that every pre-activation is already in TURNS and a sine is v_fract_f32 + v_sin_f32: no
+// range-reduction arithmetic, no magnitude test (the fract handles any magnitude an fp32 argument can resolve).  The scaled
+// weights carry one extra rounding (2^-24 relative), i.e. an argument error of the size of the reference's own rounding of
+// the same pre-activation; measured against the oracle in tests/test_gpu_parity.py like every other stage.
+__device__ __forceinline__ float sin_of_turns(float t) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(t)); }
 
-// one dense 8 -> 8 sine layer in packed fp32: out[o] = sin(b[o] + sum_i w[o][i] h[i]), weights transposed in LDS
+// one dense 8 -> 8 sine layer in packed fp32: out[o] = sin(2 pi (b[o] + sum_i w[o][i] h[i])), weights transposed in LDS
 __device__ __forceinline__ void sine_layer8(const float* __restrict__ wt, const float* __restrict__ bias,
                                             const f32x2 (&h)[4], f32x2 (&out)[4]) {
   const float4 b0 = *reinterpret_cast<const float4*>(bias), b1 = *reinterpret_cast<const float4*>(bias + 4);
@@ -86,20 +82,19 @@ __device__ __forceinline__ void sine_layer8(const float* __restrict__ wt, const 
     acc[3] = fma2(f32x2{wb.z, wb.w}, hi, acc[3]);
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) out[q] = sin_pair_bounded(acc[q]);
+  for (int q = 0; q < 4; ++q) out[q] = f32x2{sin_of_turns(acc[q].x), sin_of_turns(acc[q].y)};
 }
 
-// in-kernel exact shaper (TrainableNonlinearity, models/modules/shaping.py:36-37) on the packed-fp32 / v_sin_f32 path.
+// (TrainableNonlinearity, models/modules/shaping.py:36-37) on the packed-fp32 / v_sin_f32 path; W holds the SCALED weights.
 // Not inlined: 32 inlined copies in the unrolled tail push the kernel past 256 VGPRs into scratch.
 __device__ __noinline__ float exact_shaper(const ShaperLds& W, int s, float x) {
   const float a = W.in_scale[s] * x;
   const float4 wa = *reinterpret_cast<const float4*>(&W.w0[s * 8]), wb = *reinterpret_cast<const float4*>(&W.w0[s * 8 + 4]);
   const float4 ba = *reinterpret_cast<const float4*>(&W.b0[s * 8]), bb = *reinterpret_cast<const float4*>(&W.b0[s * 8 + 4]);
-  // first layer: the argument scales with the (unbounded) FiLM output -> range-checked sine
-  f32x2 h1[4] = {{nws_sinf_fast(fmaf(wa.x, a, ba.x)), nws_sinf_fast(fmaf(wa.y, a, ba.y))},
-                 {nws_sinf_fast(fmaf(wa.z, a, ba.z)), nws_sinf_fast(fmaf(wa.w, a, ba.w))},
-                 {nws_sinf_fast(fmaf(wb.x, a, bb.x)), nws_sinf_fast(fmaf(wb.y, a, bb.y))},
-                 {nws_sinf_fast(fmaf(wb.z, a, bb.z)), nws_sinf_fast(fmaf(wb.w, a, bb.w))}};
+  f32x2 h1[4] = {{sin_of_turns(fmaf(wa.x, a, ba.x)), sin_of_turns(fmaf(wa.y, a, ba.y))},
+                 {sin_of_turns(fmaf(wa.z, a, ba.z)), sin_of_turns(fmaf(wa.w, a, ba.w))},
+                 {sin_of_turns(fmaf(wb.x, a, bb.x)), sin_of_turns(fmaf(wb.y, a, bb.y))},
+                 {sin_of_turns(fmaf(wb.z, a, bb.z)), sin_of_turns(fmaf(wb.w, a, bb.w))}};
   f32x2 h2[4];
   sine_layer8(&W.w2t[s * 64], &W.b2[s * 8], h1, h2);
   sine_layer8(&W.w4t[s * 64], &W.b4[s * 8], h2, h1);
@@ -108,7 +103,7 @@ __device__ __noinline__ float exact_shaper(const ShaperLds& W, int s, float x) {
   acc = fma2(f32x2{va.z, va.w}, h1[1], acc);
   acc = fma2(f32x2{vb.x, vb.y}, h1[2], acc);
   acc = fma2(f32x2{vb.z, vb.w}, h1[3], acc);
-  return nws_sin_turns_checked(W.b6[s] + (acc.x + acc.y));
+  return sin_of_turns(W.b6[s] + nws_add_scalar(acc.x, acc.y));
 }
 
 // reference-grade variant (Cody-Waite polynomial sine, scalar): used to BUILD the FastNEWT table and by the stand-alone
@@ -138,22 +133,25 @@ __device__ __forceinline__ float exact_shaper_precise(const ShaperLds& W, int s,
   return nws_sinf(acc);
 }
 
+// TURNS: weights and biases of every layer times fl32(1 / (2 pi)) (exact_shaper above); in_scale stays as it is
+template <bool TURNS>
 __device__ __forceinline__ void load_shaper_lds(ShaperLds& L, const NwsWeights& w, int tid, int nthreads) {
+  const float c = TURNS ? 0.15915493667125702f : 1.0f;
   for (int i = tid; i < 64; i += nthreads) {
     L.in_scale[i] = w.shaper_in_scale[i];
-    L.b6[i] = w.shaper_b6[i];
+    L.b6[i] = w.shaper_b6[i] * c;
   }
   for (int i = tid; i < 512; i += nthreads) {
-    L.w0[i] = w.shaper_w0[i];
-    L.b0[i] = w.shaper_b0[i];
-    L.b2[i] = w.shaper_b2[i];
-    L.b4[i] = w.shaper_b4[i];
-    L.w6[i] = w.shaper_w6[i];
+    L.w0[i] = w.shaper_w0[i] * c;
+    L.b0[i] = w.shaper_b0[i] * c;
+    L.b2[i] = w.shaper_b2[i] * c;
+    L.b4[i] = w.shaper_b4[i] * c;
+    L.w6[i] = w.shaper_w6[i] * c;
   }
   for (int i = tid; i < 4096; i += nthreads) {  // i = (s*8 + o)*8 + in  ->  [s][in][o]
     const int sidx = i >> 6, o = (i >> 3) & 7, in = i & 7;
-    L.w2t[sidx * 64 + in * 8 + o] = w.shaper_w2[i];
-    L.w4t[sidx * 64 + in * 8 + o] = w.shaper_w4[i];
+    L.w2t[sidx * 64 + in * 8 + o] = w.shaper_w2[i] * c;
+    L.w4t[sidx * 64 + in * 8 + o] = w.shaper_w4[i] * c;
   }
 }
 
@@ -494,7 +492,7 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (HPB == 2 ? 7 :
       L.kf[64 + lane] = (float)(64 + lane);
     }
   }
-  if (MODE == kModeExact) load_shaper_lds(SH, w, tid, kThreads);
+  if (MODE == kModeExact) load_shaper_lds<true>(SH, w, tid, kThreads);
 
   // ---- per-sample phase: fp64 prefix sum -> fp32 rounding chain of the reference ----
   // (a second hop past the end of an odd-length utterance only helped with the staging above)
@@ -703,7 +701,7 @@ __global__ __launch_bounds__(256) void shaper_apply_kernel(NwsWeights w, const f
                                                            float* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   ShaperLds& SH = *reinterpret_cast<ShaperLds*>(smem_raw);
-  if (MODE == kModeExact) load_shaper_lds(SH, w, threadIdx.x, 256);
+  if (MODE == kModeExact) load_shaper_lds<false>(SH, w, threadIdx.x, 256);
   __syncthreads();
   const int64_t row = blockIdx.y;  // b*64 + s
   const int s = (int)(row & 63);
@@ -719,7 +717,7 @@ __global__ __launch_bounds__(256) void shaper_table_kernel(NwsWeights w, int siz
                                                            float* __restrict__ table) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   ShaperLds& SH = *reinterpret_cast<ShaperLds*>(smem_raw);
-  load_shaper_lds(SH, w, threadIdx.x, 256);
+  load_shaper_lds<false>(SH, w, threadIdx.x, 256);
   __syncthreads();
   const int s = blockIdx.y;
   // torch.linspace(min, max, size) in fp32 (ATen RangeFactories, symmetric form; bit-exact with the

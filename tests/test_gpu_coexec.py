@@ -60,3 +60,31 @@ def test_two_audio_streams_bit_exact_soak():
         pipe.synchronize()
         mismatching += sum(0 if torch.equal(o, ref) else 1 for o, ref in zip(outs, refs))
     assert mismatching == 0, f"{mismatching} of {rounds * n} batches differ from the plain forward"
+
+
+def test_torch_rng_draws_unchanged_beside_mfma_load():
+    """The two hidden draws of forward() come from torch's own kernels, which the build guard cannot inspect; in the pipeline
+    they run on the control stream beside the audio half's MFMA kernels.  Same seed -> same bits, with and without a
+    half-precision MFMA loop on the next stream."""
+    import nws_amd
+    _lib = nws_amd._lib
+    L = _lib.lib()
+    s_draw, s_load = torch.cuda.Stream(), torch.cuda.Stream()
+    sink = torch.zeros(256, device="cuda")
+    gen = torch.Generator(device="cuda")
+
+    def draws():
+        gen.manual_seed(7)
+        with torch.cuda.stream(s_draw):
+            out = [(torch.rand(101, device="cuda", generator=gen), torch.rand(63999, device="cuda", generator=gen))
+                   for _ in range(40)]
+        return out
+
+    ref = draws()
+    torch.cuda.synchronize()
+    for kind in (0, 1):
+        for _ in range(3):
+            _lib.check(L.nws_coexec_mfma_load(kind, 8192, 3000, sink.data_ptr(), s_load.cuda_stream), "load")
+            got = draws()
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, c) and torch.equal(b, d) for (a, b), (c, d) in zip(got, ref)), kind
