@@ -82,6 +82,9 @@ typedef struct NwsWeights {
   const float* shaper_b4; /* (512) */
   const float* shaper_w6; /* (64, 8)  net.6.weight */
   const float* shaper_b6; /* (64) */
+  const float* shaper_turns; /* optional (64, NWS_SHAPER_TURNS_ROW) from nws_shaper_turns(): all four layers of each shaper
+                                times 1/(2 pi), hidden layers transposed, read by scalar loads; NULL -> weights staged in
+                                LDS per workgroup (slower exact mode) */
   /* FastNEWT.lookup_table (models/modules/shaping.py:103-105); NULL selects the exact shapers */
   const float* lut;       /* (64, lut_size) */
   const float* lut_pairs; /* optional (64, lut_size, 2) from nws_lut_pairs(): {T[i], T[i+1]-T[i]}; NULL -> two gathers */
@@ -216,6 +219,10 @@ int nws_shaper_table(const NwsWeights* w, int table_size, float table_min, float
    (7 K-steps x 2 M-tiles x 2 halves x 32 lanes x 8 halfs, twice) */
 #define NWS_MIXER_FRAGS_BYTES 28672
 int nws_mixer_frags(const float* mixer_w, const float* mixer_b, void* frags_out, void* stream);
+/* Exact-mode companion of nws_lut_pairs: the TrainableNonlinearity weights (models/modules/shaping.py:15-37) of `w`
+ * (shaper_* fields) as the (64, NWS_SHAPER_TURNS_ROW) fp32 table the fused kernel's shaper bank reads. */
+#define NWS_SHAPER_TURNS_ROW 176
+int nws_shaper_turns(const NwsWeights* w, float* table_out /* device, 64 * NWS_SHAPER_TURNS_ROW floats */, void* stream);
 
 /* derived gather-friendly form of a FastNEWT table: pairs[s][i] = {table[s][i], fl(table[s][min(i+1,size-1)] - table[s][i])} */
 int nws_lut_pairs(const float* table /* (64, size) */, int table_size, float* pairs_out /* (64, size, 2) */, void* stream);

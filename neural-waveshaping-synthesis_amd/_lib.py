@@ -18,6 +18,7 @@ HOP = 128
 FIR_LEN = 256
 N_BANDS = 129
 FILM_CH = 256
+SHAPER_TURNS_ROW = 176
 FIR_DESIGN_COLS = 132
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -33,7 +34,7 @@ class NwsWeights(C.Structure):
         ("mlp_frags", _fp),
         ("shaper_in_scale", _fp),
         ("shaper_w0", _fp), ("shaper_b0", _fp), ("shaper_w2", _fp), ("shaper_b2", _fp),
-        ("shaper_w4", _fp), ("shaper_b4", _fp), ("shaper_w6", _fp), ("shaper_b6", _fp),
+        ("shaper_w4", _fp), ("shaper_b4", _fp), ("shaper_w6", _fp), ("shaper_b6", _fp), ("shaper_turns", _fp),
         ("lut", _fp), ("lut_pairs", _fp), ("lut_size", C.c_int32), ("lut_min", C.c_float), ("lut_max", C.c_float),
         ("newt_out_w", _fp), ("newt_out_b", _fp),
         ("noise_window", _fp),
@@ -79,6 +80,7 @@ _PROTOTYPES = {
     "nws_reverb": (C.c_int, [C.POINTER(NwsReverbPlan), _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, C.c_size_t, _fp]),
     "nws_shaper_table": (C.c_int, [C.POINTER(NwsWeights), C.c_int, C.c_float, C.c_float, _fp, _fp]),
     "nws_mixer_frags": (C.c_int, [_fp, _fp, _fp, _fp]),
+    "nws_shaper_turns": (C.c_int, [_fp, _fp, _fp]),
     "nws_lut_pairs": (C.c_int, [_fp, C.c_int, _fp, _fp]),
     "nws_shaper_apply": (C.c_int, [C.POINTER(NwsWeights), _fp, C.c_int64, C.c_int64, _fp, _fp]),
     "nws_forward_workspace_bytes": (C.c_size_t, [C.POINTER(NwsReverbPlan), C.c_int, C.c_int]),

@@ -31,7 +31,7 @@ constexpr int kTile = 128;                  // samples per workgroup (= control 
 constexpr float kTau = 6.283185307179586f;  // fl32(math.tau)
 constexpr float kPi = 3.141592653589793f;   // fl32(math.pi)
 
-enum Mode { kModeLut = 0, kModeExact = 1, kModeExciterOnly = 2, kModeLutPairs = 3, kModeLutPairsDiv6 = 4 };
+enum Mode { kModeLut = 0, kModeExact = 1, kModeExciterOnly = 2, kModeLutPairs = 3, kModeLutPairsDiv6 = 4, kModeExactBank = 5 };
 __host__ __device__ constexpr bool is_lut(int mode) {
   return mode == kModeLut || mode == kModeLutPairs || mode == kModeLutPairsDiv6;
 }
@@ -64,7 +64,7 @@ struct ShaperLds {
 // (load_shaper_lds<true>), so that every pre-activation is already in TURNS and a sine is v_fract_f32 + v_sin_f32: no
 // range-reduction arithmetic, no magnitude test (the fract handles any magnitude an fp32 argument can resolve).  The scaled
 // weights carry one extra rounding (2^-24 relative), i.e. an argument error of the size of the reference's own rounding of
-// the same pre-activation; measured against the oracle in tests/test_gpu_parity.py like every other stage.
+// the same pre-activation; held to the same parity bar as every other stage (tests/test_gpu_parity.py).
 __device__ __forceinline__ float sin_of_turns(float t) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(t)); }
 
 // one dense 8 -> 8 sine layer in packed fp32: out[o] = sin(2 pi (b[o] + sum_i w[o][i] h[i])), weights transposed in LDS
@@ -153,6 +153,71 @@ __device__ __forceinline__ void load_shaper_lds(ShaperLds& L, const NwsWeights& 
     L.w2t[sidx * 64 + in * 8 + o] = w.shaper_w2[i] * c;
     L.w4t[sidx * 64 + in * 8 + o] = w.shaper_w4[i] * c;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact shapers, bank form (kModeExactBank).  In the fused tail a lane holds 32 DIFFERENT shapers of one sample, so every
+// (sample, shaper) evaluation fetched its own 170 weights from LDS: 42 ds_read_b128 per evaluation, and the LDS return
+// path (not the sines) bounded the kernel.  Here the FiLM'ed shaper inputs of the workgroup's 128 samples go through LDS
+// once (xi[shaper][sample], 32 KB); then wave v evaluates shapers 16v .. 16v+15 with lane = sample, two samples per lane:
+// the shaper index is wave-uniform, its weights come from the nws_shaper_turns() table by SCALAR loads and feed the
+// VALU as SGPR operands - no LDS traffic for weights, no VGPRs for them either.  Per-wave partial sums of the 64 -> 1
+// mix meet in LDS.  Table row of shaper s (176 floats, every layer already times 1 / (2 pi)):
+//   [0,8) w0  [8,16) b0  [16,80) w2t[in][out]  [80,88) b2  [88,152) w4t[in][out]  [152,160) b4  [160,168) w6  168 b6  169 in_scale
+// ---------------------------------------------------------------------------------------------
+constexpr int kBankRow = NWS_SHAPER_TURNS_ROW;
+struct BankLds {
+  float xi[kS][kTile + 4];   // +4: the two M-tile halves of a store instruction land in different banks
+  float red[4][kTile];
+};
+
+__device__ __forceinline__ void bank_layer8(const float* __restrict__ wt, const float* __restrict__ bias,
+                                            const float (&h)[8], float (&out)[8]) {
+  f32x2 acc[4] = {{bias[0], bias[1]}, {bias[2], bias[3]}, {bias[4], bias[5]}, {bias[6], bias[7]}};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const f32x2 hi = splat2(h[i]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = fma2(f32x2{wt[8 * i + 2 * q], wt[8 * i + 2 * q + 1]}, hi, acc[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    out[2 * q] = sin_of_turns(acc[q].x);
+    out[2 * q + 1] = sin_of_turns(acc[q].y);
+  }
+}
+
+// W: wave-uniform pointer to the shaper's table row (scalar loads).  Every sine keeps its v_fract: a variant without it for
+// shapers whose hidden pre-activations provably stay inside v_sin_f32's +-256-turn domain was measured SLOWER (1.69 vs
+// 1.56 ms at B=64: two copies of the loop body, one uniform branch per shaper).
+__device__ __forceinline__ float bank_shaper(const float* __restrict__ W, float x) {
+  const float a = W[169] * x;
+  float h1[8], h2[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) h1[o] = sin_of_turns(fmaf(W[o], a, W[8 + o]));
+  bank_layer8(W + 16, W + 80, h1, h2);
+  bank_layer8(W + 88, W + 152, h2, h1);
+  float acc = W[168];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc = fmaf(W[160 + i], h1[i], acc);
+  return sin_of_turns(acc);
+}
+
+__global__ void shaper_turns_kernel(NwsWeights w, float* __restrict__ out) {
+  const int s = blockIdx.x, k = threadIdx.x;
+  if (k >= kBankRow) return;
+  const float c = 0.15915493667125702f;  // fl32(1 / (2 pi))
+  float v = 0.0f;
+  if (k < 8) v = w.shaper_w0[s * 8 + k] * c;
+  else if (k < 16) v = w.shaper_b0[s * 8 + k - 8] * c;
+  else if (k < 80) v = w.shaper_w2[(s * 8 + ((k - 16) & 7)) * 8 + ((k - 16) >> 3)] * c;   // [in][out] <- weight[s*8+out][in]
+  else if (k < 88) v = w.shaper_b2[s * 8 + k - 80] * c;
+  else if (k < 152) v = w.shaper_w4[(s * 8 + ((k - 88) & 7)) * 8 + ((k - 88) >> 3)] * c;
+  else if (k < 160) v = w.shaper_b4[s * 8 + k - 152] * c;
+  else if (k < 168) v = w.shaper_w6[s * 8 + k - 160] * c;
+  else if (k == 168) v = w.shaper_b6[s] * c;
+  else if (k == 169) v = w.shaper_in_scale[s];
+  out[s * kBankRow + k] = v;
 }
 
 // FastNEWT.shaping_fn (models/modules/shaping.py:136-151), quirks kept: index scale size/(max-min)
@@ -385,14 +450,15 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 // (0.328 ms).  (Wrong results seen with that build under two overlapping audio streams were first blamed on the scratch;
 // the multi-stream problem turned out to be independent of it, see pipeline.py.  The build still rejects scratch.)
 template <int MODE, int DBG = 0, int HPB = 1>
-__global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (HPB == 2 ? 7 : 5)) void exciter_newt_kernel(NwsWeights w, const float* __restrict__ f0,
+__global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeExactBank ? 3 : (HPB == 2 ? 7 : 5))) void exciter_newt_kernel(NwsWeights w, const float* __restrict__ f0,
                                                            const float* __restrict__ f0_up,
                                                            const double* __restrict__ carry,
                                                            const float* __restrict__ phase_u,
                                                            const float* __restrict__ rand_phase,
                                                            const float* __restrict__ film, int T, float sample_rate,
                                                            float* __restrict__ exciter_out,
-                                                           float* __restrict__ newt_out) {
+                                                           float* __restrict__ newt_out,
+                                                           const float* __restrict__ bank = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   ExcLds& L = *reinterpret_cast<ExcLds*>(smem_raw);
   ShaperLds& SH = *reinterpret_cast<ShaperLds*>(smem_raw + ((sizeof(ExcLds) + 15) & ~size_t(15)));
@@ -672,6 +738,12 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (HPB == 2 ? 7 :
         const f32x2 g_n = fma2(w1_2, NWS_PAIR(fd[2]), NWS_PAIR(fa[2]));  // already times newt.mixer.weight
         const f32x2 xi = fma2(g_i, x2, b_i);  // FiLM (models/modules/dynamic.py:8)
         f32x2 sh;
+        if (MODE == kModeExactBank) {
+          BankLds& BK = *reinterpret_cast<BankLds*>(&SH);
+          BK.xi[s4 + 2 * h2][32 * w4 + col] = xi.x;
+          BK.xi[s4 + 2 * h2 + 1][32 * w4 + col] = xi.y;
+          continue;
+        }
         if (DBG == 2) {
           sh = xi;
         } else if (MODE == kModeLutPairsDiv6) {
@@ -687,6 +759,37 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (HPB == 2 ? 7 :
       // fence the scheduler per group of 4 shapers: bounded number of gathers / FiLM operands live at once
       __builtin_amdgcn_sched_barrier(0);
     }
+  }
+  if (MODE == kModeExactBank) {
+    BankLds& BK = *reinterpret_cast<BankLds*>(&SH);
+    __syncthreads();
+    // wave v: shapers 16v .. 16v+15; lane: samples `lane` and 64 + `lane` of the hop (frame pairs (j-1, j) and (j, j+1))
+    const int n_a = jb * kTile + lane, n_b = n_a + 64;
+    const NwsLerp la = nws_lerp_coeff(n_a, T), lb = nws_lerp_coeff(n_b, T);
+    const int qa = la.i0 - (jb - 1), qb = lb.i0 - (jb - 1);
+    const int sv = __builtin_amdgcn_readfirstlane(16 * wave);
+    float pa = 0.0f, pb = 0.0f;
+#pragma unroll 1
+    for (int k = 0; k < 16; ++k) {
+      const int sh_idx = sv + k;
+      const float* __restrict__ W = bank + (size_t)sh_idx * kBankRow;   // a __restrict__ kernel argument: scalar loads
+      const float ya = bank_shaper(W, BK.xi[sh_idx][lane]);
+      const float yb = bank_shaper(W, BK.xi[sh_idx][64 + lane]);
+      pa = fmaf(fmaf(la.w1, L.fd[qa][2][sh_idx], L.fa[qa][2][sh_idx]), ya, pa);   // normalising FiLM gain x newt.mixer weight
+      pb = fmaf(fmaf(lb.w1, L.fd[qb][2][sh_idx], L.fa[qb][2][sh_idx]), yb, pb);
+    }
+    BK.red[wave][lane] = pa;
+    BK.red[wave][64 + lane] = pb;
+    __syncthreads();
+    if (tid < kTile) {
+      const int n_o = jb * kTile + tid;
+      const NwsLerp lo = nws_lerp_coeff(n_o, T);
+      const int qo = lo.i0 - (jb - 1);
+      const float sum = (BK.red[0][tid] + BK.red[1][tid]) + (BK.red[2][tid] + BK.red[3][tid]);
+      const float bias_o = fmaf(lo.w1, L.bsum[qo + 1] - L.bsum[qo], L.bsum[qo]);
+      newt_out[(size_t)b * N + n_o] = sum + (bias_o + w.newt_out_b[0]);
+    }
+    return;
   }
   const float partial = part2.x + part2.y;
   // the normalising FiLM biases went through the mixer per FRAME: interpolate their sum like any other parameter
@@ -882,6 +985,15 @@ int nws_mixer_frags(const float* mixer_w, const float* mixer_b, void* frags_out,
   return NWS_OK;
 }
 
+int nws_shaper_turns(const NwsWeights* w, float* table_out, void* stream) {
+  if (!w || !table_out || !w->shaper_in_scale || !w->shaper_w0 || !w->shaper_b0 || !w->shaper_w2 || !w->shaper_b2 ||
+      !w->shaper_w4 || !w->shaper_b4 || !w->shaper_w6 || !w->shaper_b6)
+    return NWS_ERR_BAD_ARG;
+  shaper_turns_kernel<<<NWS_N_SHAPERS, 192, 0, (hipStream_t)stream>>>(*w, table_out);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
 int nws_lut_pairs(const float* table, int table_size, float* pairs_out, void* stream) {
   if (!table || !pairs_out || table_size < 2) return NWS_ERR_BAD_ARG;
   const dim3 grid((table_size + 255) / 256, NWS_N_SHAPERS);
@@ -937,8 +1049,12 @@ int nws_exciter_newt(const NwsWeights* w, const float* f0, const float* f0_up, c
                                                                sample_rate, exciter_out, newt_out);
     } else {
       if (!w->shaper_w0 || !w->shaper_w2 || !w->shaper_w4 || !w->shaper_w6) return NWS_ERR_BAD_ARG;
-      exciter_newt_kernel<kModeExact><<<grid, 256, base + sizeof(ShaperLds), st>>>(
-          *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out);
+      if (w->shaper_turns != nullptr)
+        exciter_newt_kernel<kModeExactBank><<<grid, 256, base + sizeof(BankLds), st>>>(
+            *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out, w->shaper_turns);
+      else
+        exciter_newt_kernel<kModeExact><<<grid, 256, base + sizeof(ShaperLds), st>>>(
+            *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out);
     }
   }
   NWS_CHECK_LAUNCH();

@@ -121,6 +121,10 @@ class Engine:
             w.shaper_b4 = P(sh.net[4].bias, "newt.shaping_fn.net.4.bias", 512)
             w.shaper_w6 = P(sh.net[6].weight, "newt.shaping_fn.net.6.weight", 512)
             w.shaper_b6 = P(sh.net[6].bias, "newt.shaping_fn.net.6.bias", 64)
+            turns = torch.empty((64, _lib.SHAPER_TURNS_ROW), dtype=torch.float32, device=keep[-1].device)
+            check(_lib.lib().nws_shaper_turns(C.byref(w), ptr(turns), stream_ptr()), "nws_shaper_turns")
+            keep.append(turns)
+            w.shaper_turns = turns.data_ptr()
         table = getattr(m.newt, "lookup_table", None)
         if table is not None:
             size = int(m.newt.table_size)

@@ -732,3 +732,31 @@ def test_e2e_random_init_weights(seed):
     # LUT: the table itself inherits that argument sensitivity; extrapolation multiplies table differences by up to
     # |fract| ~ 1e3, so compare relative to the (large) output level
     assert ef <= 2e-3 * max(1.0, rms(ref_f)), (ef, rms(ref_f))
+
+
+def test_exact_shaper_bank_large_output_layer():
+    """Exact mode, shaper-bank kernel: an output layer so large that its pre-activation leaves v_sin_f32's +-256-turn input
+    domain (the kernel's v_fract has to bring it back).  Arguments of ~2e3 rad resolve to ~1e-4 rad in fp32 and the
+    oracle's conv1d sums round differently from an FMA chain, so the bar is loose; what it must catch is zeros or garbage
+    instead of sines."""
+    import nws_amd as nws
+    from oracle.newt_oracle import OracleNEWT
+
+    nws.ensure_default_config()
+    torch.manual_seed(3)
+    m = nws.NeuralWaveshaping()
+    with torch.no_grad():
+        m.reverb.ir.mul_(1e5)
+        m.newt.shaping_fn.net[6].weight.mul_(3000.0)      # 8 x ~0.2 x 3000 rad ~ 700 turns
+    weights = {k: v.detach().clone().numpy() for k, v in m.state_dict().items()}
+    m = m.cuda().eval()
+    g = torch.Generator().manual_seed(4)
+    T = 24
+    f0 = 100 + 500 * torch.rand(2, 1, T, generator=g)
+    control = torch.randn(2, 2, T, generator=g)
+    pu, nz = torch.rand(101, generator=g), torch.rand(128 * T - 1, generator=g)
+    ref = OracleNEWT(weights, fast=False)(f0, control, pu, nz).numpy()
+    y = m(f0.cuda(), control.cuda(), phase_u=pu.cuda(), noise=nz.cuda()).cpu().numpy()
+    rel = rms(y - ref) / rms(ref)
+    record("exact_bank_large_output_layer", rel_rms_err=rel, out_rms=rms(ref))
+    assert np.isfinite(y).all() and rel <= 0.02, rel
