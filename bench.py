@@ -191,10 +191,13 @@ def main():
         for s in streams:
             torch.cuda.current_stream().wait_stream(s)
 
-    # Allocator priming, before the W warmup steps and untimed like them: every stream's caching-allocator pool and every
-    # workspace of the ring has to have been through one full cycle, or the first 2 * depth timed steps contain hipMallocs
-    # (measured: 1.2 ms/step instead of 0.47 for K = 50, W = 5 with 6 workspaces in flight).
-    priming = 2 * nbuf + 2
+    # Priming, before the W warmup steps and untimed like them (reported as priming_steps): (1) every stream's caching-
+    # allocator pool and every workspace of the ring has to have been through one full cycle, or the first 2 * depth timed
+    # steps contain hipMallocs (measured: 1.2 ms/step instead of 0.47 for K = 50, W = 5 with 6 workspaces in flight);
+    # (2) ~50 ms of continuous load before the clock starts helps short runs a little (K = 50: 0.504 -> 0.491 ms/step).
+    # What stays inside the timed region by construction is the pipeline's fill and drain (first control half, last audio
+    # half: 0.5-1 ms per timed region): 0.518 ms/step at K = 10, 0.491 at 50, 0.471 at 200, 0.468 at 1000.
+    priming = max(2 * nbuf + 2, 120)
     with torch.no_grad():
         pending = None
         for i in range(priming + a.warmup):
