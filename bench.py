@@ -62,8 +62,9 @@ def parse():
                     help="1: ForwardPipeline (control half = carries + GRU of batch i+1 on a side stream under the audio "
                          "half of batch i, --streams audio streams); 0: whole forwards round-robin on --streams streams")
     ap.add_argument("--control-streams", type=int, default=1,
-                    help="side streams for the control half (two were no faster with one audio stream, and slower beside RCCL: "
-                         "0.62 vs 0.51 ms/step with the all-gather in the loop)")
+                    help="side streams for the control half (two change nothing for rand inputs, help the GRU-bound realistic-"
+                         "input case by 7 %% (0.392 -> 0.364 ms/step) and hurt beside RCCL: 0.62 vs 0.48 ms/step with the "
+                         "all-gather in the loop)")
     ap.add_argument("--gru", choices=("batched", "per-utterance"), default="per-utterance",
                     help="GRU kernel of the pipeline's control half (the plain forward always uses per-utterance)")
     return ap.parse_args()

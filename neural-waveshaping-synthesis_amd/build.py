@@ -19,8 +19,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 # -fno-slp-vectorize: the SLP vectoriser turns scalar fp32 code into packed instructions with operand swizzles of its own
 # choosing, among them the form that misbehaves beside another kernel's f16 MFMAs (see check_packed_swizzles below);
 # packed arithmetic is written explicitly (f32x2) where it pays.  Two files keep the vectoriser (the guard checks every
-# file anyway): fir_noise.hip, whose MFMA kernel sits at its register budget and only gets the harmless low-broadcast form
-# from it, and control_gru.hip, whose batched MFMA kernel was validated with it (its horizontal sums are scalar by hand).
+# file anyway) because an MFMA kernel in each sits at its register budget and spills without it: fir_noise.hip (only
+# receives the harmless low-broadcast form) and control_gru.hip (batched kernel; the per-utterance kernel's horizontal
+# sums are scalar by hand).
 KEEP_SLP = ("fir_noise.hip", "control_gru.hip")
 EXTRA_FLAGS = {src: ["-fno-slp-vectorize"] for src in SOURCES if src not in KEEP_SLP}
 LLVM_BIN = "/opt/rocm/lib/llvm/bin"

@@ -168,9 +168,14 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+// Two-term fp16 split of a set-up constant.  The residual of a small weight is an fp16 SUBNORMAL (|lo| < 2^-14 for
+// |w| < 2^-3); it must survive: v_cvt_f16_f32 produces it, whereas v_fma_mixlo_f16 - which the compiler picks for
+// "(half)(v - (float)hi)" when the SLP vectoriser is off - flushes it to zero, and the recurrence then ran with ~12-bit
+// weights (error 2e-2 instead of 1.5e-3 against a float64 GRU on the B=40, T=300 test).  Hence the explicit instruction.
 __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
   hi = (_Float16)v;
-  lo = (_Float16)(v - (float)hi);
+  const float d = v - (float)hi;
+  asm("v_cvt_f16_f32 %0, %1" : "=v"(lo) : "v"(d));
 }
 
 __global__ __launch_bounds__(512, 1) void control_gru_mfma_kernel(NwsWeights w, const float* __restrict__ control, int B,

@@ -44,11 +44,9 @@ class _Slot:
 
 
 class ForwardPipeline:
-    def __init__(self, model, depth: int = 4, audio_streams: int = 2, control_streams: int = 1, batched_gru: bool = False,
-                 allow_concurrent_audio: bool = False):
+    def __init__(self, model, depth: int = 4, audio_streams: int = 2, control_streams: int = 1, batched_gru: bool = False):
         if depth < 2 or audio_streams < 1 or control_streams < 1:
             raise ValueError("need depth >= 2 and at least one stream of each kind")
-        del allow_concurrent_audio      # accepted for compatibility: concurrency no longer needs an opt-in (module docstring)
         self.model = model
         self.eng = model._engine
         _, _, dev = self.eng.weights()
