@@ -5,8 +5,8 @@ reverb.  Everything but the GRU fills all 256 CUs; the GRU is a 500-step recurre
 batch size (B workgroups).  Whole forwards issued round-robin on several streams fall into lock-step (all streams in their
 GRU at once, then all in their oscillator).  `ForwardPipeline` instead issues the *control half* (carries + GRU) of batch
 i+1 on a side stream while the *audio half* of batch i occupies the GPU, with events for the hand-over and a small ring of
-workspaces: 0.76 ms (plain forwards) -> 0.51 (one audio stream) -> 0.46 ms (two) per 64 x 4 s batch on MI355X.  The kernels and their results are exactly those of
-`model(f0, control)`; only the issue order across batches changes.
+workspaces: 0.76 ms (plain forwards) -> 0.51 (one audio stream) -> 0.46 ms (two) per 64 x 4 s batch on MI355X.  The kernels
+and their results are exactly those of `model(f0, control)`; only the issue order across batches changes.
 
     pipe = ForwardPipeline(model)
     outs = [pipe.submit(f0_i, control_i) for ...]     # asynchronous; draws the reference's two RNG vectors per batch
