@@ -30,3 +30,8 @@ tail -12 "$OUT/coexec_matrix.txt"
 # 5. parity report of the GPU suite
 python -m pytest tests -m gpu -q > "$OUT/pytest_gpu.log" 2>&1; tail -3 "$OUT/pytest_gpu.log"
 cp gpurun_out/parity_report.json "$OUT/parity_report.json" 2>/dev/null
+# 6. other bench configurations (one line each) and a long bit-exact soak of the default pipeline
+(python bench.py --no-cpu-baseline --inputs realistic | grep '^{' > "$OUT/bench_realistic_inputs.json") 2>/dev/null
+(python bench.py --no-cpu-baseline --exact | grep '^{' > "$OUT/bench_exact_shapers.json") 2>/dev/null
+(NWS_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline | grep '^{' > "$OUT/bench_world1_rccl.json") 2>/dev/null
+python tools/soak_pipeline.py --rounds 250 > "$OUT/soak_pipeline.json" 2>/dev/null; cat "$OUT/soak_pipeline.json"
