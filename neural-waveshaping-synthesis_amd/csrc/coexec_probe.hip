@@ -69,6 +69,68 @@ __global__ __launch_bounds__(256) void pk_probe_kernel(int iters, unsigned* __re
     if (bad[k]) atomicAdd(&report[k], bad[k]);
 }
 
+// Second probe: the same question for the other VOP3P families and for a scalar-register second operand.  Every swizzled form
+// is checked against the PLAIN form of the same instruction on operands that were swizzled beforehand with integer moves.
+//  0 v_pk_add_f16 src1 halves swapped      1 v_pk_fma_f16 src1 halves swapped     2 v_pk_mul_f16 src1 high half broadcast
+//  3 v_fma_mix_f32 src1 = high fp16 half    4 v_fma_mixlo_f16 src1 = high fp16 half
+//  5 v_pk_add_f32 src1 = SGPR pair, high broadcast    6 v_pk_mul_f32 src1 = SGPR pair, swapped    7 v_pk_add_f16 plain (control)
+__global__ __launch_bounds__(256) void pk_probe2_kernel(int iters, unsigned* __restrict__ report) {
+  const int tid = threadIdx.x;
+  unsigned bad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // packed fp16 operands as raw 32-bit words: {lo, hi}
+  unsigned a = 0x3c003800u + (unsigned)tid * 0x00010003u;       // ~{0.5.., 1.0..}
+  unsigned b = 0x34003a00u + (unsigned)(blockIdx.x & 63) * 0x00030001u;
+  unsigned c = 0x2e663266u;
+  float2 fa = make_float2(0.37f + 0.001f * (float)tid, -1.21f + 0.002f * (float)(blockIdx.x & 63));
+  float fc = 0.125f;
+  for (int it = 0; it < iters; ++it) {
+    const unsigned b_sw = (b >> 16) | (b << 16);      // halves swapped
+    const unsigned b_hh = (b >> 16) | (b & 0xffff0000u);  // high half in both
+    unsigned d, r;
+    asm volatile("v_pk_add_f16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+    asm volatile("v_pk_add_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b_sw));
+    bad[0] += d != r;
+    asm volatile("v_pk_fma_f16 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b_sw), "v"(c));
+    bad[1] += d != r;
+    asm volatile("v_pk_mul_f16 %0, %1, %2 op_sel:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b_hh));
+    bad[2] += d != r;
+    float df, rf;
+    asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(df) : "v"(a), "v"(b), "v"(fc));
+    asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "=v"(rf) : "v"(a), "v"(b_sw), "v"(fc));
+    bad[3] += __float_as_uint(df) != __float_as_uint(rf);
+    d = 0u; r = 0u;
+    asm volatile("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "+v"(d) : "v"(a), "v"(b), "v"(fc));
+    asm volatile("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "+v"(r) : "v"(a), "v"(b_sw), "v"(fc));
+    bad[4] += d != r;
+    // scalar-register pair as second operand (wave-uniform values)
+    const float s_lo = 0.75f + 0.001f * (float)(it & 31), s_hi = -0.3125f + 0.002f * (float)(it & 15);
+    const unsigned long long sp = ((unsigned long long)__float_as_uint(s_hi) << 32) | __float_as_uint(s_lo);
+    const unsigned long long spu = __builtin_amdgcn_readfirstlane((unsigned)sp) |
+                                   ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(sp >> 32)) << 32);
+    float2 d2;
+    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(d2) : "v"(fa), "s"(spu));
+    bad[5] += ((d2.x != sadd(fa.x, s_hi)) || (d2.y != sadd(fa.y, s_hi))) ? 1u : 0u;
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d2) : "v"(fa), "s"(spu));
+    bad[6] += ((d2.x != smul(fa.x, s_hi)) || (d2.y != smul(fa.y, s_lo))) ? 1u : 0u;
+    // control: the plain packed f16 add against two scalar halves
+    asm volatile("v_pk_add_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    {
+      unsigned lo, hi;
+      asm volatile("v_add_f16 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+      asm volatile("v_add_f16 %0, %1, %2" : "=v"(hi) : "v"(a >> 16), "v"(b >> 16));
+      bad[7] += d != ((lo & 0xffffu) | (hi << 16));
+    }
+    // next operands: small integer steps keep the fp16 fields finite and varied
+    a = (a & 0x7bff7bffu) ^ ((d & 0x000f000fu) | 0x30003000u);
+    b = (b & 0x7bff7bffu) ^ ((unsigned)it * 0x00050003u & 0x00ff00ffu);
+    fa = make_float2(sfma(fa.x, 0.9993f, 0.0007f), sfma(fa.y, 0.9989f, -0.0003f));
+  }
+  for (int k = 0; k < 8; ++k)
+    if (bad[k]) atomicAdd(&report[k], bad[k]);
+}
+
 // KIND 0: v_mfma_f32_32x32x16_f16   1: v_mfma_f32_16x16x32_f16   2: v_mfma_f32_32x32x8f16   3: v_mfma_f32_32x32x2f32
 template <int KIND>
 __global__ __launch_bounds__(256, 4) void mfma_load_kernel(int iters, float* __restrict__ sink) {
@@ -106,6 +168,13 @@ extern "C" {
 int nws_coexec_pk_probe(int blocks, int iters, unsigned* report, void* stream) {
   if (blocks <= 0 || iters <= 0 || !report) return NWS_ERR_BAD_ARG;
   pk_probe_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(iters, report);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+int nws_coexec_pk_probe2(int blocks, int iters, unsigned* report, void* stream) {
+  if (blocks <= 0 || iters <= 0 || !report) return NWS_ERR_BAD_ARG;
+  pk_probe2_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(iters, report);
   NWS_CHECK_LAUNCH();
   return NWS_OK;
 }

@@ -17,6 +17,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 
 FORMS = ["pk_fma plain", "pk_add src0 swap", "pk_add src1 lo-bcast", "pk_fma src2 swap+neg",
          "pk_add src1 swap", "pk_add src1 hi-bcast", "pk_mul src1 swap", "pk_fma src1 swap"]
+FORMS2 = ["pk_add_f16 src1 swap", "pk_fma_f16 src1 swap", "pk_mul_f16 src1 hi-bcast", "fma_mix_f32 src1 hi", "fma_mixlo_f16 src1 hi",
+          "pk_add_f32 SGPR hi-bcast", "pk_mul_f32 SGPR swap", "pk_add_f16 plain"]
 LOADS = {"none": None, "v_mfma_f32_32x32x16_f16": 0, "v_mfma_f32_16x16x32_f16": 1, "v_mfma_f32_32x32x8f16": 2,
          "v_mfma_f32_32x32x2f32": 3}
 
@@ -51,16 +53,18 @@ def run(blocks=4096, iters=2000, rounds=5, product_kernels=True):
         loads["product: frame_mlps16_kernel x3"] = with_stream(lambda: [eng.frame_mlps(gru) for _ in range(3)])
         loads["product: fir_noise_mfma_kernel x4"] = with_stream(lambda: [eng.fir_noise(fir, nz, add_in=newt) for _ in range(4)])
         loads["product: control_gru_kernel"] = with_stream(lambda: eng.control_gru(c))
-    out = {}
-    for name, load in loads.items():
-        report.zero_()
-        torch.cuda.synchronize()
-        for _ in range(rounds):
-            _lib.check(L.nws_coexec_pk_probe(blocks, iters, report.data_ptr(), s_probe.cuda_stream), "probe")
-            load()
+    out, out2 = {}, {}
+    for probe, dst in ((L.nws_coexec_pk_probe, out), (L.nws_coexec_pk_probe2, out2)):
+        for name, load in loads.items():
+            report.zero_()
             torch.cuda.synchronize()
-        out[name] = [int(v) for v in report.cpu().numpy().astype("uint32")]
-    return {"forms": FORMS, "evaluations_per_form": blocks * 256 * iters * rounds, "wrong_results": out}
+            for _ in range(rounds):
+                _lib.check(probe(blocks, iters, report.data_ptr(), s_probe.cuda_stream), "probe")
+                load()
+                torch.cuda.synchronize()
+            dst[name] = [int(v) for v in report.cpu().numpy().astype("uint32")]
+    return {"forms": FORMS, "evaluations_per_form": blocks * 256 * iters * rounds, "wrong_results": out,
+            "forms_other_families": FORMS2, "wrong_results_other_families": out2}
 
 
 if __name__ == "__main__":
@@ -71,6 +75,9 @@ if __name__ == "__main__":
     print(f"evaluations per form and row: {r['evaluations_per_form']:.3g}")
     print(f"{'running beside':36s} " + " ".join(f"{f[:12]:>12s}" for f in r["forms"]))
     for k, v in r["wrong_results"].items():
+        print(f"{k:36s} " + " ".join(f"{x:12d}" for x in v))
+    print(f"{'other families, running beside':36s} " + " ".join(f"{f[:12]:>12s}" for f in r["forms_other_families"]))
+    for k, v in r["wrong_results_other_families"].items():
         print(f"{k:36s} " + " ".join(f"{x:12d}" for x in v))
     if a.json:
         json.dump(r, open(a.json, "w"), indent=1)
