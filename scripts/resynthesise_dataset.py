@@ -1,10 +1,13 @@
 #!/usr/bin/env python
 """Batched offline rendering of a control-feature dataset to wav files on MI355X (one process per GPU under
 torchrun: the item list is sharded round-robin, every rank writes its own files, no collective).
+The forward of batch i+1 is enqueued before the waveforms of batch i are fetched, and the wav files are written by a small
+thread pool, so that the GPU, the device-to-host copy and the file system work concurrently.
 
     python scripts/resynthesise_dataset.py --model-checkpoint ckpt --dataset-root data/ --use-fastnewt
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/resynthesise_dataset.py ...
 """
+import concurrent.futures as cf
 import importlib
 import os
 import sys
@@ -45,14 +48,31 @@ def main(model_gin, model_checkpoint, dataset_root, dataset_split, output_path, 
     model = model.to(dev)
     mine = data.shard(rank, world)
     t0, n_samples = time.time(), 0
-    with torch.no_grad():
+    sr = int(model.sample_rate)
+    writes = []
+
+    def collect(item, pool):     # blocks until that batch's kernels are done, then hands the files to the writers
+        out_dev, batch = item
+        out = out_dev.cpu().numpy()
+        for j, name in enumerate(batch["names"]):
+            writes.append(pool.submit(wavfile.write, os.path.join(output_path, f"{name}.output.wav"), sr, out[j]))
+            if write_targets and batch["audio"][j] is not None:
+                writes.append(pool.submit(wavfile.write, os.path.join(output_path, f"{name}.target.wav"), sr, batch["audio"][j]))
+        return out.size
+
+    with torch.no_grad(), cf.ThreadPoolExecutor(max_workers=4) as pool:
+        in_flight = None
         for batch in data.batches(mine, batch_size):
-            out = model(torch.from_numpy(batch["f0"]).to(dev), torch.from_numpy(batch["control"]).to(dev)).cpu().numpy()
-            n_samples += out.size
-            for j, name in enumerate(batch["names"]):
-                wavfile.write(os.path.join(output_path, f"{name}.output.wav"), int(model.sample_rate), out[j])
-                if write_targets and batch["audio"][j] is not None:
-                    wavfile.write(os.path.join(output_path, f"{name}.target.wav"), int(model.sample_rate), batch["audio"][j])
+            f0 = torch.from_numpy(batch["f0"]).to(dev, non_blocking=True)
+            control = torch.from_numpy(batch["control"]).to(dev, non_blocking=True)
+            nxt = (model(f0, control), batch)      # asynchronous: only enqueues the kernels
+            if in_flight is not None:
+                n_samples += collect(in_flight, pool)
+            in_flight = nxt
+        if in_flight is not None:
+            n_samples += collect(in_flight, pool)
+        for w in writes:
+            w.result()                              # surface write errors
     dt = time.time() - t0
     print(f"[rank {rank}/{world}] rendered {len(mine)} items, {n_samples} samples in {dt:.2f} s "
           f"({n_samples / max(dt, 1e-9) / 16000.0:.0f}x real-time incl. file I/O)")
