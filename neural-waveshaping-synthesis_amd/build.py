@@ -68,8 +68,9 @@ def check_packed_swizzles(obj):
     """MI355X co-execution hazard guard (csrc/coexec_probe.hip).
 
     v_pk_{add,mul,fma}_f32 with op_sel[1] = 1 (low lane <- high half of src1) returns wrong values while another kernel
-    runs K=16/32 f16 MFMAs on the same CU.  The check is wider than what was measured: ANY vector instruction with
-    op_sel[1] = 1 is refused (packed f16, v_fma_mix*, dot products were not probed; no product kernel needs the form).
+    runs K=16/32 f16 MFMAs on the same CU.  The check is wider than what was seen to fail: ANY vector instruction with
+    op_sel[1] = 1 is refused (packed fp16, v_fma_mix* and scalar-register operands probed clean; no product kernel needs
+    those forms either, so the guard stays simple).
     Returns [(kernel, instruction), ...] for every occurrence outside the probe."""
     import re
     found, kernel = [], None
