@@ -760,3 +760,36 @@ def test_exact_shaper_bank_large_output_layer():
     rel = rms(y - ref) / rms(ref)
     record("exact_bank_large_output_layer", rel_rms_err=rel, out_rms=rms(ref))
     assert np.isfinite(y).all() and rel <= 0.02, rel
+
+
+def test_exact_shaper_lds_fallback_matches_bank(models, oracle):
+    """The fused kernel has two exact-shaper tails: the shaper bank (weights by scalar loads from the nws_shaper_turns table,
+    what the engine uses) and the fallback a C-ABI caller gets when NwsWeights.shaper_turns is NULL (weights staged in LDS
+    per workgroup).  Same arithmetic in a different order: they must agree to rounding, and both with the oracle's stage."""
+    import ctypes as C
+    import nws_amd
+    _lib = nws_amd._lib
+    m, _ = models
+    eng = m._engine
+    w, _, dev = eng.weights()
+    assert w.shaper_turns, "the engine is expected to provide the table"
+    w2 = _lib.NwsWeights.from_buffer_copy(w)
+    w2.shaper_turns = None
+    g = torch.Generator().manual_seed(77)
+    B, T = 3, 21
+    f0 = (120 + 500 * torch.rand(B, 1, T, generator=g)).cuda()
+    control = torch.randn(B, 2, T, generator=g).cuda()
+    pu = torch.rand(101, generator=g).cuda()
+    gru = eng.control_gru(control)
+    _, film, _, _ = eng.frame_mlps(gru)
+    carry = eng.phase_carry(f0=f0[:, 0].contiguous())
+    _, bank = eng.exciter_newt(f0[:, 0].contiguous(), None, carry, pu, film)
+    lds = torch.empty_like(bank)
+    _lib.check(_lib.lib().nws_exciter_newt(C.byref(w2), _lib.ptr(f0[:, 0].contiguous()), None, _lib.ptr(carry), _lib.ptr(pu),
+                                           _lib.ptr(eng.rand_phase()), _lib.ptr(film), B, T, float(m.sample_rate), None,
+                                           _lib.ptr(lds), _lib.stream_ptr()), "nws_exciter_newt (LDS fallback)")
+    torch.cuda.synchronize()
+    d = float((bank - lds).abs().max())
+    scale = float(bank.abs().max())
+    record("exact_tail_bank_vs_lds_fallback", max_abs_diff=d, max_abs=scale)
+    assert scale > 0 and d <= 2e-6 * max(1.0, scale), (d, scale)
