@@ -793,3 +793,55 @@ def test_exact_shaper_lds_fallback_matches_bank(models, oracle):
     scale = float(bank.abs().max())
     record("exact_tail_bank_vs_lds_fallback", max_abs_diff=d, max_abs=scale)
     assert scale > 0 and d <= 2e-6 * max(1.0, scale), (d, scale)
+
+
+def test_exciter_optional_table_fallbacks(models):
+    """Every derived table of NwsWeights is optional for a C-ABI caller; each NULL selects another code path of the fused
+    kernel.  Against the engine's default (all tables present, LUT range 6 -> kModeLutPairsDiv6):
+      mixer_frags NULL  -> the workgroup splits the mixer weights itself: identical bits;
+      lut_pairs NULL    -> kModeLut (two gathers, lerp with two roundings where the hot path has one FMA): <= 1 ulp-class;
+      LUT range != 6    -> kModeLutPairs vs kModeLut on the same table: identical bits (the pair table holds the
+                           reference's own intermediate fl(upper - lower))."""
+    import ctypes as C
+    import nws_amd
+    _lib = nws_amd._lib
+    _, fast = models
+    eng = fast._engine
+    w, _, dev = eng.weights()
+    assert w.mixer_frags and w.lut_pairs and w.lut
+    g = torch.Generator().manual_seed(78)
+    B, T = 2, 19
+    f0 = (90 + 700 * torch.rand(B, 1, T, generator=g)).cuda()
+    control = torch.randn(B, 2, T, generator=g).cuda()
+    pu = torch.rand(101, generator=g).cuda()
+    gru = eng.control_gru(control)
+    _, film, _, _ = eng.frame_mlps(gru)
+    carry = eng.phase_carry(f0=f0[:, 0].contiguous())
+    f0c = f0[:, 0].contiguous()
+
+    def run(wx):
+        out = torch.empty(B, 128 * T, device="cuda")
+        _lib.check(_lib.lib().nws_exciter_newt(C.byref(wx), _lib.ptr(f0c), None, _lib.ptr(carry), _lib.ptr(pu),
+                                               _lib.ptr(eng.rand_phase()), _lib.ptr(film), B, T, float(fast.sample_rate), None,
+                                               _lib.ptr(out), _lib.stream_ptr()), "nws_exciter_newt")
+        torch.cuda.synchronize()
+        return out
+
+    ref = run(w)
+    scale = float(ref.abs().max())
+    w_nf = _lib.NwsWeights.from_buffer_copy(w)
+    w_nf.mixer_frags = None
+    assert torch.equal(run(w_nf), ref)
+    w_np = _lib.NwsWeights.from_buffer_copy(w)
+    w_np.lut_pairs = None
+    d = float((run(w_np) - ref).abs().max())
+    assert d <= 2e-6 * max(1.0, scale), (d, scale)
+    # a table range other than 6 (same table, relabelled: only the index arithmetic changes)
+    w_r = _lib.NwsWeights.from_buffer_copy(w)
+    w_r.lut_min, w_r.lut_max = -3.5, 3.5
+    a = run(w_r)
+    w_r2 = _lib.NwsWeights.from_buffer_copy(w_r)
+    w_r2.lut_pairs = None
+    assert torch.equal(a, run(w_r2))
+    assert not torch.equal(a, ref)
+    record("exciter_optional_tables", lut_two_gathers_vs_pairs_fma_max_abs=d, max_abs=scale)
