@@ -35,3 +35,9 @@ cp gpurun_out/parity_report.json "$OUT/parity_report.json" 2>/dev/null
 (python bench.py --no-cpu-baseline --exact | grep '^{' > "$OUT/bench_exact_shapers.json") 2>/dev/null
 (NWS_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline | grep '^{' > "$OUT/bench_world1_rccl.json") 2>/dev/null
 python tools/soak_pipeline.py --rounds 250 > "$OUT/soak_pipeline.json" 2>/dev/null; cat "$OUT/soak_pipeline.json"
+# 7. exact-shaper mode, one stream: kernel stats (the shaper-bank kernel)
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_exact" -o bench -- $BENCH --exact --steps 50 --warmup 5 --pipeline 0 --streams 1 > "$OUT/trace_exact.log" 2>&1
+cd $R
+cp $(find "$OUT/trace_exact" -name "*kernel_stats.csv" | head -1) "$OUT/rocprofv3_kernel_stats_exact_1stream.csv"
+head -4 "$OUT/rocprofv3_kernel_stats_exact_1stream.csv"
