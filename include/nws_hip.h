@@ -294,6 +294,8 @@ int nws_debug_sin(int mode, const float* x, float* y, int64_t n, int reps, void*
 int nws_coexec_pk_probe(int blocks, int iters, unsigned* report, void* stream);
 /* same for packed fp16, v_fma_mix* and scalar-register second operands (forms listed in csrc/coexec_probe.hip) */
 int nws_coexec_pk_probe2(int blocks, int iters, unsigned* report, void* stream);
+/* probe 1 in waves 0-1 and a v_mfma_f32_16x16x32_f16 loop in waves 2-3 of the SAME workgroups (one kernel) */
+int nws_coexec_pk_probe_mixed(int blocks, int iters, int mfma_iters, unsigned* report, float* sink, void* stream);
 int nws_coexec_mfma_load(int kind, int blocks, int iters, float* sink /* device float[256] */, void* stream);
 
 /*

@@ -56,6 +56,7 @@ _PROTOTYPES = {
     "nws_selftest_mfma": (C.c_int, [_fp, _fp]),
     "nws_coexec_pk_probe": (C.c_int, [C.c_int, C.c_int, _fp, _fp]),
     "nws_coexec_pk_probe2": (C.c_int, [C.c_int, C.c_int, _fp, _fp]),
+    "nws_coexec_pk_probe_mixed": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),
     "nws_coexec_mfma_load": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "nws_sin": (C.c_int, [_fp, _fp, C.c_int64, _fp]),
     "nws_phase_carry": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp, _fp]),

@@ -26,7 +26,7 @@ KEEP_SLP = ("fir_noise.hip", "control_gru.hip")
 EXTRA_FLAGS = {src: ["-fno-slp-vectorize"] for src in SOURCES if src not in KEEP_SLP}
 LLVM_BIN = "/opt/rocm/lib/llvm/bin"
 # kernels that contain the hazardous form on purpose (the probe that demonstrates it)
-SWIZZLE_ALLOW = ("pk_probe_kernel", "pk_probe2_kernel")
+SWIZZLE_ALLOW = ("pk_probe_kernel", "pk_probe2_kernel", "pk_probe_mixed_kernel")
 
 
 def _hipcc():

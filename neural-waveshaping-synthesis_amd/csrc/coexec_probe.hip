@@ -3,7 +3,8 @@
 // Observation (ROCm 7.2 image, torch 2.10+rocm7.0 runtime, MI355X): a packed fp32 VALU instruction
 //   v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32  with op_sel[1] = 1
 // (the LOW result lane reads the HIGH half of src1: a swapped or high-broadcast second operand) sporadically returns a
-// wrong value while a DIFFERENT kernel - another stream, same compute unit - issues the K=16/K=32 half-precision MFMAs
+// wrong value while ANOTHER WAVE on the same compute unit - a different kernel on another stream, or other waves of the
+// very same workgroup (nws_coexec_pk_probe_mixed) - issues the K=16/K=32 half-precision MFMAs
 // v_mfma_f32_32x32x16_f16 / v_mfma_f32_16x16x32_f16.  Not affected: the same packed instructions without that swizzle
 // (plain, src0 or src2 swizzles, op_sel_hi-only broadcasts, neg modifiers), scalar VALU, LDS contents, barriers; not a
 // trigger: v_mfma_f32_32x32x8f16, v_mfma_f32_32x32x2f32, dense VALU.  The reverb's FFT butterflies ("times -i" is a swapped
@@ -36,7 +37,7 @@ __device__ __forceinline__ float sadd(float a, float b) {
   return d;
 }
 
-__global__ __launch_bounds__(256) void pk_probe_kernel(int iters, unsigned* __restrict__ report) {
+__device__ __forceinline__ void pk_probe_body(int iters, unsigned* __restrict__ report) {
   const int tid = threadIdx.x;
   unsigned bad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float2 a = make_float2(0.37f + 0.001f * (float)tid, -1.21f + 0.002f * (float)(blockIdx.x & 63));
@@ -67,6 +68,31 @@ __global__ __launch_bounds__(256) void pk_probe_kernel(int iters, unsigned* __re
   }
   for (int k = 0; k < 8; ++k)
     if (bad[k]) atomicAdd(&report[k], bad[k]);
+}
+
+__global__ __launch_bounds__(256) void pk_probe_kernel(int iters, unsigned* __restrict__ report) { pk_probe_body(iters, report); }
+
+// Same kernel, different waves: waves 0-1 of every workgroup run the probe, waves 2-3 a v_mfma_f32_16x16x32_f16 loop - is the
+// hazard a matter of two KERNELS sharing a compute unit, or of any two waves?
+__global__ __launch_bounds__(256) void pk_probe_mixed_kernel(int iters, int mfma_iters, unsigned* __restrict__ report,
+                                                             float* __restrict__ sink) {
+  if (threadIdx.x < 128) {
+    pk_probe_body(iters, report);
+  } else {
+    typedef float f32x4m __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    f16x8 a, b;
+    for (int q = 0; q < 8; ++q) {
+      a[q] = (_Float16)(0.01f * (float)(lane + q));
+      b[q] = (_Float16)(0.02f * (float)(q + 1));
+    }
+    f32x4m c4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int it = 0; it < mfma_iters; ++it) {
+      c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c4, 0, 0, 0);
+      c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c4, 0, 0, 0);
+    }
+    if (c4[0] + c4[1] + c4[2] + c4[3] == 12345.678f) sink[threadIdx.x] = c4[0];
+  }
 }
 
 // Second probe: the same question for the other VOP3P families and for a scalar-register second operand.  Every swizzled form
@@ -168,6 +194,13 @@ extern "C" {
 int nws_coexec_pk_probe(int blocks, int iters, unsigned* report, void* stream) {
   if (blocks <= 0 || iters <= 0 || !report) return NWS_ERR_BAD_ARG;
   pk_probe_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(iters, report);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+int nws_coexec_pk_probe_mixed(int blocks, int iters, int mfma_iters, unsigned* report, float* sink, void* stream) {
+  if (blocks <= 0 || iters <= 0 || mfma_iters <= 0 || !report || !sink) return NWS_ERR_BAD_ARG;
+  pk_probe_mixed_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(iters, mfma_iters, report, sink);
   NWS_CHECK_LAUNCH();
   return NWS_OK;
 }

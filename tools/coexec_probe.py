@@ -63,6 +63,14 @@ def run(blocks=4096, iters=2000, rounds=5, product_kernels=True):
                 load()
                 torch.cuda.synchronize()
             dst[name] = [int(v) for v in report.cpu().numpy().astype("uint32")]
+    # one kernel: probe in waves 0-1, v_mfma_f32_16x16x32_f16 loop in waves 2-3 of the same workgroups (half the probe lanes)
+    report.zero_()
+    torch.cuda.synchronize()
+    for _ in range(rounds):
+        _lib.check(L.nws_coexec_pk_probe_mixed(blocks, iters, 10 * iters, report.data_ptr(), sink.data_ptr(),
+                                               s_probe.cuda_stream), "mixed")
+    torch.cuda.synchronize()
+    out["same kernel: MFMA in waves 2-3 (x0.5 evals)"] = [int(v) for v in report.cpu().numpy().astype("uint32")]
     return {"forms": FORMS, "evaluations_per_form": blocks * 256 * iters * rounds, "wrong_results": out,
             "forms_other_families": FORMS2, "wrong_results_other_families": out2}
 
@@ -75,7 +83,7 @@ if __name__ == "__main__":
     print(f"evaluations per form and row: {r['evaluations_per_form']:.3g}")
     print(f"{'running beside':36s} " + " ".join(f"{f[:12]:>12s}" for f in r["forms"]))
     for k, v in r["wrong_results"].items():
-        print(f"{k:36s} " + " ".join(f"{x:12d}" for x in v))
+        print(f"{k[:44]:44s} " + " ".join(f"{x:12d}" for x in v))
     print(f"{'other families, running beside':36s} " + " ".join(f"{f[:12]:>12s}" for f in r["forms_other_families"]))
     for k, v in r["wrong_results_other_families"].items():
         print(f"{k:36s} " + " ".join(f"{x:12d}" for x in v))
