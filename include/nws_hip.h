@@ -292,7 +292,8 @@ int nws_debug_sin(int mode, const float* x, float* y, int64_t n, int reps, void*
  * the caller; forms 4..7 are the swizzled-src1 ones).  nws_coexec_mfma_load runs a bare MFMA loop beside it:
  * kind 0 v_mfma_f32_32x32x16_f16, 1 v_mfma_f32_16x16x32_f16, 2 v_mfma_f32_32x32x8f16, 3 v_mfma_f32_32x32x2f32. */
 int nws_coexec_pk_probe(int blocks, int iters, unsigned* report, void* stream);
-/* same for packed fp16, v_fma_mix* and scalar-register second operands (forms listed in csrc/coexec_probe.hip) */
+/* same for packed fp16, v_fma_mix*, scalar-register second operands and fp64 (11 forms listed in csrc/coexec_probe.hip;
+ * report: device uint32[11]) */
 int nws_coexec_pk_probe2(int blocks, int iters, unsigned* report, void* stream);
 /* probe 1 in waves 0-1 and a v_mfma_f32_16x16x32_f16 loop in waves 2-3 of the SAME workgroups (one kernel) */
 int nws_coexec_pk_probe_mixed(int blocks, int iters, int mfma_iters, unsigned* report, float* sink, void* stream);

@@ -100,9 +100,12 @@ __global__ __launch_bounds__(256) void pk_probe_mixed_kernel(int iters, int mfma
 //  0 v_pk_add_f16 src1 halves swapped      1 v_pk_fma_f16 src1 halves swapped     2 v_pk_mul_f16 src1 high half broadcast
 //  3 v_fma_mix_f32 src1 = high fp16 half    4 v_fma_mixlo_f16 src1 = high fp16 half
 //  5 v_pk_add_f32 src1 = SGPR pair, high broadcast    6 v_pk_mul_f32 src1 = SGPR pair, swapped    7 v_pk_add_f16 plain (control)
+//  8 v_add_f64   9 v_mul_f64   10 v_fma_f64   (64-bit register pairs in src1; each checked against the same instruction with
+//  src0 and src1 exchanged - the operations commute bit for bit)
 __global__ __launch_bounds__(256) void pk_probe2_kernel(int iters, unsigned* __restrict__ report) {
   const int tid = threadIdx.x;
-  unsigned bad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned bad[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double da = 1.0 + 1e-3 * (double)tid, db = 0.75 - 1e-4 * (double)(blockIdx.x & 63), dc = 0.125;
   // packed fp16 operands as raw 32-bit words: {lo, hi}
   unsigned a = 0x3c003800u + (unsigned)tid * 0x00010003u;       // ~{0.5.., 1.0..}
   unsigned b = 0x34003a00u + (unsigned)(blockIdx.x & 63) * 0x00030001u;
@@ -148,12 +151,26 @@ __global__ __launch_bounds__(256) void pk_probe2_kernel(int iters, unsigned* __r
       asm volatile("v_add_f16 %0, %1, %2" : "=v"(hi) : "v"(a >> 16), "v"(b >> 16));
       bad[7] += d != ((lo & 0xffffu) | (hi << 16));
     }
+    {
+      double x, y;
+      asm volatile("v_add_f64 %0, %1, %2" : "=v"(x) : "v"(da), "v"(db));
+      asm volatile("v_add_f64 %0, %1, %2" : "=v"(y) : "v"(db), "v"(da));
+      bad[8] += __double_as_longlong(x) != __double_as_longlong(y);
+      asm volatile("v_mul_f64 %0, %1, %2" : "=v"(x) : "v"(da), "v"(db));
+      asm volatile("v_mul_f64 %0, %1, %2" : "=v"(y) : "v"(db), "v"(da));
+      bad[9] += __double_as_longlong(x) != __double_as_longlong(y);
+      asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(x) : "v"(da), "v"(db), "v"(dc));
+      asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(y) : "v"(db), "v"(da), "v"(dc));
+      bad[10] += __double_as_longlong(x) != __double_as_longlong(y);
+      da = da * 0.999 + 0.001 * y;
+      db = db * 0.998 + 0.0021;
+    }
     // next operands: small integer steps keep the fp16 fields finite and varied
     a = (a & 0x7bff7bffu) ^ ((d & 0x000f000fu) | 0x30003000u);
     b = (b & 0x7bff7bffu) ^ ((unsigned)it * 0x00050003u & 0x00ff00ffu);
     fa = make_float2(sfma(fa.x, 0.9993f, 0.0007f), sfma(fa.y, 0.9989f, -0.0003f));
   }
-  for (int k = 0; k < 8; ++k)
+  for (int k = 0; k < 11; ++k)
     if (bad[k]) atomicAdd(&report[k], bad[k]);
 }
 

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 FORMS = ["pk_fma plain", "pk_add src0 swap", "pk_add src1 lo-bcast", "pk_fma src2 swap+neg",
          "pk_add src1 swap", "pk_add src1 hi-bcast", "pk_mul src1 swap", "pk_fma src1 swap"]
 FORMS2 = ["pk_add_f16 src1 swap", "pk_fma_f16 src1 swap", "pk_mul_f16 src1 hi-bcast", "fma_mix_f32 src1 hi", "fma_mixlo_f16 src1 hi",
-          "pk_add_f32 SGPR hi-bcast", "pk_mul_f32 SGPR swap", "pk_add_f16 plain"]
+          "pk_add_f32 SGPR hi-bcast", "pk_mul_f32 SGPR swap", "pk_add_f16 plain", "v_add_f64", "v_mul_f64", "v_fma_f64"]
 LOADS = {"none": None, "v_mfma_f32_32x32x16_f16": 0, "v_mfma_f32_16x16x32_f16": 1, "v_mfma_f32_32x32x8f16": 2,
          "v_mfma_f32_32x32x2f32": 3}
 
@@ -29,7 +29,7 @@ def run(blocks=4096, iters=2000, rounds=5, product_kernels=True):
     _lib = nws_amd._lib
     L = _lib.lib()
     s_probe, s_load = torch.cuda.Stream(), torch.cuda.Stream()
-    report = torch.zeros(8, dtype=torch.int32, device="cuda")
+    report = torch.zeros(16, dtype=torch.int32, device="cuda")
     sink = torch.zeros(256, device="cuda")
     loads = {k: ((lambda kind=v: _lib.check(L.nws_coexec_mfma_load(kind, 8192, 3000, sink.data_ptr(), s_load.cuda_stream), "load"))
                  if v is not None else (lambda: None)) for k, v in LOADS.items()}
@@ -62,7 +62,7 @@ def run(blocks=4096, iters=2000, rounds=5, product_kernels=True):
                 _lib.check(probe(blocks, iters, report.data_ptr(), s_probe.cuda_stream), "probe")
                 load()
                 torch.cuda.synchronize()
-            dst[name] = [int(v) for v in report.cpu().numpy().astype("uint32")]
+            dst[name] = [int(v) for v in report.cpu().numpy().astype("uint32")[:8 if dst is out else 11]]
     # one kernel: probe in waves 0-1, v_mfma_f32_16x16x32_f16 loop in waves 2-3 of the same workgroups (half the probe lanes)
     report.zero_()
     torch.cuda.synchronize()
@@ -70,7 +70,7 @@ def run(blocks=4096, iters=2000, rounds=5, product_kernels=True):
         _lib.check(L.nws_coexec_pk_probe_mixed(blocks, iters, 10 * iters, report.data_ptr(), sink.data_ptr(),
                                                s_probe.cuda_stream), "mixed")
     torch.cuda.synchronize()
-    out["same kernel: MFMA in waves 2-3 (x0.5 evals)"] = [int(v) for v in report.cpu().numpy().astype("uint32")]
+    out["same kernel: MFMA in waves 2-3 (x0.5 evals)"] = [int(v) for v in report.cpu().numpy().astype("uint32")[:8]]
     return {"forms": FORMS, "evaluations_per_form": blocks * 256 * iters * rounds, "wrong_results": out,
             "forms_other_families": FORMS2, "wrong_results_other_families": out2}
 
