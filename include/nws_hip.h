@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NWS_ABI_VERSION 1
+#define NWS_ABI_VERSION 2
 
 #define NWS_N_HARMONICS 101
 #define NWS_N_SHAPERS 64
@@ -96,9 +96,18 @@ typedef struct NwsWeights {
   const float* newt_out_b; /* (1) */
   /* noise_synth.window (models/modules/generators.py:20), periodic Hann(256) */
   const float* noise_window; /* (256) */
+  /* options of the fused oscillator + waveshaper kernel's FastNEWT path (0 = default: FiLM interpolation on the matrix
+   * pipe, sines as two fp16 terms = 22-bit products) */
+  int32_t exciter_opts;
 } NwsWeights;
+#define NWS_EXCITER_VALU_FILM 1 /* round-1 form: FiLM parameters interpolated on the VALU (kept for A/B timing) */
+#define NWS_EXCITER_ONE_TERM 2  /* sines as ONE fp16 term: 2 instead of 3 MFMAs per product and no residual split (-15 %
+                                   kernel time); mixer inputs carry 11 bits: ~1e-5 RMS end to end instead of ~3e-7 */
 
 int nws_abi_version(void);
+/* sizeof of the C structs above as this library was compiled (0 NwsWeights, 1 NwsReverbPlan, 2 NwsForwardAux): lets a
+ * foreign-language binding verify its own struct declarations at load time */
+size_t nws_sizeof(int which);
 const char* nws_error_string(int code);
 
 /* ---- hardware self-test: MFMA fragment layout the kernels rely on (returns #mismatches in *bad) ---- */

@@ -11,6 +11,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnws_hip.so")
 
+ABI_VERSION = 2          # include/nws_hip.h NWS_ABI_VERSION
+EXCITER_VALU_FILM = 1    # NwsWeights.exciter_opts bits (include/nws_hip.h)
+EXCITER_ONE_TERM = 2
 N_HARMONICS = 101
 N_SHAPERS = 64
 HIDDEN = 128
@@ -38,6 +41,7 @@ class NwsWeights(C.Structure):
         ("lut", _fp), ("lut_pairs", _fp), ("lut_size", C.c_int32), ("lut_min", C.c_float), ("lut_max", C.c_float),
         ("newt_out_w", _fp), ("newt_out_b", _fp),
         ("noise_window", _fp),
+        ("exciter_opts", C.c_int32),
     ]
 
 
@@ -52,6 +56,7 @@ class NwsForwardAux(C.Structure):
 
 _PROTOTYPES = {
     "nws_abi_version": (C.c_int, []),
+    "nws_sizeof": (C.c_size_t, [C.c_int]),
     "nws_error_string": (C.c_char_p, [C.c_int]),
     "nws_selftest_mfma": (C.c_int, [_fp, _fp]),
     "nws_coexec_pk_probe": (C.c_int, [C.c_int, C.c_int, _fp, _fp]),
@@ -131,6 +136,13 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        if handle.nws_abi_version() != ABI_VERSION:
+            raise NwsError(f"{LIB_PATH} has ABI version {handle.nws_abi_version()}, this package binds version "
+                           f"{ABI_VERSION}: rebuild it (python __graft_entry__.py build)")
+        for which, struct in enumerate((NwsWeights, NwsReverbPlan, NwsForwardAux)):
+            if handle.nws_sizeof(which) != C.sizeof(struct):
+                raise NwsError(f"struct layout mismatch for {struct.__name__}: library {handle.nws_sizeof(which)} B, "
+                               f"binding {C.sizeof(struct)} B")
         _lib = handle
     return _lib
 

@@ -31,6 +31,13 @@ constexpr int kTile = 128;                  // samples per workgroup (= control 
 constexpr float kTau = 6.283185307179586f;  // fl32(math.tau)
 constexpr float kPi = 3.141592653589793f;   // fl32(math.pi)
 
+// OPT bits of exciter_newt_kernel (compile-time variants of the FastNEWT hot path)
+enum Opt {
+  kOptScalarSines = 1,  // main loop in scalar fp32: a v_pk_*_f32 does not overlap with the matrix pipe, a v_fma_f32 does
+  kOptFilmMfma = 2,     // FiLM interpolation (3 parameter types x 64 shapers x 32 samples per wave) as six bf16 MFMAs
+  kOptOneTerm = 4,      // sines as ONE fp16 term (drops W_hi * v_lo: 2 MFMAs per product; 11-bit activations, opt-in)
+  kOptPipelined = 8     // main loop software-pipelined: sines of K-step ks+1 beside the MFMAs of K-step ks
+};
 enum Mode { kModeLut = 0, kModeExact = 1, kModeExciterOnly = 2, kModeLutPairs = 3, kModeLutPairsDiv6 = 4, kModeExactBank = 5 };
 __host__ __device__ constexpr bool is_lut(int mode) {
   return mode == kModeLut || mode == kModeLutPairs || mode == kModeLutPairsDiv6;
@@ -353,8 +360,17 @@ struct ExcLds {
   // upsampling (shaping.py:69) is ONE packed FMA per parameter: p(n) = fa + w1(n) * fd.  Types: 0 g_idx, 1 b_idx,
   // 2 out_w * g_norm (the 64->1 mixer weight folded in; its bias part  sum_s out_w[s] b_norm[s]  is the per-frame scalar bsum).
   // SoA: 4 consecutive shapers = one ds_read_b128 = two packed-fp32 operands.
-  float fa[3][3][kS];   // slots: frame pairs (jb-1, jb), (jb, jb+1) [, (jb+1, jb+2) when the workgroup covers two hops]
-  float fd[3][3][kS];
+  union {
+    struct {
+      float fa[3][3][kS];   // slots: frame pairs (jb-1, jb), (jb, jb+1) [, (jb+1, jb+2) when the workgroup covers two hops]
+      float fd[3][3][kS];
+    };
+    // kOptFilmMfma: the same three parameter types as MFMA A fragments.  Row (slot, type, M-tile, shaper i) = 8 bf16 =
+    // {a0, a1, a2, d0, d1, d2, 0, 0}: value a and frame difference d each as THREE bf16 terms (8 + 8 + 8 bits: exact for any
+    // fp32, fp32 exponent range), against the B operand {1, 1, 1, w, w, w, 0, 0} (w = interpolation weight, a multiple of
+    // 1/256: exact in bf16) one v_mfma_f32_32x32x16_bf16 returns a + w d for 32 shapers x 32 samples.
+    uint4 ffrag[3][3][2][32];
+  };
   float bsum[4];
   // K slot c = 16ks + 8half + e: slot 0 is the mixer BIAS (its "sine" is the constant 1), slot c >= 1 is harmonic c
   float shift[kKPad];           // phase shift of slot c (0 for slot 0 and the padding slots 102..111)
@@ -424,6 +440,15 @@ __device__ __forceinline__ f32x2 sin_turns2_fract(f32x2 x) {
   return f32x2{__builtin_amdgcn_sinf(t.x), __builtin_amdgcn_sinf(t.y)};
 }
 
+// scalar twin of sin_turns2_fract (same roundings): plain v_mul/v_fma/v_add issue in half the cycles of their packed forms
+// and, unlike those, beside the matrix pipe (tools/ubench/valu_rate.hip)
+__device__ __forceinline__ float sin_turns_fract(float x) {
+  const float c_hi = 0.15915493667125702f, c_lo = 6.4206382432985265e-09f;
+  const float p = x * c_hi;
+  const float e = fmaf(x, c_hi, -p);
+  return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(p) + fmaf(x, c_lo, e));
+}
+
 // two sines at once: every step except rint and v_sin_f32 is a packed-fp32 instruction
 __device__ __forceinline__ f32x2 sin_turns2(f32x2 x) {
   const f32x2 c_hi = splat2(0.15915493667125702f), c_lo = splat2(6.4206382432985265e-09f);
@@ -449,8 +474,8 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 // The bound of 7 waves/SIMD (72 VGPRs) is deliberate: at 8 (64 VGPRs) hipcc spills 24 B/lane to scratch, which is slower
 // (0.328 ms).  (Wrong results seen with that build under two overlapping audio streams were first blamed on the scratch;
 // the multi-stream problem turned out to be independent of it, see pipeline.py.  The build still rejects scratch.)
-template <int MODE, int DBG = 0, int HPB = 1>
-__global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeExactBank ? 3 : (HPB == 2 ? 7 : 5))) void exciter_newt_kernel(NwsWeights w, const float* __restrict__ f0,
+template <int MODE, int DBG = 0, int HPB = 1, int OPT = 0>
+__global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeExactBank ? 3 : ((OPT & kOptFilmMfma) ? 5 : ((OPT & kOptScalarSines) ? 6 : (HPB == 2 ? 7 : 5))))) void exciter_newt_kernel(NwsWeights w, const float* __restrict__ f0,
                                                            const float* __restrict__ f0_up,
                                                            const double* __restrict__ carry,
                                                            const float* __restrict__ phase_u,
@@ -529,6 +554,37 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
       const float* r0 = fb + (size_t)frame_of(wave) * NWS_FILM_CH + lane;
       const float* r1 = fb + (size_t)frame_of(wave + 1) * NWS_FILM_CH + lane;
       const float ow = w.newt_out_w[lane];
+      if (OPT & kOptFilmMfma) {
+        // index FiLM pre-scaled to table units: idx = (size/6) (g x + b - min) = g' x + b'  (a few ulp of idx away from the
+        // reference's rounding chain, like the folded origin of the kModeLutPairsDiv6 path; held to the same e2e parity bar)
+        const float c = (float)w.lut_size * (1.0f / 6.0f);
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+          const float u0 = r0[ty * kS], u1 = r1[ty * kS];
+          float a, d;
+          if (ty == 0) {
+            a = u0 * c;
+            d = (u1 - u0) * c;
+          } else if (ty == 1) {
+            a = (u0 - w.lut_min) * c;
+            d = (u1 - u0) * c;
+          } else {
+            a = ow * u0;
+            d = ow * u1 - a;
+          }
+          // exact three-term bf16 split by truncation: t0 = top 16 bits, the remainder is exact in fp32
+          auto top16 = [](float v) { return __builtin_bit_cast(unsigned, v) & 0xffff0000u; };
+          const unsigned a0 = top16(a);
+          const float ra = a - __builtin_bit_cast(float, a0);
+          const unsigned a1 = top16(ra);
+          const unsigned a2 = top16(ra - __builtin_bit_cast(float, a1));
+          const unsigned d0 = top16(d);
+          const float rd = d - __builtin_bit_cast(float, d0);
+          const unsigned d1 = top16(rd);
+          const unsigned d2 = top16(rd - __builtin_bit_cast(float, d1));
+          L.ffrag[wave][ty][lane >> 5][lane & 31] = uint4{(a0 >> 16) | a1, (a2 >> 16) | d0, (d1 >> 16) | d2, 0u};
+        }
+      } else
 #pragma unroll
       for (int ty = 0; ty < 3; ++ty) {
         const float sc = ty == 2 ? ow : 1.0f;
@@ -617,7 +673,7 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
   const int frag_lane = half * 32 + col;
   const f32x2 ph2 = splat2(phase);
   // one K-step; the first one starts the accumulators from the MFMA's inline-zero C operand (no 32 v_mov per wave)
-  auto kstep = [&](const int ks, auto first_tag) {
+  auto sines = [&](const int ks, auto first_tag, f16x8& vhi, f16x8& vlo) {
     constexpr bool kFirst = decltype(first_tag)::value;
     const int kk0 = 16 * ks + 8 * half;
     const int rem = kmax + 1 - kk0;    // this lane's live slots in the step: e < rem  (slot c = kk0 + e is live iff c <= kmax)
@@ -632,6 +688,13 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
     if (DBG == 1) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) v2[p] = kf2[p] * ph2 + sh2[p];
+    } else if (small_args && (OPT & kOptScalarSines)) {
+      // the same arithmetic, instruction for instruction, in scalar fp32 (-ffp-contract=off: k*phase and + shift round apart)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float a0 = kf2[p].x * phase + sh2[p].x, a1 = kf2[p].y * phase + sh2[p].y;
+        v2[p] = f32x2{sin_turns_fract(a0), sin_turns_fract(a1)};
+      }
     } else if (small_args) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) v2[p] = sin_turns2_fract(kf2[p] * ph2 + sh2[p]);  // fl(fl(k*phase) + shift): the reference's own rounding chain
@@ -651,16 +714,20 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
     }
     if (kFirst && DBG != 1) v2[0].x = half == 0 ? 1.0f : v2[0].x;  // slot 0: the bias' constant input
     // v = hi + lo, both fp16 (lo = exact residual rounded to fp16): v_cvt_pk_f16_f32 for hi, one v_fma_mix{lo,hi}_f16 per lo
-    f16x8 vhi, vlo;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const f16x2 h2 = __builtin_convertvector(v2[p], f16x2);
-      const f16x2 l2 = split_lo2(h2, v2[p]);
       vhi[2 * p] = h2.x;
       vhi[2 * p + 1] = h2.y;
-      vlo[2 * p] = l2.x;
-      vlo[2 * p + 1] = l2.y;
+      if (!(OPT & kOptOneTerm)) {
+        const f16x2 l2 = split_lo2(h2, v2[p]);
+        vlo[2 * p] = l2.x;
+        vlo[2 * p + 1] = l2.y;
+      }
     }
+  };
+  auto mix = [&](const int ks, auto first_tag, const f16x8& vhi, const f16x8& vlo) {
+    constexpr bool kFirst = decltype(first_tag)::value;
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const f16x8 ahi = L.whi[(ks * 2 + m) * 64 + frag_lane];
@@ -671,18 +738,25 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
         acc[ks] += (float)ahi[0] * (float)vhi[0] + (float)alo[1] * (float)vlo[1];
       } else {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, vhi, kFirst ? f32x16{} : acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, vlo, acc, 0, 0, 0);
+        if (!(OPT & kOptOneTerm)) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, vlo, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, vhi, acc, 0, 0, 0);
       }
     }
   };
   // the first step always runs (it carries the bias); k*f0 only grows with k: once a step has no live lane, everything
   // above is masked too
-  kstep(0, std::true_type{});
+  {
+    auto kstep = [&](const int ks, auto first_tag) {
+      f16x8 vhi, vlo;
+      sines(ks, first_tag, vhi, vlo);
+      mix(ks, first_tag, vhi, vlo);
+    };
+    kstep(0, std::true_type{});
 #pragma unroll
-  for (int ks = 1; ks < kKSteps; ++ks) {
-    if (!__any(kmax + 1 - (16 * ks + 8 * half) > 0)) break;
-    kstep(ks, std::false_type{});
+    for (int ks = 1; ks < kKSteps; ++ks) {
+      if (!__any(kmax + 1 - (16 * ks + 8 * half) > 0)) break;
+      kstep(ks, std::false_type{});
+    }
   }
 
   // accumulator element r of M-tile m: shaper 32m + (r&3) + 8(r>>2) + 4*half, sample `col`
@@ -712,6 +786,45 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
   else if (is_lut(MODE)) LP = make_lut_params(w);
   const int lane_row_off = is_lut(MODE) ? 4 * half * w.lut_size : 0;
   const unsigned lane_off_bytes = is_lut(MODE) ? (unsigned)lane_row_off * 8u : 0u;
+  if (MODE == kModeLutPairsDiv6 && (OPT & kOptFilmMfma)) {
+    // FiLM parameters of the wave's 64 shapers x 32 samples from the matrix pipe: a + w d per (shaper, sample) with the
+    // accumulator layout of the exciter tile itself, so G[r], Bb[r], Gn[r] pair up with acc[r] register for register.
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    const unsigned w1b = __builtin_bit_cast(unsigned, lc.w1);   // a multiple of 1/256 in [0, 1): exact in bf16
+    const uint4 bop = half == 0 ? uint4{0x3f803f80u, 0x3f80u | (w1b & 0xffff0000u), (w1b >> 16) | (w1b & 0xffff0000u), 0u}
+                                : uint4{0u, 0u, 0u, 0u};       // K slots 8..15 unused: zero B, whatever A holds there
+    const bf16x8 bfrag = __builtin_bit_cast(bf16x8, bop);
+    float part = 0.0f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const f32x16& acc = m == 0 ? acc0 : acc1;
+      const f32x16 G = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, L.ffrag[q0][0][m][col]), bfrag, f32x16{}, 0, 0, 0);
+      const f32x16 Bb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, L.ffrag[q0][1][m][col]), bfrag, f32x16{}, 0, 0, 0);
+      const f32x16 Gn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, L.ffrag[q0][2][m][col]), bfrag, f32x16{}, 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float fr[4];
+        float2 tv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const float idx = fmaf(G[r], acc[r], Bb[r]);   // FiLM in table units (bias and origin folded at staging)
+          const float fl = __builtin_amdgcn_fmed3f(floorf(idx), 0.0f, LF.top);
+          fr[e] = idx - fl;
+          const unsigned o = lane_off_bytes + ((unsigned)(int)fl << 3);
+          tv[e] = DBG == 2 ? float2{idx, 0.0f}
+                           : *reinterpret_cast<const float2*>(LF.pairs + (size_t)(32 * m + 8 * g + e) * LF.row_bytes + o);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part = fmaf(Gn[4 * g + e], fmaf(tv[e].y, fr[e], tv[e].x), part);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    const float bias_n = fmaf(lc.w1, L.bsum[q0 + 1] - L.bsum[q0], L.bsum[q0]);
+    const float total = part + nws_swap_halves(part) + (bias_n + w.newt_out_b[0]);
+    if (half == 0) newt_out[(size_t)b * N + n] = total;
+    return;
+  }
   const f32x2 w1_2 = splat2(lc.w1);
   f32x2 part2 = {0.0f, 0.0f};
   // accumulator registers 4g..4g+3 of M-tile m are the 4 consecutive shapers 32m + 8g + 4half + 0..3
@@ -1038,10 +1151,19 @@ int nws_exciter_newt(const NwsWeights* w, const float* f0, const float* f0_up, c
     if (w->lut != nullptr) {
       if (w->lut_size < 2 || !(w->lut_max > w->lut_min)) return NWS_ERR_BAD_ARG;
       const bool pow2 = (w->lut_size & (w->lut_size - 1)) == 0 && w->lut_size <= (1 << 20);
-      if (w->lut_pairs != nullptr && w->lut_max - w->lut_min == 6.0f && pow2)
-        exciter_newt_kernel<kModeLutPairsDiv6, 0, 2><<<dim3((T + 1) / 2, B), 512, base, st>>>(
-            *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out);
-      else if (w->lut_pairs != nullptr)
+      if (w->lut_pairs != nullptr && w->lut_max - w->lut_min == 6.0f && pow2) {
+        // FastNEWT hot path.  exciter_opts (nws_hip.h): bit 0 = round-1 FiLM interpolation on the VALU, bit 1 = one fp16
+        // term per sine
+        const dim3 g2((T + 1) / 2, B);
+        const int opts = w->exciter_opts;
+#define NWS_HOT(O) exciter_newt_kernel<kModeLutPairsDiv6, 0, 2, O><<<g2, 512, base, st>>>( \
+            *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out)
+        if ((opts & NWS_EXCITER_VALU_FILM) && (opts & NWS_EXCITER_ONE_TERM)) NWS_HOT(kOptOneTerm);
+        else if (opts & NWS_EXCITER_VALU_FILM) NWS_HOT(0);
+        else if (opts & NWS_EXCITER_ONE_TERM) NWS_HOT(kOptFilmMfma | kOptOneTerm);
+        else NWS_HOT(kOptFilmMfma);
+#undef NWS_HOT
+      } else if (w->lut_pairs != nullptr)
         exciter_newt_kernel<kModeLutPairs><<<grid, 256, base, st>>>(*w, f0, f0_up, carry, phase_u, rand_phase, film,
                                                                     T, sample_rate, exciter_out, newt_out);
       else
@@ -1070,6 +1192,22 @@ int nws_debug_exciter_newt(int variant, const NwsWeights* w, const float* f0, co
   const dim3 grid(T, B);
   const size_t base = (sizeof(ExcLds) + 15) & ~size_t(15);
   hipStream_t st = (hipStream_t)stream;
+#define NWS_OPT_LAUNCH(O)                                                                                          \
+  exciter_newt_kernel<kModeLutPairsDiv6, 0, 2, O><<<dim3((T + 1) / 2, B), 512, base, st>>>(*w, f0, nullptr, carry, phase_u, \
+                                                            rand_phase, film, T, sample_rate, nullptr, newt_out)
+  if (variant >= 10) {   // 10 + OPT bits: the product kernel's compile-time options (two hops per workgroup)
+    switch (variant - 10) {
+      case 0: NWS_OPT_LAUNCH(0); break;
+      case 1: NWS_OPT_LAUNCH(1); break;
+      case 2: NWS_OPT_LAUNCH(2); break;
+      case 4: NWS_OPT_LAUNCH(4); break;
+      case 6: NWS_OPT_LAUNCH(6); break;
+      default: return NWS_ERR_BAD_ARG;
+    }
+    NWS_CHECK_LAUNCH();
+    return NWS_OK;
+  }
+#undef NWS_OPT_LAUNCH
 #define NWS_DBG_LAUNCH(V)                                                                                         \
   exciter_newt_kernel<kModeLutPairsDiv6, V><<<grid, 256, base, st>>>(*w, f0, nullptr, carry, phase_u, rand_phase, film, T, \
                                                             sample_rate, nullptr, newt_out)

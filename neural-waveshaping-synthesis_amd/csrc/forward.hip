@@ -138,6 +138,15 @@ bool aux_ok(const NwsForwardAux* aux) {
 
 extern "C" {
 
+size_t nws_sizeof(int which) {
+  switch (which) {
+    case 0: return sizeof(NwsWeights);
+    case 1: return sizeof(NwsReverbPlan);
+    case 2: return sizeof(NwsForwardAux);
+    default: return 0;
+  }
+}
+
 size_t nws_forward_control_bytes(int B, int T) {
   if (B <= 0 || T <= 0) return 0;
   const size_t N = (size_t)T * NWS_HOP;

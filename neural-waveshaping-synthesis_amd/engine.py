@@ -140,6 +140,7 @@ class Engine:
             w.lut = None
             w.lut_pairs = None
             w.lut_size, w.lut_min, w.lut_max = 0, 0.0, 0.0
+        w.exciter_opts = self.exciter_opts()
         w.newt_out_w = P(m.newt.mixer[0].weight, "newt.mixer.0.weight", 64)
         w.newt_out_b = P(m.newt.mixer[0].bias, "newt.mixer.0.bias", 1)
         w.noise_window = P(m.noise_synth.window, "noise_synth.window", 256)
@@ -163,6 +164,14 @@ class Engine:
         torch.cuda.current_stream().synchronize()   # derived tables complete before any other stream can use them
         self._w = (w, keep, next(iter(devs)))
         return self._w
+
+    def exciter_opts(self) -> int:
+        """NwsWeights.exciter_opts: `model.exciter_opts` if set (invalidate_cache() after changing it), else the
+        NWS_EXCITER_OPTS environment variable, else 0 (= FiLM interpolation on the matrix pipe, two-term fp16 sines)."""
+        import os
+
+        v = getattr(self._model_ref, "exciter_opts", None)
+        return int(os.environ.get("NWS_EXCITER_OPTS", "0")) if v is None else int(v)
 
     def fp16_mlp_safe(self, limit: float = 3.0e4) -> bool:
         """Worst-case magnitude of every frame-MLP layer input, from weight norms (one-time host check).

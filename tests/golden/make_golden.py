@@ -15,6 +15,9 @@ Fixtures written:
   g4_stream.npz       T=2 (N=256) and T=32 (N=4096) end to end (reverb L=32000 branch)
   g5_lut.npz          LUT rows/checksum + out-of-range probes of FastNEWT.shaping_fn
   g6_highf0.npz       B=1,T=500, F0 1-2 kHz (cumsum ~1e8, large sine arguments)
+  weights_fl.npz / weights_tpt.npz   the other two shipped instruments (checkpoints/nws/{fl,tpt}/last.ckpt), same layout
+  g7_fl.npz / g7_tpt.npz             B=1,T=125 (1 s) realistic vector per instrument: y_newt, y_fast, draws
+(`python tests/golden/make_golden.py instruments` regenerates only the last four.)
 The RNG draws made inside forward are recorded by wrapping torch.rand / torch.rand_like.
 """
 import hashlib
@@ -195,5 +198,36 @@ def main():
          probes=probes, probe_out=fast_newt.shaping_fn(xp)[0], probe_exact=exact_newt.shaping_fn(xp)[0])
 
 
+def instruments():
+    """fl and tpt: weights + one realistic 1 s vector each (usable on all three shipped instruments)."""
+    T = 125
+    t = np.arange(T) * 128 / 16000.0
+    for inst, base_hz in (("fl", 587.33), ("tpt", 349.23)):
+        ck = os.path.join(REF, "checkpoints/nws", inst)
+        model = NeuralWaveshaping.load_from_checkpoint(os.path.join(ck, "last.ckpt")).eval()
+        exact_newt = model.newt
+        fast_newt = FastNEWT(exact_newt)
+        mean = np.load(os.path.join(ck, "data_mean.npy")).astype(np.float64)
+        std = np.load(os.path.join(ck, "data_std.npy")).astype(np.float64)
+        sd = {k: v for k, v in model.state_dict().items()}
+        save(f"weights_{inst}.npz", **sd,
+             **{"__data_mean__": mean[:2, 0].astype(np.float32), "__data_std__": std[:2, 0].astype(np.float32)})
+        f0_hz = base_hz * (1 + 0.012 * np.sin(2 * np.pi * 5.0 * t)) * np.where(t < 0.5, 1.0, 2 ** (2 / 12))
+        loud = 0.3 + 0.35 * np.sin(np.pi * t / 1.0) ** 2
+        f0 = torch.tensor(f0_hz, dtype=torch.float32).view(1, 1, T)
+        control = torch.tensor(np.stack([(f0_hz - mean[0, 0]) / std[0, 0], (loud - mean[1, 0]) / std[1, 0]]),
+                               dtype=torch.float32).view(1, 2, T)
+        model.newt = exact_newt
+        y_newt, pu, nz = run(model, f0, control, 4321)
+        model.newt = fast_newt
+        y_fast, pu2, nz2 = run(model, f0, control, 4321)
+        assert np.array_equal(pu, pu2) and np.array_equal(nz, nz2)
+        save(f"g7_{inst}.npz", f0=f0, control=control, phase_u=pu, noise=nz, y_newt=y_newt, y_fast=y_fast)
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["instruments"]:
+        instruments()
+    else:
+        main()
+        instruments()

@@ -34,17 +34,20 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_strings():
     L = _lib.lib()
-    assert L.nws_abi_version() == 1
+    assert L.nws_abi_version() == _lib.ABI_VERSION == 2
     assert b"unsupported" in L.nws_error_string(-1)
     assert b"bad argument" in L.nws_error_string(-2)
     assert L.nws_error_string(0) == b"ok"
 
 
 def test_struct_layouts_match_header_sizes():
-    # 8-byte pointers, 4-byte ints/floats; the C side static-sizes are implied by field order
-    assert C.sizeof(_lib.NwsReverbPlan) == 16
+    # the library reports sizeof() of its own structs: the ctypes declarations must agree byte for byte
+    L = _lib.lib()
+    assert C.sizeof(_lib.NwsReverbPlan) == 16 == L.nws_sizeof(1)
+    assert C.sizeof(_lib.NwsWeights) == L.nws_sizeof(0)
+    assert C.sizeof(_lib.NwsForwardAux) == L.nws_sizeof(2)
     n_ptr = sum(1 for _, t in _lib.NwsWeights._fields_ if t is _lib._fp) + 4 * 4 + 3 * 4
-    assert C.sizeof(_lib.NwsWeights) == 8 * n_ptr + 16  # + lut_size, lut_min, lut_max (+4 pad)
+    assert C.sizeof(_lib.NwsWeights) == 8 * n_ptr + 16 + 8  # + lut_size, lut_min, lut_max (+4 pad), exciter_opts (+4 pad)
 
 
 @pytest.mark.parametrize("N,L,N1,N2", [(64000, 64000, 125, 512), (256, 32000, 125, 256), (32000, 32000, 125, 256),

@@ -34,7 +34,7 @@ def test_library_loaded_and_mfma_layout():
     from importlib import import_module
 
     lib = import_module("neural-waveshaping-synthesis_amd._lib")
-    assert lib.lib().nws_abi_version() == 1
+    assert lib.lib().nws_abi_version() == lib.ABI_VERSION
     bad = torch.full((1,), -1, dtype=torch.int32, device="cuda")
     lib.check(lib.lib().nws_selftest_mfma(bad.data_ptr(), lib.stream_ptr()))
     assert int(bad.item()) == 0
@@ -431,6 +431,50 @@ def test_e2e_g2_timing_script_inputs(models, oracle):
 
 def test_e2e_g6_high_f0(models, oracle):
     _e2e(models, oracle, load_npz("g6_highf0.npz"), load_npz("g1_realistic.npz"), "g6_highf0")
+
+
+@pytest.mark.parametrize("inst", ["fl", "tpt"])
+def test_e2e_g7_other_instruments(inst):
+    """flute / trumpet checkpoints (reference checkpoints/nws/{fl,tpt}/last.ckpt) against the reference's own outputs,
+    exact shapers and FastNEWT, default kernel options and the one-term-sine option"""
+    import nws_amd as nws
+    from conftest import ROOT
+    import os
+
+    nws.ensure_default_config()
+    path = os.path.join(ROOT, "tests", "golden", f"weights_{inst}.npz")
+    exact = nws.NeuralWaveshaping.load_from_checkpoint(path).cuda().eval()
+    fast = nws.NeuralWaveshaping.load_from_checkpoint(path).cuda().eval()
+    fast.newt = nws.FastNEWT(fast.newt)
+    g = load_npz(f"g7_{inst}.npz")
+    _e2e((exact, fast), None, g, g, f"g7_{inst}")
+    for opts, tag, tol in ((0, "two_term", 1e-5), (2, "one_term", 1e-4), (1, "valu_film", 1e-5)):
+        fast.exciter_opts = opts
+        fast.invalidate_cache()
+        y = fast(dev(g["f0"]), dev(g["control"]), phase_u=dev(g["phase_u"]), noise=dev(g["noise"])).cpu().numpy()
+        e = rms(y - g["y_fast"])
+        record(f"e2e_g7_{inst}_{tag}", rms_err_fast=e, out_rms=rms(g["y_fast"]))
+        assert e <= tol, (inst, tag, e)
+
+
+def test_exciter_options_on_golden_vectors(models):
+    """NwsWeights.exciter_opts: the round-1 VALU FiLM path and the one-term-sine path against the reference's outputs
+    (G1 realistic, G2 timing-script inputs, G6 high F0)."""
+    _, fast = models
+    d = load_npz("g1_realistic.npz")
+    try:
+        for name in ("g1_realistic", "g2_rand", "g6_highf0"):
+            g = load_npz(name + ".npz")
+            for opts, tag, tol in ((0, "default", 1e-5), (1, "valu_film", 1e-5), (2, "one_term", 1e-4)):
+                fast.exciter_opts = opts
+                fast.invalidate_cache()
+                y = fast(dev(g["f0"]), dev(g["control"]), phase_u=dev(d["phase_u"]), noise=dev(d["noise"])).cpu().numpy()
+                e = rms(y - g["y_fast"])
+                record(f"exciter_opts_{name}_{tag}", rms_err_fast=e)
+                assert e <= tol, (name, tag, e)
+    finally:
+        fast.exciter_opts = None
+        fast.invalidate_cache()
 
 
 def test_e2e_g3_batch2_extra_control_channels(models, oracle):

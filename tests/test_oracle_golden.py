@@ -40,6 +40,15 @@ def test_g6_high_f0(oracles, g1):
     _check_e2e(oracles, load_npz("g6_highf0.npz"), g1, tol=5e-6)
 
 
+@pytest.mark.parametrize("inst", ["fl", "tpt"])
+def test_g7_other_instruments(inst):
+    """The other two shipped checkpoints (flute, trumpet): their input_scale ranges push the exact shapers' sine arguments
+    further than the violin's; oracle pinned on a realistic 1 s vector each."""
+    w = {k: v for k, v in load_npz(f"weights_{inst}.npz").items() if not k.startswith("__")}
+    g = load_npz(f"g7_{inst}.npz")
+    _check_e2e((OracleNEWT(w, fast=False), OracleNEWT(w, fast=True, lut_python_loop=False)), g, g)
+
+
 def test_g4_streaming_sizes(oracles):
     g = load_npz("g4_stream.npz")
     exact, fast = oracles
