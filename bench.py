@@ -1,19 +1,25 @@
 #!/usr/bin/env python
 """Headline benchmark: NEWT forward throughput (audio samples/s, x real-time) on 4 s @ 16 kHz clips.
 
-    python bench.py [--gpus N --steps K --warmup W] [--batch 64] [--frames 500] [--exact]
+    python bench.py [--gpus N --steps K --warmup W] [--batch 64] [--frames 500] [--exact] [--gather rccl|copy]
 
-Contract (see DESIGN.md §5): a step = one NeuralWaveshaping.forward over a batch of `--batch` synthetic
+Contract (see DESIGN.md section 5): a step = one NeuralWaveshaping.forward over a batch of `--batch` synthetic
 utterances per GPU (torch.rand F0/control exactly like the reference's scripts/time_forward_pass.py:27-40,
 vn checkpoint, FastNEWT LUT), inputs resident in HBM, the two RNG draws of forward() made on the device
-inside the step; with N>1 the rendered waveforms are all-gathered over RCCL (overlapped with the next
-step's kernels).  Prints ONE JSON line on rank 0.
+inside the step; with N>1 the rendered waveforms are all-gathered (RCCL, or `--gather copy`: copy-engine
+peer writes) inside the timed region, overlapped with the next step's kernels.  Prints ONE JSON line on rank 0.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N` (one rank per GPU) after checking that the box HAS N GPUs;
+launched by a driver under torch.distributed.run it checks WORLD_SIZE == N.  A mismatch is an error, never a silent
+single-GPU run.
 """
 import argparse
 import ctypes as C
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -21,6 +27,7 @@ import time
 # streams onto 4 hardware queues by default and streams that share a queue serialise (measured: 0.75 vs 0.59 ms per step with
 # RCCL initialised).  Must be set before the HIP runtime starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL / peer-mapped buffers across processes
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -28,13 +35,24 @@ import torch  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic work of the dominant kernel (exciter_newt_kernel) per utterance of T=500 frames, SURVEY.md §8(d):
-#   harmonic mixer 2*64*101 flop/sample + 101 sin/sample (1 flop each) + FiLM lerp/FiLM/LUT/mix ~ 24 flop per (sample, shaper)
+# ---- algorithmic work per launch: what `achieved` divides by the live kernel time ----
+# exciter_newt_kernel: harmonic mixer 2*64*101 flop/sample + 101 sines (5 flop each) + FiLM lerp/FiLM/LUT/mix ~ 24 flop per
+# (sample, shaper)
 FLOP_PER_SAMPLE_EXCITER_NEWT = 2 * 64 * 101 + 101 * 5 + 64 * 24
-PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= the fp32 vector peak)
+# fp16 MFMA work the kernel issues per sample: (terms) MFMAs of 64 shapers x 112 K slots, + 6 bf16 MFMAs of 32x32x16 per 32
+# samples for the FiLM interpolation
+def exciter_mfma_flop_per_sample(terms, film_mfma):
+    return terms * 2 * 64 * 112 + (6 * 2 * 32 * 32 * 16 / 32.0 if film_mfma else 0.0)
+
+
+FLOP_PER_FRAME_MLPS = 2 * (128 * 128 + 3 * 128 * 128 + 256 * 128 + 3 * 128 * 128 + 129 * 128 + 256 * 132)   # proj, 2 MLPs, FIR design
+FLOP_PER_STEP_GRU = 2 * (384 * 128 + 384 * 2)           # per utterance and control frame
+FLOP_PER_FRAME_NOISE = 2 * 256 * 512                    # two overlapping 256-tap circular convolutions per output hop
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
-# matrix-core work the kernel actually issues: 3 fp16 MFMAs (hi*hi, hi*lo, lo*hi) of 64 shapers x 112 K slots per sample
-MFMA_F16_FLOP_PER_SAMPLE_EXECUTED = 3 * 2 * 64 * 112
+PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector peak
+PEAK_HBM_TBS = 8.0              # MI355X_MICROARCH.md: HBM3E spec peak (6.3 achievable)
+MAX_CLOCK_GHZ = 2.4
+N_SIMD = 1024
 
 
 def parse():
@@ -49,8 +67,14 @@ def parse():
                     help="rand: torch.rand F0/control exactly like scripts/time_forward_pass.py (sub-1 Hz 'F0': all 101 harmonics "
                          "live, the worst case for the oscillator); realistic: per-utterance F0 ~ U[100, 1000] Hz with 5.5 Hz "
                          "vibrato, control ~ N(0,1) (SURVEY 8(d) config 3)")
+    ap.add_argument("--exciter-opts", type=int, default=None,
+                    help="NwsWeights.exciter_opts (include/nws_hip.h): 0 default, 1 round-1 VALU FiLM, 2 one-term fp16 sines")
+    ap.add_argument("--gather", choices=("rccl", "copy"), default="rccl",
+                    help="N > 1: how the rendered waveforms are all-gathered: rccl = all_gather_into_tensor (RCCL kernels on the "
+                         "CUs); copy = every rank pushes its shard into every peer's buffer with device-to-device copies on "
+                         "peer-mapped memory (copy engines over xGMI, no collective kernels; parallel.PeerCopyAllGather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=60)
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="time budget of the cpu_baseline leg")
     ap.add_argument("--batch1-iters", type=int, default=200)
     ap.add_argument("--streams", type=int, default=2,
                     help="audio streams of the pipeline (or, with --pipeline 0, streams that whole forwards are issued on "
@@ -70,48 +94,142 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(weights_path, iters, T):
-    """The oracle (op-for-op torch-CPU restatement of the reference forward, python LUT loop included) timed on
-    the host cores, protocol of scripts/time_forward_pass.py: B=1, torch.rand inputs, FastNEWT."""
-    from oracle.newt_oracle import OracleNEWT, load_weights_npz
+def launch_ranks(a):
+    """`python bench.py --gpus N` typed by hand / by a driver that does not use torchrun: become N ranks."""
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        print(f"bench.py: --gpus {a.gpus} needs {a.gpus} GPUs, this box has {have}; refusing to time fewer GPUs than asked for",
+              file=sys.stderr)
+        sys.exit(2)
+    port = 29400 + os.getpid() % 500
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    sys.exit(subprocess.run(cmd).returncode)
 
-    w = {k: v for k, v in load_weights_npz(weights_path).items() if not k.startswith("__")}
-    o = OracleNEWT(w, fast=True, lut_python_loop=True)
-    torch.manual_seed(0)
-    f0, control = torch.rand(1, 1, T), torch.rand(1, 2, T)
-    for _ in range(3):
+
+def _time_oracle(o, f0, control, budget_s, max_iters):
+    for _ in range(2):
         o(f0, control)
-    ts = []
-    t_end = time.time() + 25.0
-    for _ in range(iters):
+    ts, t_end = [], time.time() + budget_s
+    while len(ts) < max_iters and (time.time() < t_end or len(ts) < 2):
         t0 = time.time()
         o(f0, control)
         ts.append(time.time() - t0)
-        if time.time() > t_end:
-            break
-    mean = float(np.mean(ts))
-    return {"value": 128 * T / mean, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(ts)} forwards of B=1, T={T} (4 s) FastNEWT, torch.rand inputs, oracle/newt_oracle.py "
-                      f"(torch {torch.__version__} CPU, {os.cpu_count()} logical cpus)",
-            "ms_per_utterance": mean * 1e3, "x_realtime": (128 * T / 16000.0) / mean}
+    return float(np.mean(ts)), len(ts)
+
+
+def cpu_baseline(weights_path, T, budget_s):
+    """The oracle (op-for-op torch-CPU restatement of the reference forward, python LUT loop included) timed on the host
+    cores, protocol of scripts/time_forward_pass.py: B=1, torch.rand inputs; intra-op thread sweep (128
+    threads on 64 000-element ops thrash: the best count is reported), FastNEWT and exact NEWT, plus one B=16 call."""
+    from oracle.newt_oracle import OracleNEWT, load_weights_npz
+
+    w = {k: v for k, v in load_weights_npz(weights_path).items() if not k.startswith("__")}
+    fast = OracleNEWT(w, fast=True, lut_python_loop=True)
+    exact = OracleNEWT(w, fast=False)
+    torch.manual_seed(0)
+    f0, control = torch.rand(1, 1, T), torch.rand(1, 2, T)
+    ncpu = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+    sweep = {}
+    for nt in sorted({1, 4, 8, 16, 32, min(64, ncpu), default_threads}):
+        if nt > ncpu:
+            continue
+        torch.set_num_threads(nt)
+        sweep[nt] = _time_oracle(fast, f0, control, budget_s * 0.06, 4)[0]
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    mean, n = _time_oracle(fast, f0, control, budget_s * 0.35, 100)
+    mean_exact, n_exact = _time_oracle(exact, f0, control, budget_s * 0.2, 20)
+    fb, cb = torch.rand(16, 1, T), torch.rand(16, 2, T)
+    t0 = time.time()
+    fast(fb, cb)
+    t_b16 = time.time() - t0
+    torch.set_num_threads(default_threads)
+    cpu_model = "?"
+    try:
+        cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        pass
+    dur = 128 * T / 16000.0
+    return {"value": 128 * T / mean, "unit": "samples/s", "cores": best, "kind": "port",
+            "sample": f"{n} forwards of B=1, T={T} (4 s) FastNEWT (reference's python LUT loop), torch.rand inputs, "
+                      f"oracle/newt_oracle.py, torch {torch.__version__} CPU, best of a thread sweep",
+            "ms_per_utterance": mean * 1e3, "x_realtime": dur / mean, "rtf_mean": mean / dur,
+            "cpu_model": cpu_model, "logical_cpus": ncpu, "torch_default_threads": default_threads,
+            "thread_sweep_ms_per_utterance": {str(k): round(v * 1e3, 2) for k, v in sorted(sweep.items())},
+            "exact_newt_b1": {"ms_per_utterance": mean_exact * 1e3, "samples_per_s": 128 * T / mean_exact,
+                              "x_realtime": dur / mean_exact, "forwards": n_exact},
+            "fastnewt_b64_as_64_sequential_b1": {"ms": 64 * mean * 1e3, "samples_per_s": 128 * T / mean},
+            "fastnewt_one_b16_call": {"ms": t_b16 * 1e3, "samples_per_s": 16 * 128 * T / t_b16,
+                                      "note": "the reference's throughput FALLS with batch (python LUT loop, BASELINE.md "
+                                              "section 2); one B=64 call would take ~4x this"}}
+
+
+def load_pmc():
+    """Per-kernel counters of the round's committed rocprofv3 --pmc passes (tools/collect_profiles.sh + tools/pmc_digest.py)."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rnd, "pmc_kernels.json")
+        if os.path.exists(path):
+            try:
+                return json.load(open(path)), f"profiles/{rnd}/pmc_kernels.json"
+            except Exception:
+                pass
+    return None, None
+
+
+def kernel_roofline(name, pmc, ms, algo_flop=None, mfma_flop=None, hbm_note=None):
+    """One roofline entry: what bounds the kernel and how close it runs to that bound."""
+    e = {"kernel": name, "kernel_ms": ms}
+    k = (pmc or {}).get("kernels", {}).get(name)
+    if algo_flop is not None and ms:
+        e["algorithmic_tflops"] = algo_flop / (ms * 1e-3) / 1e12
+    if mfma_flop is not None and ms:
+        t = mfma_flop / (ms * 1e-3) / 1e12
+        e["mfma_f16_executed"] = {"achieved": t, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": t / PEAK_F16_MFMA_TFLOPS}
+    if k:
+        busy_cycles = k["waves"] * k["valu_active_quad_cycles_per_wave"] * 4.0     # VALU-busy SIMD-cycles per launch
+        if ms:
+            rate = busy_cycles / (ms * 1e-3)
+            e["valu_issue"] = {"achieved": rate / 1e9, "peak": N_SIMD * MAX_CLOCK_GHZ, "unit": "G VALU-busy SIMD-cycles/s",
+                               "frac": rate / (N_SIMD * MAX_CLOCK_GHZ * 1e9),
+                               "frac_at_clock_of_pmc_pass": k.get("valu_busy_frac"),
+                               "insts_per_wave": {"valu": round(k["valu_insts_per_wave"], 1), "trans": round(k["trans_insts_per_wave"], 1),
+                                                  "mfma": round(k["mfma_insts_per_wave"], 1)}}
+        if k.get("hbm_bytes_per_launch") and ms:
+            e["hbm"] = {"traffic": k["hbm_bytes_per_launch"], "achieved": k["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e12,
+                        "peak": PEAK_HBM_TBS, "unit": "TB/s", "frac": k["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e12 / PEAK_HBM_TBS}
+    if hbm_note:
+        e["note"] = hbm_note
+    return e
 
 
 def main():
     a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1 and os.environ.get("NWS_BENCH_SHARE_GPU") != "1":
+        launch_ranks(a)
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the product path)"
-    # NWS_BENCH_SHARE_GPU=1 (smoke-testing the N>1 code path on a 1-GPU box): every rank uses cuda:0 and the
-    # collectives go through gloo on host copies (NCCL/RCCL refuses two ranks on one device).  Never set by the driver.
-    share_gpu = os.environ.get("NWS_BENCH_SHARE_GPU") == "1"
-    if share_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     # NWS_BENCH_FORCE_DIST=1: run the N>1 code path (RCCL init, shared draws, all-gather) with world_size 1 -- the only way
     # to exercise it on real RCCL on a 1-GPU box.  Never set by the driver.
-    distributed = world > 1 or os.environ.get("NWS_BENCH_FORCE_DIST") == "1"
+    force_dist = os.environ.get("NWS_BENCH_FORCE_DIST") == "1"
+    # NWS_BENCH_SHARE_GPU=1 (smoke-testing the N>1 code path on a 1-GPU box with TWO processes): every rank uses cuda:0 and
+    # the collectives go through gloo (RCCL refuses two ranks on one device).  Never set by the driver.
+    share_gpu = os.environ.get("NWS_BENCH_SHARE_GPU") == "1"
+    if world != a.gpus and not (force_dist and world == 1) and not share_gpu:
+        print(f"bench.py: launched with WORLD_SIZE={world} but --gpus {a.gpus}: the two must agree", file=sys.stderr)
+        sys.exit(2)
+    if share_gpu:
+        local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        print(f"bench.py: rank {rank} wants cuda:{local_rank}, this box has {torch.cuda.device_count()} GPUs", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    distributed = world > 1 or force_dist
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -122,6 +240,7 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == world, (dist.get_world_size(), world)
     nws = importlib.import_module("neural-waveshaping-synthesis_amd")
     _lib = importlib.import_module("neural-waveshaping-synthesis_amd._lib")
     par = importlib.import_module("neural-waveshaping-synthesis_amd.parallel")
@@ -130,22 +249,30 @@ def main():
     model = nws.NeuralWaveshaping.load_from_checkpoint(wpath).to(dev).eval()
     if not a.exact:
         model.newt = nws.FastNEWT(model.newt)
+    if a.exciter_opts is not None:
+        model.exciter_opts = a.exciter_opts
+        model.invalidate_cache()
+    opts = model._engine.exciter_opts()
 
     B, T = a.batch, a.frames
     N = 128 * T
-    g = torch.Generator(device=dev).manual_seed(1000 + rank)
-    if a.inputs == "rand":
-        f0 = torch.rand(B, 1, T, device=dev, generator=g)         # time_forward_pass.py:34-40
-        control = torch.rand(B, 2, T, device=dev, generator=g)    # time_forward_pass.py:27-33
-    else:
-        tt = torch.arange(T, device=dev, dtype=torch.float32) * (128.0 / 16000.0)
-        base = 100.0 + 900.0 * torch.rand(B, 1, 1, device=dev, generator=g)
-        f0 = (base * (1.0 + 0.01 * torch.sin(2 * np.pi * 5.5 * tt).view(1, 1, T))).contiguous()
-        control = torch.randn(B, 2, T, device=dev, generator=g)
+    def make_inputs(r):
+        g = torch.Generator(device=dev).manual_seed(1000 + r)
+        if a.inputs == "rand":
+            f0_ = torch.rand(B, 1, T, device=dev, generator=g)         # time_forward_pass.py:34-40
+            control_ = torch.rand(B, 2, T, device=dev, generator=g)    # time_forward_pass.py:27-33
+        else:
+            tt = torch.arange(T, device=dev, dtype=torch.float32) * (128.0 / 16000.0)
+            base = 100.0 + 900.0 * torch.rand(B, 1, 1, device=dev, generator=g)
+            f0_ = (base * (1.0 + 0.01 * torch.sin(2 * np.pi * 5.5 * tt).view(1, 1, T))).contiguous()
+            control_ = torch.randn(B, 2, T, device=dev, generator=g)
+        return f0_, control_
+
+    f0, control = make_inputs(rank)
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, a.streams))]
     shared_gen = par.make_shared_generator(dev) if distributed else None   # same draws on every rank, no broadcast
-    use_pipe = bool(a.pipeline) and not share_gpu
+    use_pipe = bool(a.pipeline)
     pipe = None
     if use_pipe:
         pmod = importlib.import_module("neural-waveshaping-synthesis_amd.pipeline")
@@ -153,36 +280,52 @@ def main():
                                     audio_streams=len(streams), control_streams=max(1, a.control_streams), batched_gru=a.gru == "batched")
         streams = pipe.audio
     nbuf = len(pipe.slots) if use_pipe else len(streams)
-    full = [torch.empty((B * world, N), dtype=torch.float32, device=dev) for _ in range(nbuf)] if distributed else None
+    full, peer = None, None
+    gather_kind = a.gather if distributed else None
+    if distributed and (a.gather == "copy" or share_gpu):
+        # copy-engine all-gather: peer-mapped gather buffers, one device-to-device copy per peer (also the only form that
+        # works for two smoke-test ranks on ONE device, where RCCL refuses to initialise)
+        peer = par.PeerCopyAllGather(B, N, dev, nbuf=nbuf)
+        full = peer.full
+        gather_kind = "copy"
+    elif distributed:
+        full = [torch.empty((B * world, N), dtype=torch.float32, device=dev) for _ in range(nbuf)]
 
-    def step(i, pending):
+    def gather(i, y):
+        """all-gather of this step's waveforms on the CURRENT stream; returns a work handle (or None)"""
+        if peer is not None:
+            return peer.gather(y, i % nbuf)[1]
+        return dist.all_gather_into_tensor(full[i % nbuf], y, async_op=True)
+
+    def step(i, pending, do_gather=True, do_compute=True):
         if use_pipe:
             if not distributed:
                 pipe.submit(f0, control)
                 return None
             au = pipe.audio[i % len(pipe.audio)]        # the audio stream submit() is about to use for this batch
-            with torch.cuda.stream(au):                 # draws where they are consumed: nothing ever runs on the null stream
-                pu, nz = par.shared_draws(101, N - 1, dev, generator=shared_gen)   # identical on all ranks
-            y = pipe.submit(f0, control, phase_u=pu, noise=nz)
+            y = None
+            if do_compute:
+                with torch.cuda.stream(au):             # draws where they are consumed: nothing ever runs on the null stream
+                    pu, nz = par.shared_draws(101, N - 1, dev, generator=shared_gen)   # identical on all ranks (SURVEY 8(e))
+                y = pipe.submit(f0, control, phase_u=pu, noise=nz)
             with torch.cuda.stream(au):                 # ordered after this batch's reverb
                 if pending is not None:
                     pending.wait()
-                return dist.all_gather_into_tensor(full[i % nbuf], y, async_op=True)
+                if do_gather:
+                    return gather(i, y if y is not None else gather_src)
+            return None
         s = streams[i % len(streams)]
         with torch.cuda.stream(s):
-            if distributed and share_gpu:   # smoke mode only: host-staged gloo collectives
-                pu, nz = par.shared_draws(101, N - 1, torch.device("cpu"))
-                y = model(f0, control, phase_u=pu.to(dev), noise=nz.to(dev))
-                parts = [torch.empty((B, N)) for _ in range(world)]
-                dist.all_gather(parts, y.cpu())
-                full[i % nbuf].copy_(torch.cat(parts, 0))
-                return None
             if distributed:
-                pu, nz = par.shared_draws(101, N - 1, dev, generator=shared_gen)   # identical on all ranks
-                y = model(f0, control, phase_u=pu, noise=nz)
+                y = None
+                if do_compute:
+                    pu, nz = par.shared_draws(101, N - 1, dev, generator=shared_gen)   # identical on all ranks (SURVEY 8(e))
+                    y = model(f0, control, phase_u=pu, noise=nz)
                 if pending is not None:
                     pending.wait()
-                return dist.all_gather_into_tensor(full[i % nbuf], y, async_op=True)
+                if do_gather:
+                    return gather(i, y if y is not None else gather_src)
+                return None
             model(f0, control)
         return None
 
@@ -192,6 +335,30 @@ def main():
         for s in streams:
             torch.cuda.current_stream().wait_stream(s)
 
+    def timed(n_steps, **kw):
+        """n_steps of the issue pattern, bracketed by barrier + synchronize on both sides; seconds, max over ranks"""
+        pending = None
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            pending = step(i, pending, **kw)
+        if pending is not None:
+            pending.wait()
+        join_streams()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        per_rank = [el]
+        if distributed:
+            tt = torch.tensor([el], dtype=torch.float64, device="cpu" if share_gpu else dev)
+            allr = [torch.zeros_like(tt) for _ in range(world)]
+            dist.all_gather(allr, tt)
+            per_rank = [float(t.item()) for t in allr]
+        return max(per_rank), per_rank
+
     # Priming, before the W warmup steps and untimed like them (reported as priming_steps): (1) every stream's caching-
     # allocator pool and every workspace of the ring has to have been through one full cycle, or the first 2 * depth timed
     # steps contain hipMallocs (measured: 1.2 ms/step instead of 0.47 for K = 50, W = 5 with 6 workspaces in flight);
@@ -199,6 +366,8 @@ def main():
     # What stays inside the timed region by construction is the pipeline's fill and drain (first control half, last audio
     # half: 0.5-1 ms per timed region): 0.518 ms/step at K = 10, 0.491 at 50, 0.471 at 200, 0.468 at 1000.
     priming = max(2 * nbuf + 2, 120)
+    gather_src = torch.zeros((B, N), dtype=torch.float32, device=dev) if distributed else None
+    extra = {}
     with torch.no_grad():
         pending = None
         for i in range(priming + a.warmup):
@@ -207,42 +376,34 @@ def main():
             pending.wait()
         join_streams()
         torch.cuda.synchronize()
-        # live HIP-event timing of the dominant kernel on its launch stream, inside the timed region
+        # live HIP-event timing of the dominant kernel (and the GRU) on their launch streams, inside the timed region
         _lib.check(_lib.lib().nws_profile_begin(a.steps, (1 << 3) | (1 << 1)))
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        pending = None
-        for i in range(a.steps):
-            pending = step(i, pending)
-        if pending is not None:
-            pending.wait()
-        join_streams()
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
+        elapsed, per_rank = timed(a.steps)
         ms = (C.c_float * (a.steps * 6))()
         n = C.c_int(0)
         _lib.check(_lib.lib().nws_profile_collect(ms, C.byref(n)))
         k_ms = float(np.mean([ms[i * 6 + 3] for i in range(n.value)])) if n.value else float("nan")
         gru_ms_live = float(np.mean([ms[i * 6 + 1] for i in range(n.value)])) if n.value else float("nan")
+        _lib.lib().nws_profile_end()
 
         if distributed:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
             # the gathered batch must hold every rank's rows (rank r at rows [r*B, (r+1)*B))
             last = full[(a.steps - 1) % nbuf]
             assert torch.isfinite(last).all() and float(last[B * (world - 1):].abs().max()) > 0.0
+            # exchange and compute told apart (outside the headline region, same issue pattern): the all-gather alone
+            # (compute skipped: a resident (B, N) shard is gathered every step) and the compute alone (no gather)
+            k2 = max(10, min(a.steps, 100))
+            g_el, g_ranks = timed(k2, do_compute=False)
+            c_el, c_ranks = timed(k2, do_gather=False)
+            extra["exchange"] = {"kind": gather_kind, "gather_ms": g_el / k2 * 1e3, "compute_only_ms": c_el / k2 * 1e3,
+                                 "steps": k2, "bytes_gathered_per_rank_per_step": B * world * N * 4,
+                                 "gather_ms_per_rank": [round(t / k2 * 1e3, 4) for t in g_ranks],
+                                 "compute_only_ms_per_rank": [round(t / k2 * 1e3, 4) for t in c_ranks]}
 
-        extra = {}
         if use_pipe:
             # self-check outside the timed region: the issue pattern of the timed loop (pipeline, and the all-gather when
             # distributed) must return bit for bit what a plain forward returns for the same draws
-            _lib.lib().nws_profile_end()
-            gchk = torch.Generator(device=dev).manual_seed(4242 + rank)
+            gchk = torch.Generator(device=dev).manual_seed(4242)   # the same draws on every rank, like the timed loop
             draws = [(torch.rand(101, device=dev, generator=gchk), torch.rand(N - 1, device=dev, generator=gchk))
                      for _ in range(12)]
             torch.cuda.synchronize()
@@ -254,7 +415,7 @@ def main():
                     with torch.cuda.stream(pipe.audio[i % len(pipe.audio)]):
                         if pend is not None:
                             pend.wait()
-                        pend = dist.all_gather_into_tensor(full[i % nbuf], y, async_op=True)
+                        pend = gather(i, y)
             if pend is not None:
                 pend.wait()
             pipe.synchronize()
@@ -264,6 +425,19 @@ def main():
                 wrong += 0 if torch.equal(y, model(f0, control, phase_u=pu_c, noise=nz_c)) else 1
             torch.cuda.synchronize()
             extra["pipeline_selfcheck"] = {"batches": len(ys), "mismatching": wrong}
+            if distributed:
+                # the last gathered buffer must hold this rank's own last batch at its rows, bit for bit
+                if share_gpu:
+                    dist.barrier()
+                # the last gathered buffer must hold EVERY rank's last batch at its rows, bit for bit: each rank re-renders
+                # the other ranks' batches itself (their inputs come from seeded generators, the draws are shared)
+                last = full[(len(ys) - 1) % nbuf]
+                ok = True
+                for r in range(world):
+                    y_r = ys[-1] if r == rank else model(*make_inputs(r), phase_u=draws[-1][0], noise=draws[-1][1])
+                    ok = ok and bool(torch.equal(last[r * B:(r + 1) * B], y_r))
+                extra["pipeline_selfcheck"]["gathered_rows_match"] = ok
+                wrong += 0 if ok else 1
             if wrong:   # reported, not raised: the line must still come out, with the evidence in it
                 print(f"bench.py: pipeline self-check FAILED on rank {rank}: {wrong} of {len(ys)} batches differ from the plain "
                       f"forward", file=sys.stderr)
@@ -333,56 +507,78 @@ def main():
         total_samples = B * world * N * a.steps
         value = total_samples / elapsed
         ms_per_step = elapsed / a.steps * 1e3
+        pmc, pmc_src = load_pmc()
+        if pmc and (pmc.get("batch_per_gpu") != B or pmc.get("frames") != T or a.exact or pmc.get("exciter_opts", 0) != opts):
+            pmc = None        # counters of another workload: not quoted
+        st = extra.get("stage_ms", {})
+        one_term = bool(opts & 2) and not a.exact
+        terms = 2 if one_term else 3
         flops = FLOP_PER_SAMPLE_EXCITER_NEWT * B * N
-        achieved = flops / (k_ms * 1e-3) / 1e12
-        traffic, valu_issue = None, None   # from the committed rocprofv3 PMC passes (profiles/r01/pmc_traffic.json)
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
-            if tr["batch_per_gpu"] == B and tr["frames"] == T and not a.exact:
-                traffic = tr["hbm_bytes_per_launch"]
-                if tr.get("valu_busy_frac"):
-                    # VALU-busy share of the kernel: (waves x VALU-active cycles per wave) / (1024 SIMDs x kernel cycles)
-                    valu_issue = {"insts_per_wave": round(tr["valu_insts_per_wave"], 1),
-                                  "trans_per_wave": round(tr["trans_insts_per_wave"], 1),
-                                  "busy_frac_of_kernel_cycles": round(tr["valu_busy_frac"], 3),
-                                  "source": "rocprofv3 --pmc, one stream (profiles/r01/pmc_traffic.json)"}
-        except Exception:
-            pass
-        mfma_exec = MFMA_F16_FLOP_PER_SAMPLE_EXECUTED * B * N / (k_ms * 1e-3) / 1e12
+        mfma_flop = exciter_mfma_flop_per_sample(terms, not (opts & 1) and not a.exact) * B * N
+        dom = kernel_roofline("exciter_newt_kernel", pmc, k_ms, algo_flop=flops, mfma_flop=mfma_flop)
+        vi = dom.get("valu_issue")
+        # Headline roofline object.  The kernel is bound by VALU issue (sines, split, table index math; every vector
+        # instruction occupies its SIMD's issue port for 2-8 cycles and an MFMA hides at most ~1/3 of its own duration under
+        # them: tools/ubench/valu_rate.hip), so `frac` is the VALU-busy share of the SIMD-cycles the launch
+        # takes; the matrix-pipe and algorithmic-flop fractions ride along.
+        roofline = {"bound": "valu_issue", "kernel": "exciter_newt_kernel",
+                    "achieved": vi["achieved"] if vi else None, "peak": N_SIMD * MAX_CLOCK_GHZ, "unit": "G VALU-busy SIMD-cycles/s",
+                    "frac": vi["frac"] if vi else None,
+                    "frac_at_clock_of_pmc_pass": vi["frac_at_clock_of_pmc_pass"] if vi else None,
+                    "traffic": (dom.get("hbm") or {}).get("traffic"), "kernel_ms": k_ms,
+                    "kernel_ms_isolated": st.get("exciter_newt"),
+                    "algorithmic": {"flop_per_launch": flops, "achieved": flops / (k_ms * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS,
+                                    "unit": "TFLOP/s", "frac": flops / (k_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                                    "note": "14 969 flop/sample (86 % in the 101->64 contraction, which runs on the fp16 matrix "
+                                            "pipe): algorithmic flop / live kernel time against the dense fp16 MFMA peak"},
+                    "mfma_f16_executed": dom.get("mfma_f16_executed"), "hbm": dom.get("hbm"),
+                    "valu_insts_per_wave": (vi or {}).get("insts_per_wave"), "counters": pmc_src if pmc else None,
+                    "gru_ms_in_timed_region": gru_ms_live}
+        roofline_all = [dom]
+        if st:
+            roofline_all += [
+                kernel_roofline("control_gru_kernel", pmc, st.get("control_gru"), algo_flop=FLOP_PER_STEP_GRU * B * T,
+                                hbm_note="sequential recurrence, one workgroup per utterance: bound by the per-step latency chain "
+                                         "(B of 256 CUs busy); fp32 VALU peak of those CUs = B/256 x 157.3 TFLOP/s"),
+                kernel_roofline("frame_mlps16_kernel", pmc, st.get("frame_mlps"), algo_flop=FLOP_PER_FRAME_MLPS * B * T,
+                                mfma_flop=3 * FLOP_PER_FRAME_MLPS * B * T),
+                kernel_roofline("fir_noise_mfma_kernel", pmc, st.get("fir_noise"), algo_flop=FLOP_PER_FRAME_NOISE * B * T,
+                                mfma_flop=3 * FLOP_PER_FRAME_NOISE * B * T),
+                kernel_roofline("reverb (col125_fwd + row + col125_inv)", pmc, st.get("reverb"),
+                                hbm_note="memory-latency bound four-step FFT: 3 passes over (B, L) complex planes")]
+            if pmc:   # the reverb's three launches: HBM traffic summed
+                tot = sum(pmc["kernels"].get(kn, {}).get("hbm_bytes_per_launch", 0.0) for kn in ("col125_fwd_kernel", "row_kernel", "col125_inv_kernel"))
+                if tot and st.get("reverb"):
+                    roofline_all[-1]["hbm"] = {"traffic": tot, "achieved": tot / (st["reverb"] * 1e-3) / 1e12, "peak": PEAK_HBM_TBS,
+                                               "unit": "TB/s", "frac": tot / (st["reverb"] * 1e-3) / 1e12 / PEAK_HBM_TBS}
+        if a.exact:
+            dtype = "f32 (101->64 mixer, frame MLPs, FIR noise: fp16x2-split MFMA contractions = 22-bit products, fp32 accumulate; exact sin-MLP shapers in fp32)"
+        elif one_term:
+            dtype = ("f32 (frame MLPs, FIR noise: fp16x2-split MFMA contractions, fp32 accumulate; 101->64 mixer: weights fp16x2, "
+                     "sines ONE fp16 term = 11-bit mixer inputs, fp32 accumulate)")
+        else:
+            dtype = "f32 (fp16x2-split MFMA contractions = 22-bit products, fp32 accumulate; FiLM interpolation bf16x3-split MFMA = exact fp32 operands)"
         out = {
             "metric": "audio_samples_per_sec", "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "priming_steps": priming, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"NEWT forward, vn checkpoint, {'exact sin-MLP shapers' if a.exact else 'FastNEWT LUT'}, "
                                    f"batch {B}/GPU x {T} frames (4 s @ 16 kHz), "
                                    f"{'torch.rand F0/control' if a.inputs == 'rand' else 'F0 ~ U[100,1000] Hz with vibrato, control ~ N(0,1)'}, "
-                                   f"RNG draws on device{', RCCL all-gather of waveforms' if distributed else ''}",
+                                   f"RNG draws on device{', all-gather of waveforms (' + str(gather_kind) + ')' if distributed else ''}",
                        "batch_per_gpu": B, "frames": T, "samples_per_utterance": N, "parallelism": f"batch-shard x{world}",
-                       "streams": len(streams),
+                       "exciter_opts": opts, "streams": len(streams),
                        "issue": (f"ForwardPipeline: control half (carries + {a.gru} GRU) on {len(pipe.control)} side stream(s), "
                                  f"audio half on {len(streams)} streams, {len(pipe.slots)} workspaces in flight") if use_pipe
                        else f"whole forwards round-robin on {len(streams)} streams"},
             "x_realtime_aggregate": value / 16000.0,
             "rtf_per_utterance": (ms_per_step * 1e-3) / (N / 16000.0) / B,
-            "roofline": {"bound": "mfma", "kernel": "exciter_newt_kernel", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel_ms": k_ms, "flop_per_launch": flops, "gru_ms_in_timed_region": gru_ms_live,
-                         "note": "achieved = algorithmic fp32 flop per launch / live kernel time, peak = fp32 matrix (= vector) "
-                                 "peak as the path computes in f32.  The 101->64 contraction runs as three fp16 MFMAs per fp32 "
-                                 "product on the fp16 matrix pipe (16x the fp32 MFMA rate), which is how frac can pass 1; the "
-                                 "kernel is bound by VALU issue (sines, table index math), see valu_issue and DESIGN.md 3.2",
-                         "mfma_f16_executed": {"achieved": mfma_exec, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                               "frac": mfma_exec / PEAK_F16_MFMA_TFLOPS},
-                         "valu_issue": valu_issue,
-                         # the same kernel with nothing else in flight (diagnostic pass, one stream): steps of the timed
-                         # region overlap on --streams HIP streams, which stretches each individual launch
-                         "kernel_ms_isolated": extra.get("stage_ms", {}).get("exciter_newt"),
-                         "frac_isolated": (flops / (extra["stage_ms"]["exciter_newt"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS)
-                         if extra.get("stage_ms") else None},
+            "ms_per_step_per_rank": [round(t / a.steps * 1e3, 4) for t in per_rank],
+            "roofline": roofline, "roofline_all": roofline_all,
         }
         out.update(extra)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wpath, a.cpu_iters, T)
+            out["cpu_baseline"] = cpu_baseline(wpath, T, a.cpu_seconds)
     if distributed:
         dist.destroy_process_group()
     if rank == 0:

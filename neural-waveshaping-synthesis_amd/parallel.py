@@ -46,12 +46,13 @@ def shared_draws(n_harmonics: int, n_noise: int, device, group=None, src: int = 
 
 
 def render_sharded(render_fn, f0, control, group=None, phase_u=None, noise=None, gather: bool = True,
-                   out: torch.Tensor | None = None, async_op: bool = False):
+                   out: torch.Tensor | None = None, async_op: bool = False, force_collective: bool = False):
     """f0 (B,1,T), control (B,C,T) are the FULL batch on every rank (or pre-sharded with gather-only use).
 
     Returns the full (B, N) result on every rank (gather=True) or the local shard.  With
     ``async_op=True`` returns (out, work) so the all-gather of this step overlaps the next render.
     Equal shards use one all_gather_into_tensor; ragged shards fall back to all_gather of padded rows.
+    ``force_collective=True`` issues the all-gather even at world size 1 (exercises the RCCL call on a 1-GPU box).
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -61,7 +62,7 @@ def render_sharded(render_fn, f0, control, group=None, phase_u=None, noise=None,
     if phase_u is None or noise is None:
         raise ValueError("render_sharded needs the shared draws (see shared_draws())")
     local = render_fn(f0[lo:hi].contiguous(), control[lo:hi].contiguous(), phase_u, noise)
-    if not gather or world == 1:
+    if not gather or (world == 1 and not (force_collective and dist.is_initialized())):
         return (local, None) if async_op else local
     N = local.shape[-1]
     if B % world == 0:
@@ -77,3 +78,62 @@ def render_sharded(render_fn, f0, control, group=None, phase_u=None, noise=None,
     full = torch.cat([parts[r][: shard_bounds(B, world, r)[1] - shard_bounds(B, world, r)[0]] for r in range(world)], 0)
     del hop_n
     return (full, None) if async_op else full
+
+
+class PeerCopyAllGather:
+    """All-gather of the rendered waveforms WITHOUT collective kernels: every rank pushes its (b, N) shard straight into
+    every peer's gather buffer with device-to-device copies (hipMemcpyAsync on peer-mapped memory = the SDMA copy
+    engines over the point-to-point xGMI links, one link per peer: 7 x 16.4 MB in parallel at 64 clips per rank), so that
+    no compute unit is taken from the oscillator kernels the way RCCL's ring/tree kernels take them.
+
+    Set-up (once): each rank allocates `nbuf` gather buffers of (world * b, N), exports them as IPC handles
+    (dmabuf IPC; HSA_ENABLE_IPC_MODE_LEGACY=0 must be set, as it is on the GPU boxes) and opens every peer's buffers.
+    Per step: `gather(y, slot)` enqueues world copies on the CURRENT stream, then one tiny stream-ordered collective
+    (4-byte all-reduce; on the "gloo" test backend a host barrier after a stream sync) whose completion on rank q implies
+    that every rank's copies into q's buffer were complete when that rank joined it.  Returns (full_buffer, work).
+
+    The caller must not reuse slot s for a new gather before every rank has finished reading its full[s] (bench.py cycles
+    through `nbuf` slots and never reads them inside the loop; a consumer would put its own synchronisation there).
+    """
+
+    def __init__(self, rows: int, n_samples: int, device, nbuf: int = 2, group=None, dtype=torch.float32):
+        if not dist.is_initialized():
+            raise RuntimeError("PeerCopyAllGather needs an initialised process group (handle exchange)")
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.rows, self.n = int(rows), int(n_samples)
+        self.device = torch.device(device)
+        self.backend = dist.get_backend(group)
+        self.full = [torch.empty((self.world * self.rows, self.n), dtype=dtype, device=self.device) for _ in range(nbuf)]
+        # export: one IPC handle per buffer (the same mechanism torch.multiprocessing uses to share CUDA tensors)
+        mine = [(t.untyped_storage()._share_cuda_(), t.storage_offset(), tuple(t.shape), tuple(t.stride())) for t in self.full]
+        everybody = [None] * self.world
+        dist.all_gather_object(everybody, mine, group=group)
+        self.remote = []        # remote[p][slot] = rank p's gather buffer, opened in this process
+        for p, handles in enumerate(everybody):
+            if p == self.rank:
+                self.remote.append(self.full)
+                continue
+            opened = []
+            for h, off, shape, stride in handles:
+                storage = torch.UntypedStorage._new_shared_cuda(*h)
+                t = torch.empty(0, dtype=dtype, device=storage.device).set_(storage, off, shape, stride)
+                opened.append(t)
+            self.remote.append(opened)
+        self._flag = torch.zeros(1, dtype=torch.float32, device=self.device)
+        dist.barrier(group=group)   # nobody starts pushing before everybody has opened everything
+
+    def gather(self, y: torch.Tensor, slot: int):
+        if y.shape != (self.rows, self.n) or not y.is_contiguous():
+            raise ValueError(f"expected a contiguous {(self.rows, self.n)} shard, got {tuple(y.shape)}")
+        lo = self.rank * self.rows
+        for k in range(self.world):             # start with the right-hand neighbour: the ranks' pushes spread over the links
+            p = (self.rank + k) % self.world
+            self.remote[p][slot][lo:lo + self.rows].copy_(y, non_blocking=True)
+        if self.backend == "gloo":              # CPU-side test backend: no stream-ordered collectives
+            torch.cuda.current_stream(self.device).synchronize()
+            dist.barrier(group=self.group)
+            return self.full[slot], None
+        work = dist.all_reduce(self._flag, group=self.group, async_op=True)   # ordered after the copies on this stream
+        return self.full[slot], work

@@ -1,0 +1,96 @@
+"""-m gpu tests of the multi-GPU path on the hardware available to the test box (ONE MI355X): the sharded render with the
+HIP engine on real RCCL at world size 1, bench.py's N>1 code path on RCCL (world size 1) and on two ranks sharing the GPU
+(peer-mapped copy-engine all-gather between two processes), and bench.py's refusal to time fewer GPUs than asked for."""
+import importlib
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT, load_npz
+from gpu_util import build_model, dev
+
+pytestmark = pytest.mark.gpu
+ENV = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="8")
+SMALL = ["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--batch1-iters", "0", "--batch", "4", "--frames", "16"]
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert lines, stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_render_sharded_hip_engine_on_rccl_world1():
+    import torch.distributed as dist
+
+    par = importlib.import_module("neural-waveshaping-synthesis_amd.parallel")
+    model = build_model(True)
+    g = load_npz("g4_stream.npz")
+    f0, control = dev(g["f0_T32"]), dev(g["control_T32"])
+    pu, nz = dev(g["phase_u_T32"]), dev(g["noise_T32"])
+    ref = model(f0, control, phase_u=pu, noise=nz)
+    port = 29600 + os.getpid() % 300
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        render = lambda a, b, p, n: model(a, b, phase_u=p, noise=n)  # noqa: E731
+        full = par.render_sharded(render, f0, control, phase_u=pu, noise=nz, force_collective=True)
+        out, work = par.render_sharded(render, f0, control, phase_u=pu, noise=nz, force_collective=True, async_op=True)
+        assert work is not None          # the RCCL all-gather really was issued
+        work.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(full, ref) and torch.equal(out, ref)
+        # shared draws: generator form (no collective) and broadcast form agree with themselves across calls
+        gen = par.make_shared_generator(torch.device("cuda", 0), seed=7)
+        a1 = par.shared_draws(101, 4095, torch.device("cuda", 0), generator=gen)
+        gen2 = par.make_shared_generator(torch.device("cuda", 0), seed=7)
+        a2 = par.shared_draws(101, 4095, torch.device("cuda", 0), generator=gen2)
+        assert torch.equal(a1[0], a2[0]) and torch.equal(a1[1], a2[1])
+        b1 = par.shared_draws(101, 4095, torch.device("cuda", 0))     # drawn on rank 0, broadcast skipped at world 1
+        assert b1[0].shape == (101,) and b1[1].shape == (4095,)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_distributed_code_path_on_rccl_world1():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL], env=dict(ENV, NWS_BENCH_FORCE_DIST="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 1 and j["exchange"]["kind"] == "rccl" and j["exchange"]["gather_ms"] > 0
+    assert j["pipeline_selfcheck"]["mismatching_all_ranks"] == 0 and j["pipeline_selfcheck"]["gathered_rows_match"]
+    # the copy-engine form of the same path (no peers at world 1: the local copy + the stream-ordered flag collective)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL, "--gather", "copy"],
+                       env=dict(ENV, NWS_BENCH_FORCE_DIST="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    assert j["exchange"]["kind"] == "copy" and j["pipeline_selfcheck"]["mismatching_all_ranks"] == 0
+
+
+def test_bench_refuses_more_gpus_than_present():
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), *SMALL], env=ENV,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and f"needs {n} GPUs" in r.stderr, (r.returncode, r.stderr[-1000:])
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]        # no JSON line: nothing was timed
+    # WORLD_SIZE and --gpus must agree
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL],
+                       env=dict(ENV, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "must agree" in r.stderr
+
+
+def test_two_ranks_on_one_gpu_peer_copy_all_gather():
+    """Two processes, both on cuda:0 (rendezvous over gloo): each opens the other's gather buffers through IPC handles and
+    pushes its shard with device-to-device copies - the N>1 exchange of bench.py --gather copy, minus the second GPU."""
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", *SMALL]
+    r = subprocess.run(cmd, env=dict(ENV, NWS_BENCH_SHARE_GPU="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and j["exchange"]["kind"] == "copy"
+    assert len(j["ms_per_step_per_rank"]) == 2 and len(j["exchange"]["gather_ms_per_rank"]) == 2
+    assert j["pipeline_selfcheck"]["mismatching_all_ranks"] == 0 and j["pipeline_selfcheck"]["gathered_rows_match"]

@@ -1,43 +1,26 @@
 #!/bin/bash
-# Round evidence set, run ON THE GPU BOX from the repo root:  bash tools/collect_profiles.sh r01
-# Writes gpurun_out/prof_<round>/ (kernel traces with --stats, separate --pmc passes, bench lines, parity report);
-# tools/pmc_digest.py turns that into the files committed under profiles/<round>/.
-set -u
-ROUND=${1:-r01}
-R=$PWD
-OUT=$R/gpurun_out/prof_$ROUND
-rm -rf "$OUT"; mkdir -p "$OUT"
-cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --no-cpu-baseline --batch1-iters 0"
-# 1. the default bench line (with cpu baseline, batch-1 and streaming extras)
-(cd $R && python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err")
-# 2. kernel traces + stats: default issue (pipeline, 2 audio streams) and one stream, no pipeline (undisturbed kernels)
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_default" -o bench -- $BENCH --steps 200 --warmup 20 > "$OUT/trace_default.log" 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_1stream" -o bench -- $BENCH --steps 200 --warmup 20 --pipeline 0 --streams 1 > "$OUT/trace_1stream.log" 2>&1
-# 3. counters, one stream, separate passes (never together with trace domains other than the kernel trace)
-P="$BENCH --steps 5 --warmup 2 --pipeline 0 --streams 1"
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o bench -- $P > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o bench -- $P > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d "$OUT/pmc_sq" -o bench -- $P > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_TRANS_F32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS --output-format csv -d "$OUT/pmc_mfma" -o bench -- $P > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_l2" -o bench -- $P > /dev/null 2>&1
-cd $R
+# Collect the round's rocprofv3 evidence ON THE GPU BOX:  bash tools/collect_profiles.sh r02
+#   gpurun_out/prof_<round>/trace_default   --kernel-trace --stats of the default bench command (pipelined issue)
+#   gpurun_out/prof_<round>/trace_1stream   same, --pipeline 0 --streams 1 (undisturbed per-kernel durations)
+#   gpurun_out/prof_<round>/pmc_*           counter passes (separate runs: SQ has 8 slots, FETCH_SIZE and WRITE_SIZE do not
+#                                           fit one pass; never combined with sys/hip/hsa traces)
+# then tools/pmc_digest.py condenses them; copy the digest files into profiles/<round>/ and commit.
+R=${1:-r02}
+OUT=gpurun_out/prof_$R
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+BENCH="python bench.py --no-cpu-baseline --batch1-iters 0 --warmup 5 ${NWS_PROFILE_ARGS:-}"
+rocprofv3 --kernel-trace --stats -d "$OUT/trace_default" -- $BENCH --steps 50 > "$OUT/trace_default.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/trace_1stream" -- $BENCH --steps 30 --pipeline 0 --streams 1 > "$OUT/trace_1stream.log" 2>&1
+P="$BENCH --steps 6 --pipeline 0 --streams 1"
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_TRANS_F32 SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY \
+  -d "$OUT/pmc_sq" -- $P > "$OUT/pmc_sq.log" 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
+  -d "$OUT/pmc_mfma" -- $P > "$OUT/pmc_mfma.log" 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_l2" -- $P > "$OUT/pmc_l2.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -- $P > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" -- $P > "$OUT/pmc_write.log" 2>&1
 python tools/pmc_digest.py "$OUT" > "$OUT/digest.log" 2>&1
-tail -30 "$OUT/digest.log"
-# 4. the co-execution hazard matrix (csrc/coexec_probe.hip)
-python tools/coexec_probe.py --json "$OUT/coexec_matrix.json" > "$OUT/coexec_matrix.txt" 2>&1
-tail -12 "$OUT/coexec_matrix.txt"
-# 5. parity report of the GPU suite
-python -m pytest tests -m gpu -q > "$OUT/pytest_gpu.log" 2>&1; tail -3 "$OUT/pytest_gpu.log"
-cp gpurun_out/parity_report.json "$OUT/parity_report.json" 2>/dev/null
-# 6. other bench configurations (one line each) and a long bit-exact soak of the default pipeline
-(python bench.py --no-cpu-baseline --inputs realistic | grep '^{' > "$OUT/bench_realistic_inputs.json") 2>/dev/null
-(python bench.py --no-cpu-baseline --exact | grep '^{' > "$OUT/bench_exact_shapers.json") 2>/dev/null
-(NWS_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline | grep '^{' > "$OUT/bench_world1_rccl.json") 2>/dev/null
-python tools/soak_pipeline.py --rounds 250 > "$OUT/soak_pipeline.json" 2>/dev/null; cat "$OUT/soak_pipeline.json"
-# 7. exact-shaper mode, one stream: kernel stats (the shaper-bank kernel)
-cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_exact" -o bench -- $BENCH --exact --steps 50 --warmup 5 --pipeline 0 --streams 1 > "$OUT/trace_exact.log" 2>&1
-cd $R
-cp $(find "$OUT/trace_exact" -name "*kernel_stats.csv" | head -1) "$OUT/rocprofv3_kernel_stats_exact_1stream.csv"
-head -4 "$OUT/rocprofv3_kernel_stats_exact_1stream.csv"
+# keep the merge-back small: the raw per-dispatch csv files are dropped, the digests stay
+find "$OUT" -name "*.csv" ! -name "*kernel_stats.csv" ! -name "rocprofv3_kernel_stats_*" -size +2M -delete
+ls -la "$OUT"

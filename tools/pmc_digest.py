@@ -50,6 +50,38 @@ def main(root):
             f"WRITE_KB {g('WRITE_SIZE'):8.0f} | GUI_ACTIVE {g('GRBM_GUI_ACTIVE'):.3g}")
     open(os.path.join(root, "pmc_digest.txt"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
+    # per-kernel record for bench.py's roofline / roofline_all (profiles/<round>/pmc_kernels.json)
+    stats = {}
+    for path in glob.glob(os.path.join(root, "trace_1stream", "**", "*kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(path)):
+            stats[short(r["Name"])] = float(r["AverageNs"])
+    kernels = {}
+    for k, m in out.items():
+        w = m.get("SQ_WAVES", 0) or 1
+        name = re.sub(r"<.*", "", k)
+        e = {"waves": w, "valu_insts_per_wave": m.get("SQ_INSTS_VALU", 0) / w, "mfma_insts_per_wave": m.get("SQ_INSTS_MFMA", 0) / w,
+             "trans_insts_per_wave": m.get("SQ_INSTS_VALU_TRANS_F32", 0) / w,
+             "valu_active_quad_cycles_per_wave": m.get("SQ_ACTIVE_INST_VALU", 0) / w,
+             "wave_quad_cycles_per_wave": m.get("SQ_WAVE_CYCLES", 0) / w,
+             "mfma_busy_cycles_per_wave": m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / w,
+             "wait_any_frac_of_wave_cycles": m.get("SQ_WAIT_ANY", 0) / (m.get("SQ_WAVE_CYCLES", 0) or 1),
+             "wait_inst_frac_of_wave_cycles": m.get("SQ_WAIT_INST_ANY", 0) / (m.get("SQ_WAVE_CYCLES", 0) or 1)}
+        if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+            e["fetch_kb"], e["write_kb"] = m["FETCH_SIZE"], m["WRITE_SIZE"]
+            e["hbm_bytes_per_launch"] = (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0   # gfx950: FETCH_SIZE x2 (MICROARCH guide)
+        ns, gui = stats.get(k), m.get("GRBM_GUI_ACTIVE")
+        if ns and gui:
+            if gui / ns > 4.0:
+                gui /= 8.0
+            e.update(kernel_avg_ns_one_stream=ns, kernel_cycles=gui, clock_ghz_during_pass=gui / ns,
+                     valu_busy_frac=w * e["valu_active_quad_cycles_per_wave"] * 4.0 / (1024.0 * gui))
+        kernels[name] = e
+    json.dump({"source": "rocprofv3 --pmc, separate passes, one stream, whole forwards (tools/collect_profiles.sh, tools/pmc_digest.py)",
+               "batch_per_gpu": int(os.environ.get("NWS_PROFILE_BATCH", 64)), "frames": int(os.environ.get("NWS_PROFILE_FRAMES", 500)),
+               "exciter_opts": int(os.environ.get("NWS_EXCITER_OPTS", 0)),
+               "correction": "FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md HBM "
+                             "section); WRITE_SIZE as reported", "kernels": kernels},
+              open(os.path.join(root, "pmc_kernels.json"), "w"), indent=1)
     ex = next((v for k, v in out.items() if k.startswith("exciter_newt_kernel")), None)
     if ex and "FETCH_SIZE" in ex and "WRITE_SIZE" in ex:
         w = ex.get("SQ_WAVES", 0) or 1
