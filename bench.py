@@ -302,7 +302,8 @@ def main():
             if not distributed:
                 pipe.submit(f0, control)
                 return None
-            au = pipe.audio[i % len(pipe.audio)]        # the audio stream submit() is about to use for this batch
+            # the audio stream submit() is about to use for this batch (gather-only steps just alternate)
+            au = pipe.next_audio_stream() if do_compute else pipe.audio[i % len(pipe.audio)]
             y = None
             if do_compute:
                 with torch.cuda.stream(au):             # draws where they are consumed: nothing ever runs on the null stream
@@ -409,10 +410,11 @@ def main():
             torch.cuda.synchronize()
             ys, pend = [], None
             for i, (pu_c, nz_c) in enumerate(draws):
+                au = pipe.next_audio_stream()
                 y = pipe.submit(f0, control, phase_u=pu_c, noise=nz_c)
                 ys.append(y)
                 if distributed:
-                    with torch.cuda.stream(pipe.audio[i % len(pipe.audio)]):
+                    with torch.cuda.stream(au):
                         if pend is not None:
                             pend.wait()
                         pend = gather(i, y)

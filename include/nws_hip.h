@@ -102,7 +102,10 @@ typedef struct NwsWeights {
 } NwsWeights;
 #define NWS_EXCITER_VALU_FILM 1 /* round-1 form: FiLM parameters interpolated on the VALU (kept for A/B timing) */
 #define NWS_EXCITER_ONE_TERM 2  /* sines as ONE fp16 term: 2 instead of 3 MFMAs per product and no residual split (-15 %
-                                   kernel time); mixer inputs carry 11 bits: ~1e-5 RMS end to end instead of ~3e-7 */
+                                   kernel time); mixer inputs carry 11 bits: 4e-6 .. 1.1e-5 RMS end to end on the shipped
+                                   checkpoints instead of ~3e-7 */
+#define NWS_EXCITER_HYBRID 4    /* two fp16 terms for the mixer bias + harmonics 1..15 (K-step 0: 61-85 % of the mixer's
+                                   weight energy in the shipped checkpoints), one term for harmonics 16..101 */
 
 int nws_abi_version(void);
 /* sizeof of the C structs above as this library was compiled (0 NwsWeights, 1 NwsReverbPlan, 2 NwsForwardAux): lets a

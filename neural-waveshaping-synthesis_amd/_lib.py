@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libnws_hip.so")
 ABI_VERSION = 2          # include/nws_hip.h NWS_ABI_VERSION
 EXCITER_VALU_FILM = 1    # NwsWeights.exciter_opts bits (include/nws_hip.h)
 EXCITER_ONE_TERM = 2
+EXCITER_HYBRID = 4
 N_HARMONICS = 101
 N_SHAPERS = 64
 HIDDEN = 128

@@ -35,7 +35,8 @@ constexpr float kPi = 3.141592653589793f;   // fl32(math.pi)
 enum Opt {
   kOptScalarSines = 1,  // main loop in scalar fp32: a v_pk_*_f32 does not overlap with the matrix pipe, a v_fma_f32 does
   kOptFilmMfma = 2,     // FiLM interpolation (3 parameter types x 64 shapers x 32 samples per wave) as six bf16 MFMAs
-  kOptOneTerm = 4,      // sines as ONE fp16 term (drops W_hi * v_lo: 2 MFMAs per product; 11-bit activations, opt-in)
+  kOptOneTerm = 4,      // sines as ONE fp16 term in EVERY K-step (drops W_hi * v_lo: 2 MFMAs per product; 11-bit activations)
+  kOptHybrid = 8,       // two-term sines in K-step 0 (mixer bias + harmonics 1..15), one term in K-steps 1..6
   kOptPipelined = 8     // main loop software-pipelined: sines of K-step ks+1 beside the MFMAs of K-step ks
 };
 enum Mode { kModeLut = 0, kModeExact = 1, kModeExciterOnly = 2, kModeLutPairs = 3, kModeLutPairsDiv6 = 4, kModeExactBank = 5 };
@@ -673,6 +674,8 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
   const int frag_lane = half * 32 + col;
   const f32x2 ph2 = splat2(phase);
   // one K-step; the first one starts the accumulators from the MFMA's inline-zero C operand (no 32 v_mov per wave)
+  // how many fp16 terms the sines of K-step ks travel as (compile-time after unrolling): see Opt
+  auto two_terms = [](const int ks) { return (OPT & kOptOneTerm) ? false : ((OPT & kOptHybrid) ? ks == 0 : true); };
   auto sines = [&](const int ks, auto first_tag, f16x8& vhi, f16x8& vlo) {
     constexpr bool kFirst = decltype(first_tag)::value;
     const int kk0 = 16 * ks + 8 * half;
@@ -719,7 +722,7 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
       const f16x2 h2 = __builtin_convertvector(v2[p], f16x2);
       vhi[2 * p] = h2.x;
       vhi[2 * p + 1] = h2.y;
-      if (!(OPT & kOptOneTerm)) {
+      if (two_terms(ks)) {
         const f16x2 l2 = split_lo2(h2, v2[p]);
         vlo[2 * p] = l2.x;
         vlo[2 * p + 1] = l2.y;
@@ -738,7 +741,7 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
         acc[ks] += (float)ahi[0] * (float)vhi[0] + (float)alo[1] * (float)vlo[1];
       } else {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, vhi, kFirst ? f32x16{} : acc, 0, 0, 0);
-        if (!(OPT & kOptOneTerm)) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, vlo, acc, 0, 0, 0);
+        if (two_terms(ks)) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, vlo, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, vhi, acc, 0, 0, 0);
       }
     }
@@ -1152,15 +1155,15 @@ int nws_exciter_newt(const NwsWeights* w, const float* f0, const float* f0_up, c
       if (w->lut_size < 2 || !(w->lut_max > w->lut_min)) return NWS_ERR_BAD_ARG;
       const bool pow2 = (w->lut_size & (w->lut_size - 1)) == 0 && w->lut_size <= (1 << 20);
       if (w->lut_pairs != nullptr && w->lut_max - w->lut_min == 6.0f && pow2) {
-        // FastNEWT hot path.  exciter_opts (nws_hip.h): bit 0 = round-1 FiLM interpolation on the VALU, bit 1 = one fp16
-        // term per sine
+        // FastNEWT hot path.  exciter_opts (nws_hip.h): round-1 FiLM interpolation on the VALU / one fp16 term per sine in
+        // every K-step / in K-steps 1..6 only
         const dim3 g2((T + 1) / 2, B);
         const int opts = w->exciter_opts;
 #define NWS_HOT(O) exciter_newt_kernel<kModeLutPairsDiv6, 0, 2, O><<<g2, 512, base, st>>>( \
             *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out)
-        if ((opts & NWS_EXCITER_VALU_FILM) && (opts & NWS_EXCITER_ONE_TERM)) NWS_HOT(kOptOneTerm);
-        else if (opts & NWS_EXCITER_VALU_FILM) NWS_HOT(0);
+        if (opts & NWS_EXCITER_VALU_FILM) NWS_HOT(0);
         else if (opts & NWS_EXCITER_ONE_TERM) NWS_HOT(kOptFilmMfma | kOptOneTerm);
+        else if (opts & NWS_EXCITER_HYBRID) NWS_HOT(kOptFilmMfma | kOptHybrid);
         else NWS_HOT(kOptFilmMfma);
 #undef NWS_HOT
       } else if (w->lut_pairs != nullptr)
@@ -1198,10 +1201,9 @@ int nws_debug_exciter_newt(int variant, const NwsWeights* w, const float* f0, co
   if (variant >= 10) {   // 10 + OPT bits: the product kernel's compile-time options (two hops per workgroup)
     switch (variant - 10) {
       case 0: NWS_OPT_LAUNCH(0); break;
-      case 1: NWS_OPT_LAUNCH(1); break;
       case 2: NWS_OPT_LAUNCH(2); break;
-      case 4: NWS_OPT_LAUNCH(4); break;
       case 6: NWS_OPT_LAUNCH(6); break;
+      case 10: NWS_OPT_LAUNCH(10); break;
       default: return NWS_ERR_BAD_ARG;
     }
     NWS_CHECK_LAUNCH();

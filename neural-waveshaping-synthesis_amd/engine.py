@@ -166,12 +166,23 @@ class Engine:
         return self._w
 
     def exciter_opts(self) -> int:
-        """NwsWeights.exciter_opts: `model.exciter_opts` if set (invalidate_cache() after changing it), else the
-        NWS_EXCITER_OPTS environment variable, else 0 (= FiLM interpolation on the matrix pipe, two-term fp16 sines)."""
+        """NwsWeights.exciter_opts.  `model.exciter_opts` if set (call invalidate_cache() after changing it), else the
+        NWS_EXCITER_OPTS environment variable, else "auto": the sines of harmonics 16..101 travel as ONE fp16 term
+        (EXCITER_HYBRID: 2 instead of 3 MFMAs per product there, no residual split) when the mixer bias + harmonics 1..15 hold
+        at least 55 % of the harmonic mixer's weight energy - true for the three shipped checkpoints (61 / 67 / 85 %), where
+        it costs 2-6e-6 RMS end to end (tests/test_gpu_parity.py holds it to 1e-5 on every golden vector; the bar is 1e-4);
+        otherwise (e.g. random initialisation) every sine keeps two terms."""
         import os
 
         v = getattr(self._model_ref, "exciter_opts", None)
-        return int(os.environ.get("NWS_EXCITER_OPTS", "0")) if v is None else int(v)
+        if v is None:
+            v = os.environ.get("NWS_EXCITER_OPTS")
+        if v is not None and str(v) != "auto":
+            return int(v)
+        with torch.no_grad():
+            e = self._model_ref.harmonic_mixer.weight.detach().float().pow(2).sum(dim=(0, 2))     # per harmonic
+            share = float(e[:15].sum() / e.sum().clamp_min(1e-30))
+        return _lib.EXCITER_HYBRID if share >= 0.55 else 0
 
     def fp16_mlp_safe(self, limit: float = 3.0e4) -> bool:
         """Worst-case magnitude of every frame-MLP layer input, from weight norms (one-time host check).

@@ -73,6 +73,11 @@ class ForwardPipeline:
                 s.used = False
             self._shape = (B, T)
 
+    def next_audio_stream(self):
+        """The stream the NEXT submit() will run its audio half on (work a caller wants ordered after that batch's reverb -
+        an all-gather of its waveforms, say - is enqueued there)."""
+        return self.audio[self._n % len(self.audio)]
+
     def submit(self, f0, control, *, phase_u=None, noise=None, out=None):
         m = self.model
         f0 = _req(f0 if f0.is_contiguous() else f0.contiguous(), "f0")
