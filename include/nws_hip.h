@@ -224,6 +224,35 @@ int nws_reverb_linear_chunk(const NwsReverbPlan* plan, const void* tables, const
                             const float* tail_in, float* tail_out, int tail_len, float* y, void* workspace,
                             size_t workspace_bytes, void* stream);
 
+/*
+ * Stand-alone forms of the reference's sub-modules ("the seven module classes" are public interface).  Inside
+ * nws_forward the same arithmetic is fused; these entry points serve callers that invoke a sub-module on its own
+ * (model.osc(f0), model.newt(exciter, emb), model.h_generator(emb), model.noise_synth(H), ...).
+ */
+/* HarmonicOscillator.forward (models/modules/generators.py:58-66): f0_up (B, N) Hz at sample rate, N a multiple of 128;
+ * carry from nws_phase_carry(NULL, f0_up, B, N/128, .); phase_u / rand_phase as in nws_exciter_newt; out (B, 101, N) */
+int nws_oscillator(const float* f0_up, const double* carry, const float* phase_u, const float* rand_phase, int B, int N,
+                   float sample_rate, float* out, void* stream);
+/* NEWT.forward / FastNEWT.forward on a materialised exciter (models/modules/shaping.py:67-79): exciter (B, 64, N),
+ * film (B, 256, T) = newt.mlp(control_embedding) channel-major as the reference's Conv1d stack returns it; out (B, N).
+ * w: shaper_* or lut fields, newt_out_w / newt_out_b. */
+int nws_newt_apply(const NwsWeights* w, const float* exciter, const float* film, int B, int T, float* out, void* stream);
+/* TimeDistributedMLP.forward (models/modules/dynamic.py:20-40), any sizes: x (B, in, T) -> y (B, out, T);
+ * depth Conv1d(k=1) layers (HOST arrays of depth device pointers: w[i] (rows_i, cols_i), b[i]), LayerNorm over channels
+ * (ln_g[i], ln_b[i], i < depth-1, biased variance, eps) + LeakyReLU(slope) after every layer but the last.
+ * 1 <= depth <= 8 (depth 1 = a bare Conv1d(k=1), e.g. ControlModule.proj), max(in, hidden) <= ~600 (LDS). */
+int nws_td_mlp(const float* x, int B, int in_size, int hidden, int out_size, int depth, int T, const float* const* w,
+               const float* const* b, const float* const* ln_g, const float* const* ln_b, float ln_eps, float leaky_slope,
+               float* y, void* stream);
+/* TimeDistributedLayerNorm.forward (dynamic.py:11-17): LayerNorm over the channel axis of (B, C, T) */
+int nws_td_layer_norm(const float* x, const float* gain, const float* bias, int B, int C, int T, float eps, float* y,
+                      void* stream);
+/* FiLM.forward (dynamic.py:6-8): y = gamma * x + beta on n equally laid out elements */
+int nws_film(const float* x, const float* gamma, const float* beta, int64_t n, float* y, void* stream);
+/* zero-phase FIR design of FIRNoiseSynth.forward (generators.py:22-28): H (B, 129, T) -> fir (B, T, 256) taps
+ * (window * roll(irfft(H), 128)); feed nws_fir_noise with them */
+int nws_fir_from_h(const float* H, const float* fir_design /* (256,132) */, int B, int T, float* fir_out, void* stream);
+
 /* ---- FastNEWT table (models/modules/shaping.py:107-119): table[s][i] = shaper_s(linspace(min,max,size)[i]) ---- */
 int nws_shaper_table(const NwsWeights* w, int table_size, float table_min, float table_max, float* table_out, void* stream);
 

@@ -107,6 +107,13 @@ _PROTOTYPES = {
     "nws_debug_exciter_newt": (C.c_int, [C.c_int, C.POINTER(NwsWeights), _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_float,
                                          _fp, _fp]),
     "nws_debug_sin": (C.c_int, [C.c_int, _fp, _fp, C.c_int64, C.c_int, _fp]),
+    "nws_oscillator": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_float, _fp, _fp]),
+    "nws_newt_apply": (C.c_int, [C.POINTER(NwsWeights), _fp, _fp, C.c_int, C.c_int, _fp, _fp]),
+    "nws_td_mlp": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_fp), C.POINTER(_fp),
+                             C.POINTER(_fp), C.POINTER(_fp), C.c_float, C.c_float, _fp, _fp]),
+    "nws_td_layer_norm": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp]),
+    "nws_film": (C.c_int, [_fp, _fp, _fp, C.c_int64, _fp, _fp]),
+    "nws_fir_from_h": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp, _fp]),
     "nws_profile_begin": (C.c_int, [C.c_int, C.c_uint]),
     "nws_profile_collect": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "nws_profile_end": (C.c_int, []),

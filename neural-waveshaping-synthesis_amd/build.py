@@ -12,8 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libnws_hip.so")
+OPS_LIB = os.path.join(HERE, "libnws_torch_ops.so")     # torch.ops.newt_hip.* over the C-ABI (csrc/torch_ops.cpp)
 SOURCES = ["exciter_newt.hip", "control_gru.hip", "frame_mlps.hip", "fir_noise.hip", "reverb_fft.hip", "forward.hip",
-           "loudness.hip", "coexec_probe.hip"]
+           "loudness.hip", "stages.hip", "coexec_probe.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=default",
          "-Wall", "-Wno-unused-function", "-Wno-pass-failed", "-Rpass-analysis=kernel-resource-usage"]
 # -fno-slp-vectorize: the SLP vectoriser turns scalar fp32 code into packed instructions with operand swizzles of its own
@@ -40,7 +41,7 @@ def _stamp():
     h = hashlib.sha256((" ".join(FLAGS) + repr(sorted(EXTRA_FLAGS.items()))).encode())
     for f in sorted(os.listdir(CSRC)):
         p = os.path.join(CSRC, f)
-        if os.path.isfile(p):
+        if os.path.isfile(p) and f != "torch_ops.cpp":
             h.update(f.encode())
             h.update(open(p, "rb").read())
     h.update(open(os.path.join(HERE, "..", "include", "nws_hip.h"), "rb").read())
@@ -85,7 +86,46 @@ def check_packed_swizzles(obj):
     return found
 
 
+def build_torch_ops(force=False, verbose=True):
+    """torch.ops.newt_hip.*: one host-only translation unit (no kernels) compiled with g++ against the torch headers and linked
+    to libnws_hip.so next to it.  Needs an importable torch; returns None (with a note) when there is none - the ctypes
+    binding of the C-ABI keeps working without it."""
+    try:
+        import torch
+        from torch.utils import cpp_extension as ce
+    except Exception as e:   # pragma: no cover
+        print(f"torch not importable ({e}): skipping libnws_torch_ops.so", file=sys.stderr)
+        return None
+    src = os.path.join(CSRC, "torch_ops.cpp")
+    h = hashlib.sha256(open(src, "rb").read())
+    h.update(open(os.path.join(HERE, "..", "include", "nws_hip.h"), "rb").read())
+    h.update(torch.__version__.encode())
+    stamp, stamp_file = h.hexdigest(), OPS_LIB + ".stamp"
+    if not force and os.path.exists(OPS_LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return OPS_LIB
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-Wall", "-Wno-unused-function",
+           *[f"-I{p}" for p in ce.include_paths()], "-I/opt/rocm/include", src, "-o", OPS_LIB,
+           f"-L{HERE}", "-lnws_hip", f"-L{tlib}", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip",
+           "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"g++ failed on torch_ops.cpp:\n{r.stderr[-6000:]}")
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
+    if verbose:
+        print(f"built {OPS_LIB}")
+    return OPS_LIB
+
+
 def build(force=False, verbose=True):
+    lib = build_hip(force, verbose)
+    build_torch_ops(force, verbose)
+    return lib
+
+
+def build_hip(force=False, verbose=True):
     stamp_file = LIB + ".stamp"
     stamp = _stamp()
     if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:

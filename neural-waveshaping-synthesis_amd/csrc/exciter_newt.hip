@@ -914,6 +914,68 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
   if (half == 0) newt_out[(size_t)b * N + n] = total;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stand-alone HarmonicOscillator.forward (models/modules/generators.py:58-66): (B, N) upsampled F0 -> (B, 101, N) sines
+// times the anti-alias mask.  Same phase arithmetic as the fused kernel (fp64 prefix sum from the 32-sample carries, the
+// reference's fp32 rounding chain, arguments fl(fl(k phase) + shift)); one thread per sample, 101 coalesced stores.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void oscillator_kernel(const float* __restrict__ f0_up, const double* __restrict__ carry,
+                                                         const float* __restrict__ phase_u, const float* __restrict__ rand_phase,
+                                                         int N, float sample_rate, float* __restrict__ out) {
+  __shared__ float shift[kK];
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * 128 + threadIdx.x;          // N is a multiple of 128: no partial blocks
+  if (threadIdx.x < kK) shift[threadIdx.x] = phase_u[threadIdx.x] * rand_phase[threadIdx.x] - kPi;   // generators.py:54-56
+  const float f0n = f0_up[(size_t)b * N + n];
+  double cs = scan32_f64((double)f0n);
+  cs += carry[(size_t)b * (N / 32) + (n >> 5)];
+  const float tc = kTau * (float)cs;
+  const float phase = __fdiv_rn(tc, sample_rate);
+  const float nyquist = sample_rate * 0.5f;
+  __syncthreads();
+  float* o = out + (size_t)b * kK * N + n;
+  for (int k = 1; k <= kK; ++k) {
+    const float kf = (float)k;
+    const float arg = kf * phase + shift[k - 1];           // two roundings (-ffp-contract=off)
+    const float v = nws_sinf(arg);
+    o[(size_t)(k - 1) * N] = (f0n * kf) < nyquist ? v : 0.0f;   // NaN F0: mask false, like the reference's comparison
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stand-alone NEWT.forward / FastNEWT.forward on a materialised exciter (models/modules/shaping.py:67-79):
+// film (B, 256, T) channel-major [g_idx | b_idx | g_norm | b_norm] as newt.mlp returns it, upsampled x128 on the fly;
+// x = g_idx e + b_idx -> shaper -> g_norm s + b_norm -> Conv1d(64 -> 1).  One thread per sample; the reference's own
+// rounding chains (FiLM as multiply then add, LUT index chain of FastNEWT._lookup), since nothing is fused here.
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(128) void newt_apply_kernel(NwsWeights w, const float* __restrict__ exciter,
+                                                         const float* __restrict__ film, int T, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  ShaperLds& SH = *reinterpret_cast<ShaperLds*>(smem_raw);
+  if (MODE == kModeExact) load_shaper_lds<false>(SH, w, threadIdx.x, 128);
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int N = T * NWS_HOP;
+  const int n = blockIdx.x * 128 + threadIdx.x;          // one hop per workgroup
+  const NwsLerp lc = nws_lerp_coeff(n, T);
+  LutParams LP;
+  if (MODE == kModeLut) LP = make_lut_params(w);
+  const float* fb = film + (size_t)b * NWS_FILM_CH * T;
+  const float* eb = exciter + (size_t)b * kS * N + n;
+  float acc = w.newt_out_b[0];
+  for (int s = 0; s < kS; ++s) {
+    const float g_i = nws_lerp(fb[(size_t)s * T + lc.i0], fb[(size_t)s * T + lc.i1], lc.w0, lc.w1);
+    const float b_i = nws_lerp(fb[(size_t)(kS + s) * T + lc.i0], fb[(size_t)(kS + s) * T + lc.i1], lc.w0, lc.w1);
+    const float g_n = nws_lerp(fb[(size_t)(2 * kS + s) * T + lc.i0], fb[(size_t)(2 * kS + s) * T + lc.i1], lc.w0, lc.w1);
+    const float b_n = nws_lerp(fb[(size_t)(3 * kS + s) * T + lc.i0], fb[(size_t)(3 * kS + s) * T + lc.i1], lc.w0, lc.w1);
+    const float x = g_i * eb[(size_t)s * N] + b_i;                                     // FiLM: gamma * x + beta (dynamic.py:8)
+    const float sh = MODE == kModeLut ? lut_shaper<false, false>(LP, s * LP.size, x) : exact_shaper_precise(SH, s, x);
+    acc = fmaf(w.newt_out_w[s], g_n * sh + b_n, acc);
+  }
+  out[(size_t)b * N + n] = acc;
+}
+
 // element-wise shaper application on (B,64,N) (stage tests / FastNEWT table construction)
 template <int MODE>
 __global__ __launch_bounds__(256) void shaper_apply_kernel(NwsWeights w, const float* __restrict__ x, int64_t N,
@@ -1222,6 +1284,32 @@ int nws_debug_exciter_newt(int variant, const NwsWeights* w, const float* f0, co
     default: return NWS_ERR_BAD_ARG;
   }
 #undef NWS_DBG_LAUNCH
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+int nws_oscillator(const float* f0_up, const double* carry, const float* phase_u, const float* rand_phase, int B, int N,
+                   float sample_rate, float* out, void* stream) {
+  if (!f0_up || !carry || !phase_u || !rand_phase || !out || B <= 0 || N <= 0) return NWS_ERR_BAD_ARG;
+  if (N % NWS_HOP != 0 || B > 65535) return NWS_ERR_UNSUPPORTED;
+  oscillator_kernel<<<dim3(N / NWS_HOP, B), 128, 0, (hipStream_t)stream>>>(
+      f0_up, carry, phase_u, rand_phase, N, sample_rate, out);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+int nws_newt_apply(const NwsWeights* w, const float* exciter, const float* film, int B, int T, float* out, void* stream) {
+  if (!w || !exciter || !film || !out || B <= 0 || T <= 0 || !w->newt_out_w || !w->newt_out_b) return NWS_ERR_BAD_ARG;
+  if (B > 65535) return NWS_ERR_UNSUPPORTED;
+  const dim3 grid(T, B);
+  const int threads = 128;
+  if (w->lut != nullptr) {
+    if (w->lut_size < 2 || !(w->lut_max > w->lut_min)) return NWS_ERR_BAD_ARG;
+    newt_apply_kernel<kModeLut><<<grid, threads, 16, (hipStream_t)stream>>>(*w, exciter, film, T, out);
+  } else {
+    if (!w->shaper_in_scale || !w->shaper_w0 || !w->shaper_w2 || !w->shaper_w4 || !w->shaper_w6) return NWS_ERR_BAD_ARG;
+    newt_apply_kernel<kModeExact><<<grid, threads, sizeof(ShaperLds), (hipStream_t)stream>>>(*w, exciter, film, T, out);
+  }
   NWS_CHECK_LAUNCH();
   return NWS_OK;
 }

@@ -665,15 +665,14 @@ int nws_frame_mlps(const NwsWeights* w, const float* gru_out, const float* fir_d
   for (int i = 0; i < 3; ++i)
     if (!w->newt_ln_g[i] || !w->newt_ln_b[i] || !w->hgen_ln_g[i] || !w->hgen_ln_b[i]) return NWS_ERR_BAD_ARG;
   if (B > 65535) return NWS_ERR_UNSUPPORTED;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_devices = 0;
+  if (nws_first_use_on_device(attr_devices)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_mlps_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpLds));
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_mlps16_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpLds16));
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   const dim3 grid((T + kFT - 1) / kFT, B);
   if (w->mlp_frags != nullptr)

@@ -111,8 +111,16 @@ __global__ void loudness_db_kernel(const float* __restrict__ power, const unsign
 }
 
 __host__ int rows_padded(int n_fft) { return ((2 * (n_fft / 2 + 1)) + 31) / 32 * 32; }
+// LDS tile of one workgroup: the (kFrames - 1) hop + n_fft samples its 32 overlapping frames are cut from (+ skew words)
+constexpr size_t kLoudnessLdsCap = 160 * 1024;
+__host__ size_t tile_lds_bytes(int n_fft, int hop) {
+  const size_t span = (size_t)(32 - 1) * hop + n_fft;
+  return (span + (span >> 7) + 1) * sizeof(float);
+}
 __host__ bool fft_ok(int n_fft, int hop) {
-  return n_fft >= 64 && n_fft <= 2048 && (n_fft & (n_fft - 1)) == 0 && hop >= 1 && hop <= n_fft;
+  // the tile must fit the CU's 160 KB of LDS: e.g. n_fft 2048 allows hop <= 1250, n_fft 1024 hop <= 1024
+  return n_fft >= 64 && n_fft <= 2048 && (n_fft & (n_fft - 1)) == 0 && hop >= 1 && hop <= n_fft &&
+         tile_lds_bytes(n_fft, hop) <= kLoudnessLdsCap;
 }
 
 }  // namespace
@@ -157,14 +165,12 @@ int nws_loudness(const float* audio, int B, int N, int n_fft, int hop, const flo
   hipError_t e = hipMemsetAsync(max_bits, 0, (size_t)B * sizeof(unsigned), st);
   if (e != hipSuccess) return (int)e;
   const int m_tiles = rows_padded(n_fft) / 32;
-  const int span = (kFrames - 1) * hop + n_fft;
-  const size_t lds = (size_t)(span + (span >> 7) + 1) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  const size_t lds = tile_lds_bytes(n_fft, hop);
+  static unsigned long long attr_devices = 0;
+  if (nws_first_use_on_device(attr_devices)) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(loudness_power_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            96 * 1024);
+                            (int)kLoudnessLdsCap);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   const dim3 grid(frames_pad / kFrames, (m_tiles + 3) / 4, B);
   loudness_power_kernel<<<grid, 256, lds, st>>>(audio, N, n_fft, hop, frames, frames_pad, dft, m_tiles, power, max_bits);

@@ -23,6 +23,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     if (e__ != hipSuccess) return (int)e__;     \
   } while (0)
 
+// One-time-per-DEVICE guard for hipFuncSetAttribute (the attribute belongs to the kernel's image on ONE device: a flag per
+// process would leave a second GPU of the same process without it).  `mask` is a static per call site; returns true the
+// first time the calling thread's current device is seen.  (A benign race repeats the call, nothing worse.)
+inline bool nws_first_use_on_device(unsigned long long& mask) {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) return true;
+  if ((mask >> d) & 1ull) return false;
+  mask |= 1ull << d;
+  return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // F.upsample(x, T*128, mode="linear") of the reference (align_corners=False), bit-exact with
 // ATen's CPU kernel as probed in the build container:  out = fmaf(1-l, x[i0], fl(l*x[i1])).

@@ -504,15 +504,14 @@ size_t nws_reverb_workspace_bytes(const NwsReverbPlan* plan, int B) {
 }
 
 static int ensure_col125_attrs() {
-  static bool done = false;
-  if (!done) {
+  static unsigned long long attr_devices = 0;
+  if (nws_first_use_on_device(attr_devices)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(col125_fwd_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCol125Lds);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(col125_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kCol125Lds);
     if (e != hipSuccess) return (int)e;
-    done = true;
   }
   return NWS_OK;
 }

@@ -2,18 +2,27 @@
 owns the weight-independent tables (FIR design matrix, reverb DFT tables) and the cached IR spectrum,
 and enqueues the HIP kernels on torch's current stream.
 
+Two bindings of the same C-ABI (include/nws_hip.h):
+  * `torch.ops.newt_hip.*` (csrc/torch_ops.cpp -> libnws_torch_ops.so): dispatcher-visible custom ops with TORCH_CHECK
+    argument validation, device guard and current-stream lookup in C++ - the default;
+  * ctypes on libnws_hip.so directly (`NWS_BACKEND=ctypes`): the torch-free binding a foreign host would write
+    (INTEGRATION.md), kept as a second test path.
+Both end in the same `extern "C"` launchers; there is no CPU or PyTorch fallback behind either.
+
 PyTorch is used here only as plumbing: device memory (tensors), the current HIP stream and the
 device RNG that the reference itself draws from inside forward().
 """
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 import math
+import os
 
 import torch
 
 from . import _lib
-from ._lib import NwsForwardAux, NwsReverbPlan, NwsWeights, check, ptr, stream_ptr
+from ._lib import NwsForwardAux, NwsReverbPlan, NwsWeights, check, ptr
 
 
 def _req(t: torch.Tensor, name: str, numel: int | None = None) -> torch.Tensor:
@@ -33,7 +42,63 @@ def _req(t: torch.Tensor, name: str, numel: int | None = None) -> torch.Tensor:
     return t
 
 
-_TABLE_CACHE: dict = {}  # (device index, L) -> (plan, tables tensor)
+def same_device(ref: torch.device, **tensors):
+    """Every tensor of one call must live on the GPU the weights live on (the reference raises a RuntimeError for mixed
+    devices as well; raw pointers would be mixed silently otherwise)."""
+    for name, t in tensors.items():
+        if t is not None and t.device != ref:
+            raise RuntimeError(f"{name} is on {t.device} but the model's parameters are on {ref}: move them to the same GPU")
+
+
+# ---- which binding ------------------------------------------------------------------------------------------------------
+_OPS = None
+_OPS_TRIED = False
+
+
+def ops():
+    """torch.ops.newt_hip, or None when the ctypes binding is selected (NWS_BACKEND=ctypes)."""
+    global _OPS, _OPS_TRIED
+    if not _OPS_TRIED:
+        want = os.environ.get("NWS_BACKEND", "ops")
+        if want not in ("ops", "ctypes"):
+            raise _lib.NwsError(f"NWS_BACKEND={want!r}: expected 'ops' or 'ctypes'")
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnws_torch_ops.so")
+        if want == "ops":
+            if not os.path.exists(path):
+                raise _lib.NwsError(f"{path} not found: build it (python __graft_entry__.py build) or select the ctypes "
+                                    "binding with NWS_BACKEND=ctypes")
+            _lib.lib()                                    # ABI / struct-layout checks of libnws_hip.so first
+            torch.ops.load_library(path)
+            if int(torch.ops.newt_hip.abi_version()) != _lib.ABI_VERSION:
+                raise _lib.NwsError("libnws_torch_ops.so was built against another ABI version: rebuild")
+            _OPS = torch.ops.newt_hip
+        _OPS_TRIED = True
+    return _OPS
+
+
+def stream_ptr(dev: torch.device):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+# ---- registry epoch: bumped whenever ANY module registers a parameter / buffer / sub-module ------------------------------
+_EPOCH = [0]
+
+
+def _bump(*_a, **_k):
+    _EPOCH[0] += 1
+
+
+try:   # torch >= 2.0
+    from torch.nn.modules.module import (register_module_buffer_registration_hook, register_module_module_registration_hook,
+                                         register_module_parameter_registration_hook)
+    register_module_parameter_registration_hook(_bump)
+    register_module_buffer_registration_hook(_bump)
+    register_module_module_registration_hook(_bump)
+except Exception:   # pragma: no cover
+    pass
+
+
+_TABLE_CACHE: dict = {}  # (device index, L) -> (plan, tables tensor, plan tensor)
 
 
 def reverb_plan_and_tables(device: torch.device, n_samples: int, ir_len_plus1: int):
@@ -43,12 +108,13 @@ def reverb_plan_and_tables(device: torch.device, n_samples: int, ir_len_plus1: i
     hit = _TABLE_CACHE.get(key)
     if hit is None:
         nbytes = _lib.lib().nws_reverb_table_bytes(C.byref(plan))
-        tables = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
-        check(_lib.lib().nws_reverb_build_tables(C.byref(plan), ptr(tables), stream_ptr()), "nws_reverb_build_tables")
-        # one-time: make the tables visible to every stream before anybody can use them (callers may issue forwards
-        # round-robin on several streams; the builder stream is whichever one got here first)
-        torch.cuda.current_stream().synchronize()
-        hit = (plan, tables)
+        with torch.cuda.device(device):
+            tables = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+            check(_lib.lib().nws_reverb_build_tables(C.byref(plan), ptr(tables), stream_ptr(device)), "nws_reverb_build_tables")
+            # one-time: make the tables visible to every stream before anybody can use them (callers may issue forwards
+            # round-robin on several streams; the builder stream is whichever one got here first)
+            torch.cuda.current_stream(device).synchronize()
+        hit = (plan, tables, torch.tensor([plan.L, plan.N1, plan.N2, 0], dtype=torch.int32))
         _TABLE_CACHE[key] = hit
     return hit
 
@@ -58,22 +124,54 @@ class Engine:
 
     def __init__(self, model):
         self._model_ref = model
-        self._w = None          # (NwsWeights, keep-alive list, device)
+        self._w = None          # (NwsWeights, keep-alive list, device, wdesc tensor)
+        self._fp = None         # what the cache was built from: ((data_ptr, version) per tensor, registry epoch, options)
+        self._tensors = None    # the parameter / buffer objects the fingerprint walks
         self._fir_design = None
         self._spectra = {}      # L -> spectrum tensor
-        self._workspaces = {}   # (B, T) -> tensor
+        self._workspaces = {}   # (B, T, stream) -> tensor
+
+    # a copied / unpickled module gets a fresh engine (the caches hold raw device pointers of the ORIGINAL's tensors)
+    def __deepcopy__(self, memo):
+        return Engine(memo.get(id(self._model_ref), self._model_ref))
+
+    def __reduce__(self):
+        return (Engine, (self._model_ref,))
 
     # ---- cache control -----------------------------------------------------------------------
     def invalidate(self):
         self._w = None
+        self._fp = None
+        self._tensors = None
         self._fir_design = None
         self._spectra.clear()
         self._workspaces.clear()
 
+    def _fingerprint(self):
+        """Cheap identity of everything the cached pointer struct and derived tables were computed from: the storage address
+        and in-place version counter of every parameter and buffer (in-place updates - optimizer steps, `p.mul_()`,
+        `p.copy_()`, `load_state_dict` on a sub-module - bump the version; re-homing changes the address), the module
+        registry epoch (a replaced Parameter / sub-module object) and the kernel options.  ~12 us, once per forward.
+        What it cannot see: writes through `p.data` (that view has its own version counter) - call
+        `model.invalidate_cache()` after those."""
+        m = self._model_ref
+        if self._tensors is None or self._tensors[0] != _EPOCH[0]:
+            self._tensors = (_EPOCH[0], list(itertools.chain(m.parameters(), m.buffers())))
+        return (tuple((t.data_ptr(), t._version) for t in self._tensors[1]), id(m.newt), getattr(m, "exciter_opts", None),
+                os.environ.get("NWS_EXCITER_OPTS"))
+
     # ---- weights -----------------------------------------------------------------------------
     def weights(self):
-        if self._w is not None:
+        """(NwsWeights struct, keep-alive list, device) - rebuilt when the parameters' fingerprint changed"""
+        return self._wd()[:3]
+
+    def _wd(self):
+        fp = self._fingerprint()
+        if self._w is not None and fp == self._fp:
             return self._w
+        if self._w is not None:
+            self.invalidate()
+            fp = self._fingerprint()
         m = self._model_ref
         keep = []
 
@@ -92,88 +190,92 @@ class Engine:
         w.proj_b = P(m.embedding.proj.bias, "embedding.proj.bias", 128)
         w.mixer_w = P(m.harmonic_mixer.weight, "harmonic_mixer.weight", 64 * 101)
         w.mixer_b = P(m.harmonic_mixer.bias, "harmonic_mixer.bias", 64)
-        frags = torch.empty(28672, dtype=torch.uint8, device=keep[-1].device)
-        check(_lib.lib().nws_mixer_frags(w.mixer_w, w.mixer_b, ptr(frags), stream_ptr()), "nws_mixer_frags")
-        keep.append(frags)
-        w.mixer_frags = frags.data_ptr()
-        for name, mlp, out_rows, wf, bf, gf, lf in (
-                ("newt.mlp", m.newt.mlp, 256, w.newt_mlp_w, w.newt_mlp_b, w.newt_ln_g, w.newt_ln_b),
-                ("h_generator", m.h_generator, 129, w.hgen_w, w.hgen_b, w.hgen_ln_g, w.hgen_ln_b)):
-            if len(mlp.net) != 10:
-                raise RuntimeError(f"{name}: kernels are specialised for depth=4 TimeDistributedMLP")
-            for i in range(4):
-                rows = 128 if i < 3 else out_rows
-                wf[i] = P(mlp.net[3 * i].weight, f"{name}.net.{3 * i}.weight", rows * 128)
-                bf[i] = P(mlp.net[3 * i].bias, f"{name}.net.{3 * i}.bias", rows)
-                if i < 3:
-                    gf[i] = P(mlp.net[3 * i + 1].layer_norm.weight, f"{name}.net.{3 * i + 1}.layer_norm.weight", 128)
-                    lf[i] = P(mlp.net[3 * i + 1].layer_norm.bias, f"{name}.net.{3 * i + 1}.layer_norm.bias", 128)
-        sh = m.newt._modules.get("shaping_fn")
-        if sh is not None:
-            if len(sh.net) != 8:
-                raise RuntimeError("newt.shaping_fn: kernels are specialised for depth=4, width=8")
-            w.shaper_in_scale = P(sh.input_scale, "newt.shaping_fn.input_scale", 64)
-            w.shaper_w0 = P(sh.net[0].weight, "newt.shaping_fn.net.0.weight", 512)
-            w.shaper_b0 = P(sh.net[0].bias, "newt.shaping_fn.net.0.bias", 512)
-            w.shaper_w2 = P(sh.net[2].weight, "newt.shaping_fn.net.2.weight", 4096)
-            w.shaper_b2 = P(sh.net[2].bias, "newt.shaping_fn.net.2.bias", 512)
-            w.shaper_w4 = P(sh.net[4].weight, "newt.shaping_fn.net.4.weight", 4096)
-            w.shaper_b4 = P(sh.net[4].bias, "newt.shaping_fn.net.4.bias", 512)
-            w.shaper_w6 = P(sh.net[6].weight, "newt.shaping_fn.net.6.weight", 512)
-            w.shaper_b6 = P(sh.net[6].bias, "newt.shaping_fn.net.6.bias", 64)
-            turns = torch.empty((64, _lib.SHAPER_TURNS_ROW), dtype=torch.float32, device=keep[-1].device)
-            check(_lib.lib().nws_shaper_turns(C.byref(w), ptr(turns), stream_ptr()), "nws_shaper_turns")
-            keep.append(turns)
-            w.shaper_turns = turns.data_ptr()
-        table = getattr(m.newt, "lookup_table", None)
-        if table is not None:
-            size = int(m.newt.table_size)
-            w.lut = P(table, "newt.lookup_table", 64 * size)
-            pairs = torch.empty((64, size, 2), dtype=torch.float32, device=table.device)
-            check(_lib.lib().nws_lut_pairs(w.lut, size, ptr(pairs), stream_ptr()), "nws_lut_pairs")
-            keep.append(pairs)
-            w.lut_pairs = pairs.data_ptr()
-            w.lut_size = size
-            w.lut_min = float(m.newt.table_min)
-            w.lut_max = float(m.newt.table_max)
-        else:
-            w.lut = None
-            w.lut_pairs = None
-            w.lut_size, w.lut_min, w.lut_max = 0, 0.0, 0.0
-        w.exciter_opts = self.exciter_opts()
-        w.newt_out_w = P(m.newt.mixer[0].weight, "newt.mixer.0.weight", 64)
-        w.newt_out_b = P(m.newt.mixer[0].bias, "newt.mixer.0.bias", 1)
-        w.noise_window = P(m.noise_synth.window, "noise_synth.window", 256)
-        # FIR design matrix (weights-independent apart from the window buffer) and, when every layer input provably
-        # stays inside fp16 range, the pre-split fp16 fragment table that moves the frame MLPs to the fp16 matrix pipe
-        fd = torch.empty(_lib.FIR_LEN * _lib.FIR_DESIGN_COLS, dtype=torch.float32, device=keep[0].device)
-        check(_lib.lib().nws_fir_design_matrix(w.noise_window, ptr(fd), stream_ptr()), "nws_fir_design_matrix")
-        self._fir_design = fd
-        keep.append(fd)
-        w.mlp_frags = None
-        if self.fp16_mlp_safe():
-            frags = torch.empty(819200, dtype=torch.uint8, device=fd.device)
-            check(_lib.lib().nws_mlp_frags(C.byref(w), ptr(fd), ptr(frags), stream_ptr()), "nws_mlp_frags")
+        dev = keep[-1].device
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            st = stream_ptr(dev)
+            frags = torch.empty(28672, dtype=torch.uint8, device=dev)
+            check(L.nws_mixer_frags(w.mixer_w, w.mixer_b, ptr(frags), st), "nws_mixer_frags")
             keep.append(frags)
-            w.mlp_frags = frags.data_ptr()
-        keep.append(_req(m.osc.rand_phase.detach(), "osc.rand_phase", 101))
-        keep.append(_req(m.reverb.ir.detach(), "reverb.ir"))
-        devs = {t.device for t in keep}
-        if len(devs) != 1:
-            raise RuntimeError(f"model parameters are spread over several devices: {devs}")
-        torch.cuda.current_stream().synchronize()   # derived tables complete before any other stream can use them
-        self._w = (w, keep, next(iter(devs)))
+            w.mixer_frags = frags.data_ptr()
+            for name, mlp, out_rows, wf, bf, gf, lf in (
+                    ("newt.mlp", m.newt.mlp, 256, w.newt_mlp_w, w.newt_mlp_b, w.newt_ln_g, w.newt_ln_b),
+                    ("h_generator", m.h_generator, 129, w.hgen_w, w.hgen_b, w.hgen_ln_g, w.hgen_ln_b)):
+                if len(mlp.net) != 10:
+                    raise RuntimeError(f"{name}: kernels are specialised for depth=4 TimeDistributedMLP")
+                for i in range(4):
+                    rows = 128 if i < 3 else out_rows
+                    wf[i] = P(mlp.net[3 * i].weight, f"{name}.net.{3 * i}.weight", rows * 128)
+                    bf[i] = P(mlp.net[3 * i].bias, f"{name}.net.{3 * i}.bias", rows)
+                    if i < 3:
+                        gf[i] = P(mlp.net[3 * i + 1].layer_norm.weight, f"{name}.net.{3 * i + 1}.layer_norm.weight", 128)
+                        lf[i] = P(mlp.net[3 * i + 1].layer_norm.bias, f"{name}.net.{3 * i + 1}.layer_norm.bias", 128)
+            sh = m.newt._modules.get("shaping_fn")
+            if sh is not None:
+                if len(sh.net) != 8:
+                    raise RuntimeError("newt.shaping_fn: kernels are specialised for depth=4, width=8")
+                w.shaper_in_scale = P(sh.input_scale, "newt.shaping_fn.input_scale", 64)
+                w.shaper_w0 = P(sh.net[0].weight, "newt.shaping_fn.net.0.weight", 512)
+                w.shaper_b0 = P(sh.net[0].bias, "newt.shaping_fn.net.0.bias", 512)
+                w.shaper_w2 = P(sh.net[2].weight, "newt.shaping_fn.net.2.weight", 4096)
+                w.shaper_b2 = P(sh.net[2].bias, "newt.shaping_fn.net.2.bias", 512)
+                w.shaper_w4 = P(sh.net[4].weight, "newt.shaping_fn.net.4.weight", 4096)
+                w.shaper_b4 = P(sh.net[4].bias, "newt.shaping_fn.net.4.bias", 512)
+                w.shaper_w6 = P(sh.net[6].weight, "newt.shaping_fn.net.6.weight", 512)
+                w.shaper_b6 = P(sh.net[6].bias, "newt.shaping_fn.net.6.bias", 64)
+                turns = torch.empty((64, _lib.SHAPER_TURNS_ROW), dtype=torch.float32, device=dev)
+                check(L.nws_shaper_turns(C.byref(w), ptr(turns), st), "nws_shaper_turns")
+                keep.append(turns)
+                w.shaper_turns = turns.data_ptr()
+            table = getattr(m.newt, "lookup_table", None)
+            if table is not None:
+                size = int(m.newt.table_size)
+                w.lut = P(table, "newt.lookup_table", 64 * size)
+                pairs = torch.empty((64, size, 2), dtype=torch.float32, device=table.device)
+                check(L.nws_lut_pairs(w.lut, size, ptr(pairs), st), "nws_lut_pairs")
+                keep.append(pairs)
+                w.lut_pairs = pairs.data_ptr()
+                w.lut_size = size
+                w.lut_min = float(m.newt.table_min)
+                w.lut_max = float(m.newt.table_max)
+            else:
+                w.lut = None
+                w.lut_pairs = None
+                w.lut_size, w.lut_min, w.lut_max = 0, 0.0, 0.0
+            w.exciter_opts = self.exciter_opts()
+            w.newt_out_w = P(m.newt.mixer[0].weight, "newt.mixer.0.weight", 64)
+            w.newt_out_b = P(m.newt.mixer[0].bias, "newt.mixer.0.bias", 1)
+            w.noise_window = P(m.noise_synth.window, "noise_synth.window", 256)
+            # FIR design matrix (weights-independent apart from the window buffer) and, when every layer input provably
+            # stays inside fp16 range, the pre-split fp16 fragment table that moves the frame MLPs to the fp16 matrix pipe
+            fd = torch.empty(_lib.FIR_LEN * _lib.FIR_DESIGN_COLS, dtype=torch.float32, device=dev)
+            check(L.nws_fir_design_matrix(w.noise_window, ptr(fd), st), "nws_fir_design_matrix")
+            self._fir_design = fd
+            keep.append(fd)
+            w.mlp_frags = None
+            if self.fp16_mlp_safe():
+                frags = torch.empty(819200, dtype=torch.uint8, device=dev)
+                check(L.nws_mlp_frags(C.byref(w), ptr(fd), ptr(frags), st), "nws_mlp_frags")
+                keep.append(frags)
+                w.mlp_frags = frags.data_ptr()
+            keep.append(_req(m.osc.rand_phase.detach(), "osc.rand_phase", 101))
+            keep.append(_req(m.reverb.ir.detach(), "reverb.ir"))
+            devs = {t.device for t in keep}
+            if len(devs) != 1:
+                raise RuntimeError(f"model parameters are spread over several devices: {devs}")
+            torch.cuda.current_stream(dev).synchronize()   # derived tables complete before any other stream can use them
+        wdesc = torch.frombuffer(bytearray(bytes(w)), dtype=torch.uint8)      # the struct as the op layer takes it
+        self._w = (w, keep, dev, wdesc)
+        self._fp = fp
         return self._w
 
     def exciter_opts(self) -> int:
-        """NwsWeights.exciter_opts.  `model.exciter_opts` if set (call invalidate_cache() after changing it), else the
-        NWS_EXCITER_OPTS environment variable, else "auto": the sines of harmonics 16..101 travel as ONE fp16 term
-        (EXCITER_HYBRID: 2 instead of 3 MFMAs per product there, no residual split) when the mixer bias + harmonics 1..15 hold
-        at least 55 % of the harmonic mixer's weight energy - true for the three shipped checkpoints (61 / 67 / 85 %), where
-        it costs 2-6e-6 RMS end to end (tests/test_gpu_parity.py holds it to 1e-5 on every golden vector; the bar is 1e-4);
-        otherwise (e.g. random initialisation) every sine keeps two terms."""
-        import os
-
+        """NwsWeights.exciter_opts.  `model.exciter_opts` if set, else the NWS_EXCITER_OPTS environment variable, else
+        "auto": the sines of harmonics 16..101 travel as ONE fp16 term (EXCITER_HYBRID: 2 instead of 3 MFMAs per product
+        there, no residual split) when the mixer bias + harmonics 1..15 hold at least 55 % of the harmonic mixer's weight
+        energy - true for the three shipped checkpoints (61 / 67 / 85 %), where it costs 2e-7 .. 2e-6 RMS end to end
+        (tests/test_gpu_parity.py holds it to 1e-5 on every golden vector; the bar is 1e-4); otherwise (e.g. random
+        initialisation) every sine keeps two terms."""
         v = getattr(self._model_ref, "exciter_opts", None)
         if v is None:
             v = os.environ.get("NWS_EXCITER_OPTS")
@@ -220,147 +322,252 @@ class Engine:
         return self._fir_design
 
     def reverb_aux(self, n_samples: int):
-        ir = self.ir()
-        plan, tables = reverb_plan_and_tables(self.device, n_samples, ir.numel() + 1)
+        """(plan, tables, spectrum, plan tensor) for a forward of n_samples; the IR spectrum is rebuilt with the weights"""
+        self._wd()
+        return self._reverb_aux(n_samples)
+
+    def _reverb_aux(self, n_samples: int):     # after _wd(): no second fingerprint walk
+        ir = self._w[1][-1]
+        dev = self._w[2]
+        plan, tables, plan_t = reverb_plan_and_tables(dev, n_samples, ir.numel() + 1)
         spec = self._spectra.get(plan.L)
         if spec is None:
-            spec = torch.empty(_lib.lib().nws_reverb_spectrum_bytes(C.byref(plan)) // 4, dtype=torch.float32,
-                               device=self.device)
-            nbytes = _lib.lib().nws_reverb_workspace_bytes(C.byref(plan), 1)
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            check(_lib.lib().nws_reverb_ir_spectrum(C.byref(plan), ptr(tables), ptr(ir), ir.numel(), ptr(spec), ptr(ws),
-                                                    nbytes, stream_ptr()), "nws_reverb_ir_spectrum")
-            torch.cuda.current_stream().synchronize()
+            with torch.cuda.device(dev):
+                spec = torch.empty(_lib.lib().nws_reverb_spectrum_bytes(C.byref(plan)) // 4, dtype=torch.float32, device=dev)
+                nbytes = _lib.lib().nws_reverb_workspace_bytes(C.byref(plan), 1)
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                check(_lib.lib().nws_reverb_ir_spectrum(C.byref(plan), ptr(tables), ptr(ir), ir.numel(), ptr(spec), ptr(ws),
+                                                        nbytes, stream_ptr(dev)), "nws_reverb_ir_spectrum")
+                torch.cuda.current_stream(dev).synchronize()
             self._spectra[plan.L] = spec
-        return plan, tables, spec
+        return plan, tables, spec, plan_t
 
-    # ---- stage launchers (public for the parity tests; each is one C-ABI call) ------------------
+    # ---- stage launchers (public for the parity tests; each is one C-ABI call / one torch op) ------------------
     def phase_carry(self, f0=None, f0_up=None):
         src = f0 if f0 is not None else f0_up
+        o = ops()
+        if o is not None:
+            return o.phase_carry(f0, f0_up)
         B = src.shape[0]
         T = f0.shape[-1] if f0 is not None else f0_up.shape[-1] // _lib.HOP
-        carry = torch.empty((B, T * _lib.HOP // 32), dtype=torch.float64, device=src.device)
-        check(_lib.lib().nws_phase_carry(ptr(f0), ptr(f0_up), B, T, ptr(carry), stream_ptr()), "nws_phase_carry")
+        with torch.cuda.device(src.device):
+            carry = torch.empty((B, T * _lib.HOP // 32), dtype=torch.float64, device=src.device)
+            check(_lib.lib().nws_phase_carry(ptr(f0), ptr(f0_up), B, T, ptr(carry), stream_ptr(src.device)), "nws_phase_carry")
         return carry
 
     def exciter_newt(self, f0, f0_up, carry, phase_u, film, want_exciter=False, want_newt=True):
-        w, _, dev = self.weights()
+        w, _, dev, wdesc = self._wd()
         src = f0 if f0 is not None else f0_up
+        same_device(dev, f0=src, carry=carry, phase_u=phase_u, film=film)
+        sr = float(self._model_ref.sample_rate)
+        o = ops()
+        if o is not None:
+            exc, out = o.exciter_newt(wdesc, f0, f0_up, carry, phase_u, self._w[1][-2], film, sr, want_exciter, want_newt)
+            return (exc if want_exciter else None), (out if want_newt else None)
         B = src.shape[0]
         T = f0.shape[-1] if f0 is not None else f0_up.shape[-1] // _lib.HOP
         N = T * _lib.HOP
-        exc = torch.empty((B, _lib.N_SHAPERS, N), dtype=torch.float32, device=dev) if want_exciter else None
-        out = torch.empty((B, N), dtype=torch.float32, device=dev) if want_newt else None
-        m = self._model_ref
-        check(_lib.lib().nws_exciter_newt(C.byref(w), ptr(f0), ptr(f0_up), ptr(carry), ptr(phase_u),
-                                          ptr(self.rand_phase()), ptr(film), B, T, float(m.sample_rate), ptr(exc),
-                                          ptr(out), stream_ptr()), "nws_exciter_newt")
+        with torch.cuda.device(dev):
+            exc = torch.empty((B, _lib.N_SHAPERS, N), dtype=torch.float32, device=dev) if want_exciter else None
+            out = torch.empty((B, N), dtype=torch.float32, device=dev) if want_newt else None
+            check(_lib.lib().nws_exciter_newt(C.byref(w), ptr(f0), ptr(f0_up), ptr(carry), ptr(phase_u), ptr(self._w[1][-2]),
+                                              ptr(film), B, T, sr, ptr(exc), ptr(out), stream_ptr(dev)), "nws_exciter_newt")
         return exc, out
 
-    def control_gru(self, control, batched=False):
-        w, _, dev = self.weights()
+    def control_gru(self, control, batched=False, h0=None, return_state=False):
+        w, _, dev, wdesc = self._wd()
+        same_device(dev, control=control, h0=h0)
         B, Cc, T = control.shape
-        out = torch.empty((B, T, _lib.HIDDEN), dtype=torch.float32, device=dev)
-        if batched:
-            check(_lib.lib().nws_control_gru_batched(C.byref(w), ptr(control), B, Cc, T, None, ptr(out), None,
-                                                     stream_ptr()), "nws_control_gru_batched")
-        else:
-            check(_lib.lib().nws_control_gru(C.byref(w), ptr(control), B, Cc, T, ptr(out), stream_ptr()), "nws_control_gru")
-        return out
+        o = ops()
+        if o is not None:
+            out, hT = o.control_gru(wdesc, control, h0, bool(batched))
+            return (out, hT) if return_state else out
+        with torch.cuda.device(dev):
+            out = torch.empty((B, T, _lib.HIDDEN), dtype=torch.float32, device=dev)
+            hT = torch.empty((B, _lib.HIDDEN), dtype=torch.float32, device=dev) if return_state else None
+            fn = _lib.lib().nws_control_gru_batched if batched else _lib.lib().nws_control_gru_state
+            check(fn(C.byref(w), ptr(control), B, Cc, T, ptr(h0), ptr(out), ptr(hT), stream_ptr(dev)), "nws_control_gru")
+        return (out, hT) if return_state else out
 
     def frame_mlps(self, gru_out, want_emb=False, want_H=False):
-        w, _, dev = self.weights()
+        w, _, dev, wdesc = self._wd()
+        same_device(dev, gru_out=gru_out)
         B, T, _ = gru_out.shape
-        emb = torch.empty((B, _lib.HIDDEN, T), dtype=torch.float32, device=dev) if want_emb else None
-        film = torch.empty((B, T, _lib.FILM_CH), dtype=torch.float32, device=dev)
-        H = torch.empty((B, T, _lib.N_BANDS), dtype=torch.float32, device=dev) if want_H else None
-        fir = torch.empty((B, T, _lib.FIR_LEN), dtype=torch.float32, device=dev)
-        check(_lib.lib().nws_frame_mlps(C.byref(w), ptr(gru_out), ptr(self.fir_design()), B, T, ptr(emb), ptr(film),
-                                        ptr(H), ptr(fir), stream_ptr()), "nws_frame_mlps")
+        o = ops()
+        if o is not None:
+            emb, film, H, fir = o.frame_mlps(wdesc, gru_out, self._fir_design, want_emb, want_H)
+            return (emb if want_emb else None), film, (H if want_H else None), fir
+        with torch.cuda.device(dev):
+            emb = torch.empty((B, _lib.HIDDEN, T), dtype=torch.float32, device=dev) if want_emb else None
+            film = torch.empty((B, T, _lib.FILM_CH), dtype=torch.float32, device=dev)
+            H = torch.empty((B, T, _lib.N_BANDS), dtype=torch.float32, device=dev) if want_H else None
+            fir = torch.empty((B, T, _lib.FIR_LEN), dtype=torch.float32, device=dev)
+            check(_lib.lib().nws_frame_mlps(C.byref(w), ptr(gru_out), ptr(self._fir_design), B, T, ptr(emb), ptr(film),
+                                            ptr(H), ptr(fir), stream_ptr(dev)), "nws_frame_mlps")
         return emb, film, H, fir
 
-    def fir_noise(self, fir, noise, add_in=None):
+    def fir_noise(self, fir, noise, add_in=None, origin=None, noise_len=None):
+        """origin None: the reference's framing (N-1 noise samples, reflect padding); else a streaming window whose frame t
+        covers noise[128 t - origin, +256) of the first `noise_len` samples (nws_fir_noise_window)"""
         B, T, _ = fir.shape
-        out = torch.empty((B, T * _lib.HOP), dtype=torch.float32, device=fir.device)
-        check(_lib.lib().nws_fir_noise(ptr(fir), ptr(noise), ptr(add_in), B, T, ptr(out), stream_ptr()), "nws_fir_noise")
+        same_device(fir.device, noise=noise, add_in=add_in)
+        o = ops()
+        if o is not None:
+            nz = noise if noise_len is None or noise_len == noise.numel() else noise[:noise_len]
+            return o.fir_noise(fir, nz, add_in, -1 if origin is None else int(origin))
+        with torch.cuda.device(fir.device):
+            out = torch.empty((B, T * _lib.HOP), dtype=torch.float32, device=fir.device)
+            if origin is None:
+                check(_lib.lib().nws_fir_noise(ptr(fir), ptr(noise), ptr(add_in), B, T, ptr(out), stream_ptr(fir.device)),
+                      "nws_fir_noise")
+            else:
+                n_len = noise.numel() if noise_len is None else int(noise_len)
+                check(_lib.lib().nws_fir_noise_window(ptr(fir), ptr(noise), n_len, int(origin), ptr(add_in), B, T, ptr(out),
+                                                      stream_ptr(fir.device)), "nws_fir_noise_window")
         return out
 
     def reverb(self, x):
         B, N = x.shape
-        plan, tables, spec = self.reverb_aux(N)
-        nbytes = _lib.lib().nws_reverb_workspace_bytes(C.byref(plan), B)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        y = torch.empty_like(x)
-        check(_lib.lib().nws_reverb(C.byref(plan), ptr(tables), ptr(spec), ptr(x), B, N, ptr(y), ptr(ws), nbytes,
-                                    stream_ptr()), "nws_reverb")
+        _, _, dev, _ = self._wd()
+        same_device(dev, x=x)
+        plan, tables, spec, plan_t = self._reverb_aux(N)
+        o = ops()
+        if o is not None:
+            return o.reverb(plan_t, tables, spec, x)
+        with torch.cuda.device(x.device):
+            nbytes = _lib.lib().nws_reverb_workspace_bytes(C.byref(plan), B)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            y = torch.empty_like(x)
+            check(_lib.lib().nws_reverb(C.byref(plan), ptr(tables), ptr(spec), ptr(x), B, N, ptr(y), ptr(ws), nbytes,
+                                        stream_ptr(x.device)), "nws_reverb")
         return y
 
+    def reverb_linear_chunk(self, plan_aux, x, tail_in):
+        """streaming: y = x + wet[:M] + tail_in[:M]; returns (y, tail_out)"""
+        plan, tables, spec, plan_t = plan_aux
+        same_device(tables.device, x=x, tail_in=tail_in)
+        o = ops()
+        if o is not None:
+            return o.reverb_linear_chunk(plan_t, tables, spec, x, tail_in)
+        B, M = x.shape
+        with torch.cuda.device(x.device):
+            nfl = (2 * ((B + 1) // 2) + B) * plan.L
+            ws = torch.empty(nfl, dtype=torch.float32, device=x.device)
+            y, tail_out = torch.empty_like(x), torch.empty_like(tail_in)
+            check(_lib.lib().nws_reverb_linear_chunk(C.byref(plan), ptr(tables), ptr(spec), ptr(x), B, M, ptr(tail_in),
+                                                     ptr(tail_out), tail_in.shape[1], ptr(y), ptr(ws), nfl * 4,
+                                                     stream_ptr(x.device)), "nws_reverb_linear_chunk")
+        return y, tail_out
+
     def shaper_table(self, size, tmin, tmax):
-        w, _, dev = self.weights()
-        t = torch.empty((_lib.N_SHAPERS, size), dtype=torch.float32, device=dev)
-        check(_lib.lib().nws_shaper_table(C.byref(w), int(size), float(tmin), float(tmax), ptr(t), stream_ptr()),
-              "nws_shaper_table")
+        w, _, dev, wdesc = self._wd()
+        o = ops()
+        if o is not None:
+            return o.shaper_table(wdesc, self._w[1][-2], int(size), float(tmin), float(tmax))
+        with torch.cuda.device(dev):
+            t = torch.empty((_lib.N_SHAPERS, size), dtype=torch.float32, device=dev)
+            check(_lib.lib().nws_shaper_table(C.byref(w), int(size), float(tmin), float(tmax), ptr(t), stream_ptr(dev)),
+                  "nws_shaper_table")
         return t
 
     def shaper_apply(self, x):
-        w, _, _ = self.weights()
+        w, _, dev, wdesc = self._wd()
+        same_device(dev, x=x)
+        o = ops()
+        if o is not None:
+            return o.shaper_apply(wdesc, x)
         B, S, N = x.shape
-        y = torch.empty_like(x)
-        check(_lib.lib().nws_shaper_apply(C.byref(w), ptr(x), B, N, ptr(y), stream_ptr()), "nws_shaper_apply")
+        with torch.cuda.device(dev):
+            y = torch.empty_like(x)
+            check(_lib.lib().nws_shaper_apply(C.byref(w), ptr(x), B, N, ptr(y), stream_ptr(dev)), "nws_shaper_apply")
         return y
 
-    # ---- the whole forward: ONE C-ABI call --------------------------------------------------------
+    def newt_apply(self, exciter, film):
+        """NEWT.forward on a materialised exciter: exciter (B, 64, N), film (B, 256, T) channel-major -> (B, 1, N)"""
+        w, _, dev, wdesc = self._wd()
+        same_device(dev, exciter=exciter, film=film)
+        o = ops()
+        if o is not None:
+            return o.newt_apply(wdesc, exciter, film)
+        B, _, N = exciter.shape
+        T = film.shape[2]
+        if film.shape[1] != _lib.FILM_CH or N != T * _lib.HOP:
+            raise RuntimeError(f"NEWT: exciter {tuple(exciter.shape)} and FiLM parameters {tuple(film.shape)} disagree")
+        with torch.cuda.device(dev):
+            out = torch.empty((B, 1, N), dtype=torch.float32, device=dev)
+            check(_lib.lib().nws_newt_apply(C.byref(w), ptr(exciter), ptr(film), B, T, ptr(out), stream_ptr(dev)), "nws_newt_apply")
+        return out
+
     # ---- the forward in two halves (throughput pipeline, pipeline.py) ------------------------------------------------
     def new_workspace(self, B, T):
-        plan, _, _ = self.reverb_aux(T * _lib.HOP)
-        _, _, dev = self.weights()
+        _, _, dev, _ = self._wd()
+        plan, _, _, _ = self._reverb_aux(T * _lib.HOP)
         return torch.empty(_lib.lib().nws_forward_workspace_bytes(C.byref(plan), B, T), dtype=torch.uint8, device=dev)
 
     def forward_control(self, f0, control, ws, batched_gru=True):
         """phase carries + GRU into the head of `ws`, on the current stream"""
-        w, _, _ = self.weights()
+        w, _, dev, wdesc = self._wd()
+        same_device(dev, f0=f0, control=control, workspace=ws)
+        o = ops()
+        if o is not None:
+            o.forward_control(wdesc, f0, control, ws, bool(batched_gru))
+            return
         B, Cc, T = control.shape
-        check(_lib.lib().nws_forward_control(C.byref(w), ptr(f0), ptr(control), B, Cc, T, 1 if batched_gru else 0, ptr(ws),
-                                             ws.numel(), stream_ptr()), "nws_forward_control")
+        with torch.cuda.device(dev):
+            check(_lib.lib().nws_forward_control(C.byref(w), ptr(f0), ptr(control), B, Cc, T, 1 if batched_gru else 0, ptr(ws),
+                                                 ws.numel(), stream_ptr(dev)), "nws_forward_control")
 
     def forward_audio(self, f0, B, T, phase_u, noise, ws, out=None):
         """frame MLPs .. reverb from the head of `ws` (forward_control must have completed in stream order / by event)"""
-        w, _, dev = self.weights()
+        w, _, dev, wdesc = self._wd()
+        same_device(dev, f0=f0, phase_u=phase_u, noise=noise, workspace=ws, out=out)
         N = T * _lib.HOP
-        plan, tables, spec = self.reverb_aux(N)
-        if out is None:
-            out = torch.empty((B, N), dtype=torch.float32, device=dev)
-        aux = NwsForwardAux()
-        aux.fir_design = ptr(self.fir_design())
-        aux.plan = C.pointer(plan)
-        aux.reverb_tables = ptr(tables)
-        aux.reverb_spectrum = ptr(spec)
-        check(_lib.lib().nws_forward_audio(C.byref(w), C.byref(aux), ptr(f0), B, T, float(self._model_ref.sample_rate),
-                                           ptr(phase_u), ptr(self.rand_phase()), ptr(noise), ptr(out), ptr(ws), ws.numel(),
-                                           stream_ptr()), "nws_forward_audio")
+        plan, tables, spec, plan_t = self._reverb_aux(N)
+        sr = float(self._model_ref.sample_rate)
+        o = ops()
+        if o is not None:
+            return o.forward_audio(wdesc, f0, phase_u, self._w[1][-2], noise, self._fir_design, plan_t, tables, spec, ws, sr, out)
+        with torch.cuda.device(dev):
+            if out is None:
+                out = torch.empty((B, N), dtype=torch.float32, device=dev)
+            aux = NwsForwardAux()
+            aux.fir_design = ptr(self._fir_design)
+            aux.plan = C.pointer(plan)
+            aux.reverb_tables = ptr(tables)
+            aux.reverb_spectrum = ptr(spec)
+            check(_lib.lib().nws_forward_audio(C.byref(w), C.byref(aux), ptr(f0), B, T, sr, ptr(phase_u), ptr(self._w[1][-2]),
+                                               ptr(noise), ptr(out), ptr(ws), ws.numel(), stream_ptr(dev)), "nws_forward_audio")
         return out
 
-    def forward(self, f0, control, phase_u, noise, out=None):
-        w, _, dev = self.weights()
+    # ---- the whole forward: ONE op / ONE C-ABI call --------------------------------------------------------
+    def forward(self, f0, control, phase_u, noise):
+        w, _, dev, wdesc = self._wd()
+        same_device(dev, f0=f0, control=control, phase_u=phase_u, noise=noise)
         B, Cc, T = control.shape
         N = T * _lib.HOP
-        plan, tables, spec = self.reverb_aux(N)
-        key = (B, T, stream_ptr())   # one scratch arena per stream: forwards on different streams may overlap
+        plan, tables, spec, plan_t = self._reverb_aux(N)
+        key = (B, T, stream_ptr(dev))   # one scratch arena per stream: forwards on different streams may overlap
         ws = self._workspaces.get(key)
         if ws is None:
             nbytes = _lib.lib().nws_forward_workspace_bytes(C.byref(plan), B, T)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            if len(self._workspaces) > 8:
-                self._workspaces.clear()
+            if len(self._workspaces) >= 16:
+                # forget the oldest entry only: arenas of other streams may still be in use by enqueued work (their memory
+                # is handed back to the caching allocator, which re-issues a block only in the stream order it was used in)
+                self._workspaces.pop(next(iter(self._workspaces)))
             self._workspaces[key] = ws
-        if out is None:
+        sr = float(self._model_ref.sample_rate)
+        o = ops()
+        if o is not None:
+            return o.forward(wdesc, f0, control, phase_u, self._w[1][-2], noise, self._fir_design, plan_t, tables, spec, ws, sr)
+        with torch.cuda.device(dev):
             out = torch.empty((B, N), dtype=torch.float32, device=dev)
-        aux = NwsForwardAux()
-        aux.fir_design = ptr(self.fir_design())
-        aux.plan = C.pointer(plan)
-        aux.reverb_tables = ptr(tables)
-        aux.reverb_spectrum = ptr(spec)
-        check(_lib.lib().nws_forward(C.byref(w), C.byref(aux), ptr(f0), ptr(control), B, Cc, T,
-                                     float(self._model_ref.sample_rate), ptr(phase_u), ptr(self.rand_phase()),
-                                     ptr(noise), ptr(out), ptr(ws), ws.numel(), stream_ptr()), "nws_forward")
+            aux = NwsForwardAux()
+            aux.fir_design = ptr(self._fir_design)
+            aux.plan = C.pointer(plan)
+            aux.reverb_tables = ptr(tables)
+            aux.reverb_spectrum = ptr(spec)
+            check(_lib.lib().nws_forward(C.byref(w), C.byref(aux), ptr(f0), ptr(control), B, Cc, T, sr, ptr(phase_u),
+                                         ptr(self._w[1][-2]), ptr(noise), ptr(out), ptr(ws), ws.numel(), stream_ptr(dev)),
+                  "nws_forward")
         return out

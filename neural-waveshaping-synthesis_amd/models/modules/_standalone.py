@@ -1,0 +1,65 @@
+"""Plumbing for sub-modules called on their own (model.osc(f0), model.newt(exciter, emb), model.h_generator(emb), ...).
+
+Inside NeuralWaveshaping.forward these modules never run as separate launches (everything is fused into five kernels);
+called stand-alone each one maps to ONE stage kernel through torch.ops.newt_hip.* (or the ctypes binding of the same
+C-ABI entry point with NWS_BACKEND=ctypes).  No PyTorch arithmetic fallback: CPU tensors raise."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from ... import _lib
+from ...engine import _req, ops, stream_ptr
+
+
+def contiguous(t: torch.Tensor, name: str) -> torch.Tensor:
+    return _req(t if t.is_contiguous() else t.contiguous(), name)
+
+
+class Desc:
+    """A partial NwsWeights descriptor for one sub-module, cached until one of its tensors changes."""
+
+    def __init__(self):
+        self._key = None
+        self._val = None
+
+    def get(self, tensors: dict, scalars: dict | None = None):
+        key = tuple((k, t.data_ptr(), t._version) for k, t in tensors.items()) + tuple(sorted((scalars or {}).items()))
+        if key != self._key:
+            w = _lib.NwsWeights()
+            keep = []
+            for field, t in tensors.items():
+                t = _req(t.detach(), field)
+                keep.append(t)
+                setattr(w, field, t.data_ptr())
+            for field, v in (scalars or {}).items():
+                setattr(w, field, v)
+            self._val = (w, keep, torch.frombuffer(bytearray(bytes(w)), dtype=torch.uint8))
+            self._key = key
+        return self._val
+
+
+def shaper_fields(sh) -> dict:
+    """NwsWeights fields of a TrainableNonlinearity (reference shaping.py:15-37); the kernels are specialised for the
+    architecture of gin/models/newt.gin"""
+    if sh.depth != 4 or sh.width != 8 or sh.channels != 64:
+        raise RuntimeError("kernels are specialised for 64 shapers, width 8, depth 4 (gin/models/newt.gin)")
+    return {"shaper_in_scale": sh.input_scale, "shaper_w0": sh.net[0].weight, "shaper_b0": sh.net[0].bias,
+            "shaper_w2": sh.net[2].weight, "shaper_b2": sh.net[2].bias, "shaper_w4": sh.net[4].weight,
+            "shaper_b4": sh.net[4].bias, "shaper_w6": sh.net[6].weight, "shaper_b6": sh.net[6].bias}
+
+
+def call(op_name: str, c_name: str, op_args: tuple, c_call):
+    """Run `torch.ops.newt_hip.<op_name>(*op_args)` or, on the ctypes binding, `c_call(lib)` (which returns the result)."""
+    o = ops()
+    if o is not None:
+        return getattr(o, op_name)(*op_args)
+    return c_call(_lib.lib())
+
+
+def checked(rc: int, what: str):
+    _lib.check(rc, what)
+
+
+__all__ = ["C", "Desc", "call", "checked", "contiguous", "shaper_fields", "stream_ptr", "_req", "_lib", "ops"]

@@ -1,21 +1,32 @@
-"""Parameter containers for the frame-rate MLPs (reference: models/modules/dynamic.py:6-40).
+"""Frame-rate building blocks (reference: models/modules/dynamic.py:6-40).
 
-State-dict keys match the reference (``net.{0,3,6,9}.weight|bias``,
-``net.{1,4,7}.layer_norm.weight|bias``) so its checkpoints load unchanged.  The arithmetic
-(1x1 conv -> LayerNorm over channels -> LeakyReLU(0.01)) runs inside the HIP kernel
-``frame_mlps_kernel`` (csrc/frame_mlps.hip) on fp32 MFMA tiles.
+State-dict keys match the reference (``net.{0,3,6,9}.weight|bias``, ``net.{1,4,7}.layer_norm.weight|bias``) so its
+checkpoints load unchanged.  Inside ``NeuralWaveshaping.forward`` this arithmetic (1x1 conv -> LayerNorm over channels ->
+LeakyReLU(0.01), FiLM) runs fused in ``frame_mlps16_kernel`` / ``exciter_newt_kernel``; called on their own the modules
+run the stand-alone stage kernels of csrc/stages.hip (any layer sizes), one launch per call.
 """
+import torch
 import torch.nn as nn
 
 from ... import ginlite as gin
-from ._fused import fused_only
+from . import _standalone as sa
 
 
 class FiLM(nn.Module):
-    """gamma * x + beta (reference dynamic.py:6-8); fused into csrc/exciter_newt.hip."""
+    """gamma * x + beta (reference dynamic.py:6-8) on CUDA tensors; operands are broadcast like the reference's."""
 
     def forward(self, x, gamma, beta):
-        raise fused_only("FiLM", "NeuralWaveshaping.forward (exciter_newt_kernel)")
+        x, gamma, beta = torch.broadcast_tensors(x, gamma, beta)
+        x, gamma, beta = sa.contiguous(x, "x"), sa.contiguous(gamma, "gamma"), sa.contiguous(beta, "beta")
+
+        def c_call(L):
+            y = torch.empty_like(x)
+            with torch.cuda.device(x.device):
+                sa.checked(L.nws_film(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), x.numel(), y.data_ptr(),
+                                      sa.stream_ptr(x.device)), "nws_film")
+            return y
+
+        return sa.call("film", "nws_film", (x, gamma, beta), c_call)
 
 
 class TimeDistributedLayerNorm(nn.Module):
@@ -26,7 +37,20 @@ class TimeDistributedLayerNorm(nn.Module):
         self.layer_norm = nn.LayerNorm(size)
 
     def forward(self, x):
-        raise fused_only("TimeDistributedLayerNorm", "NeuralWaveshaping.forward (frame_mlps_kernel)")
+        x = sa.contiguous(x, "x")
+        ln = self.layer_norm
+        if x.dim() != 3 or x.shape[1] != ln.weight.numel():
+            raise RuntimeError(f"TimeDistributedLayerNorm({ln.weight.numel()}): expected (B, {ln.weight.numel()}, T), got {tuple(x.shape)}")
+        g, b = sa._req(ln.weight.detach(), "layer_norm.weight"), sa._req(ln.bias.detach(), "layer_norm.bias")
+
+        def c_call(L):
+            y = torch.empty_like(x)
+            with torch.cuda.device(x.device):
+                sa.checked(L.nws_td_layer_norm(x.data_ptr(), g.data_ptr(), b.data_ptr(), x.shape[0], x.shape[1], x.shape[2],
+                                               float(ln.eps), y.data_ptr(), sa.stream_ptr(x.device)), "nws_td_layer_norm")
+            return y
+
+        return sa.call("td_layer_norm", "nws_td_layer_norm", (x, g, b, float(ln.eps)), c_call)
 
 
 @gin.configurable
@@ -44,4 +68,37 @@ class TimeDistributedMLP(nn.Module):
         self.in_size, self.hidden_size, self.out_size, self.depth = in_size, hidden_size, out_size, depth
 
     def forward(self, x):
-        raise fused_only("TimeDistributedMLP", "NeuralWaveshaping.forward (frame_mlps_kernel)")
+        """(B, in_size, T) -> (B, out_size, T) on a CUDA tensor: one launch of td_mlp_kernel (csrc/stages.hip)."""
+        x = sa.contiguous(x, "x")
+        if x.dim() != 3 or x.shape[1] != self.in_size:
+            raise RuntimeError(f"TimeDistributedMLP: expected (B, {self.in_size}, T), got {tuple(x.shape)}")
+        return td_mlp_forward(x, self.net)
+
+
+def td_mlp_forward(x, net):
+    """Run a Conv1d(k=1) [-> TimeDistributedLayerNorm -> LeakyReLU] ... stack (or a bare Conv1d) on (B, C, T)."""
+    mods = list(net) if isinstance(net, (nn.Sequential, list, tuple)) else [net]
+    convs = [m for m in mods if isinstance(m, nn.Conv1d)]
+    norms = [m for m in mods if isinstance(m, TimeDistributedLayerNorm)]
+    acts = [m for m in mods if isinstance(m, nn.LeakyReLU)]
+    if len(norms) != len(convs) - 1 or any(c.kernel_size != (1,) or c.groups != 1 for c in convs):
+        raise RuntimeError("TimeDistributedMLP: unexpected layer stack")
+    ws = [sa._req(c.weight.detach(), "net weight") for c in convs]
+    bs = [sa._req(c.bias.detach(), "net bias") for c in convs]
+    gs = [sa._req(n.layer_norm.weight.detach(), "layer_norm.weight") for n in norms]
+    ls = [sa._req(n.layer_norm.bias.detach(), "layer_norm.bias") for n in norms]
+    eps = float(norms[0].layer_norm.eps) if norms else 1e-5
+    slope = float(acts[0].negative_slope) if acts else 0.01
+    depth = len(convs)
+    hidden = ws[0].shape[0]
+    out_size = ws[-1].shape[0]
+
+    def c_call(L):
+        arr = lambda ts: (sa.C.c_void_p * max(1, len(ts)))(*[t.data_ptr() for t in ts])  # noqa: E731
+        y = torch.empty((x.shape[0], out_size, x.shape[2]), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            sa.checked(L.nws_td_mlp(x.data_ptr(), x.shape[0], x.shape[1], hidden, out_size, depth, x.shape[2], arr(ws), arr(bs),
+                                    arr(gs), arr(ls), eps, slope, y.data_ptr(), sa.stream_ptr(x.device)), "nws_td_mlp")
+        return y
+
+    return sa.call("td_mlp", "nws_td_mlp", (x, ws, bs, gs, ls, eps, slope), c_call)

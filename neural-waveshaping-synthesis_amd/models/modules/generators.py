@@ -1,8 +1,10 @@
 """Signal generators of the NEWT synthesiser (reference: models/modules/generators.py:11-66).
 
-These classes keep the reference's constructor signatures, buffers and state-dict keys; the DSP
-itself runs in csrc/exciter_newt.hip (oscillator bank, fused with the 101->64 mixer and the
-waveshapers) and csrc/fir_noise.hip (time-varying FIR noise).
+These classes keep the reference's constructor signatures, buffers and state-dict keys.  Inside
+``NeuralWaveshaping.forward`` the DSP runs fused (csrc/exciter_newt.hip: oscillator bank + 101->64 mixer + waveshapers;
+csrc/fir_noise.hip: time-varying FIR noise); called on their own the modules run the stand-alone stage kernels
+(``oscillator_kernel``; ``fir_from_h_kernel`` + the noise kernel), drawing from the device's default generator exactly
+like the reference (``rand_like`` for the phase offsets, ``rand(hop * T - 1)`` for the excitation).
 """
 import math
 from typing import Callable
@@ -11,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from ... import ginlite as gin
-from ._fused import fused_only
+from . import _standalone as sa
 
 
 @gin.configurable
@@ -21,9 +23,55 @@ class FIRNoiseSynth(nn.Module):
         self.ir_length = ir_length
         self.hop_length = hop_length
         self.register_buffer("window", window_fn(ir_length))
+        self._design = {}
 
-    def forward(self, H_re):
-        raise fused_only("FIRNoiseSynth", "NeuralWaveshaping.forward (frame_mlps_kernel + fir_noise_kernel)")
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_design"] = {}
+        return d
+
+    def _design_matrix(self, dev):
+        """window * roll(irfft(.), ir_length / 2) folded into one (256, 132) matrix (nws_fir_design_matrix), per window"""
+        win = sa._req(self.window.detach(), "noise_synth.window", sa._lib.FIR_LEN)
+        key = (win.data_ptr(), win._version)
+        hit = self._design.get(key)
+        if hit is None:
+            self._design.clear()
+            hit = torch.empty(sa._lib.FIR_LEN * sa._lib.FIR_DESIGN_COLS, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                sa.checked(sa._lib.lib().nws_fir_design_matrix(win.data_ptr(), hit.data_ptr(), sa.stream_ptr(dev)),
+                           "nws_fir_design_matrix")
+            self._design[key] = hit
+        return hit
+
+    def forward(self, H_re, *, noise=None):
+        """H_re (B, ir_length/2 + 1, T) real filter magnitudes -> (B, 1, hop * T) filtered noise (generators.py:21-35).
+        `noise` injects the excitation draw (hop * T - 1 samples) for parity tests."""
+        if self.ir_length != sa._lib.FIR_LEN or self.hop_length != sa._lib.HOP:
+            raise RuntimeError("kernels are specialised for ir_length 256, hop_length 128 (gin/models/newt.gin)")
+        H = sa.contiguous(H_re, "H_re")
+        if H.dim() != 3 or H.shape[1] != sa._lib.N_BANDS:
+            raise RuntimeError(f"FIRNoiseSynth: expected (B, {sa._lib.N_BANDS}, T), got {tuple(H.shape)}")
+        B, _, T = H.shape
+        if T < 2:
+            raise RuntimeError("need at least 2 frames (reflect padding of the noise STFT, generators.py:31)")
+        D = self._design_matrix(H.device)
+        if noise is None:
+            noise = torch.rand(self.hop_length * T - 1, device=H.device)          # the reference's draw (generators.py:30)
+        noise = sa._req(noise, "noise", self.hop_length * T - 1)
+
+        def c_call(L):
+            with torch.cuda.device(H.device):
+                fir = torch.empty((B, T, sa._lib.FIR_LEN), dtype=torch.float32, device=H.device)
+                out = torch.empty((B, T * sa._lib.HOP), dtype=torch.float32, device=H.device)
+                sa.checked(L.nws_fir_from_h(H.data_ptr(), D.data_ptr(), B, T, fir.data_ptr(), sa.stream_ptr(H.device)), "nws_fir_from_h")
+                sa.checked(L.nws_fir_noise(fir.data_ptr(), noise.data_ptr(), None, B, T, out.data_ptr(), sa.stream_ptr(H.device)),
+                           "nws_fir_noise")
+            return out
+
+        o = sa.ops()
+        out = o.fir_noise(o.fir_from_h(H, D), noise, None, -1) if o is not None else c_call(sa._lib.lib())
+        return out.unsqueeze(1)
 
 
 @gin.configurable
@@ -36,5 +84,28 @@ class HarmonicOscillator(nn.Module):
         self.register_buffer("harmonic_axis", torch.arange(1, n_harmonics + 1).view(1, -1, 1))
         self.register_buffer("rand_phase", torch.full((1, n_harmonics, 1), math.tau))
 
-    def forward(self, f0):
-        raise fused_only("HarmonicOscillator", "NeuralWaveshaping.render_exciter / forward (exciter_newt_kernel)")
+    def forward(self, f0, *, phase_u=None):
+        """(B, N) upsampled F0 in Hz -> (B, n_harmonics, N): sin(k * tau * cumsum(f0) / sr + shift_k) * [k f0 < sr / 2]
+        (generators.py:58-66; the cumulative sum is accumulated in float64 like torch's CPU cumsum).  N must be a multiple
+        of 128.  `phase_u` injects the U[0,1) phase draw for parity tests."""
+        if self.n_harmonics != sa._lib.N_HARMONICS:
+            raise RuntimeError("kernels are specialised for 101 harmonics (gin/models/newt.gin)")
+        f0 = sa.contiguous(f0, "f0")
+        if f0.dim() != 2 or f0.shape[1] % sa._lib.HOP:
+            raise RuntimeError(f"HarmonicOscillator: expected (B, 128*T), got {tuple(f0.shape)}")
+        rp = sa._req(self.rand_phase.detach().reshape(-1), "osc.rand_phase", sa._lib.N_HARMONICS)
+        u = torch.rand_like(self.rand_phase) if phase_u is None else phase_u            # the reference's draw (generators.py:55)
+        u = sa._req(u.reshape(-1), "phase_u", sa._lib.N_HARMONICS)
+        B, N = f0.shape
+
+        def c_call(L):
+            with torch.cuda.device(f0.device):
+                carry = torch.empty((B, N // 32), dtype=torch.float64, device=f0.device)
+                out = torch.empty((B, sa._lib.N_HARMONICS, N), dtype=torch.float32, device=f0.device)
+                st = sa.stream_ptr(f0.device)
+                sa.checked(L.nws_phase_carry(None, f0.data_ptr(), B, N // sa._lib.HOP, carry.data_ptr(), st), "nws_phase_carry")
+                sa.checked(L.nws_oscillator(f0.data_ptr(), carry.data_ptr(), u.data_ptr(), rp.data_ptr(), B, N,
+                                            float(self.sample_rate), out.data_ptr(), st), "nws_oscillator")
+            return out
+
+        return sa.call("oscillator", "nws_oscillator", (f0, u, rp, float(self.sample_rate)), c_call)

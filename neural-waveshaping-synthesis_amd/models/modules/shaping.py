@@ -2,20 +2,46 @@
 
 Constructor signatures, attribute names and state-dict keys follow the reference so that
 ``model.newt = FastNEWT(model.newt)`` (scripts/time_forward_pass.py:42-43, colab cell 17) and
-checkpoint loading work unchanged.  The arithmetic lives in csrc/exciter_newt.hip (FiLM -> shaper
-LUT / sin-MLP -> FiLM -> 64->1 mix, fused with the exciter) and csrc/reverb_fft.hip.
+checkpoint loading work unchanged.  Inside ``NeuralWaveshaping.forward`` the arithmetic lives in csrc/exciter_newt.hip
+(FiLM -> shaper LUT / sin-MLP -> FiLM -> 64->1 mix, fused with the exciter) and csrc/reverb_fft.hip; called on their own,
+``NEWT.forward(exciter, control_embedding)``, ``TrainableNonlinearity.forward``, ``FastNEWT.shaping_fn``, ``Sine`` and
+``Reverb.forward`` each run one stand-alone stage kernel.
 """
+import ctypes as C
+
 import torch
 import torch.nn as nn
 
 from ... import ginlite as gin
+from . import _standalone as sa
 from .dynamic import FiLM, TimeDistributedMLP
-from ._fused import fused_only
 
 
 class Sine(nn.Module):
     def forward(self, x):
-        raise fused_only("Sine", "the shaper kernels (nws_sinf in csrc/nws_common.h)")
+        """sin(x) on a CUDA tensor with the engine's full-range sine (nws_sin: <= 1.5e-7 absolute)."""
+        x = sa.contiguous(x, "x")
+
+        def c_call(L):
+            y = torch.empty_like(x)
+            with torch.cuda.device(x.device):
+                sa.checked(L.nws_sin(x.data_ptr(), y.data_ptr(), x.numel(), sa.stream_ptr(x.device)), "nws_sin")
+            return y
+
+        return sa.call("sine", "nws_sin", (x,), c_call)
+
+
+def _shaper_apply(x, wdesc_tuple):
+    w, _, wdesc = wdesc_tuple
+
+    def c_call(L):
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            sa.checked(L.nws_shaper_apply(C.byref(w), x.data_ptr(), x.shape[0], x.shape[2], y.data_ptr(), sa.stream_ptr(x.device)),
+                       "nws_shaper_apply")
+        return y
+
+    return sa.call("shaper_apply", "nws_shaper_apply", (wdesc, x), c_call)
 
 
 @gin.configurable
@@ -33,36 +59,21 @@ class TrainableNonlinearity(nn.Module):
             stack.append(final_nonlinearity() if last else nonlinearity())
         self.net = nn.Sequential(*stack)
         self.channels, self.width, self.depth = channels, width, depth
+        self._desc = sa.Desc()
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_desc"] = sa.Desc()
+        return d
 
     def forward(self, x):
         """Exact shapers on a (B, 64, N) CUDA tensor - one HIP kernel (nws_shaper_apply)."""
-        from ...engine import _req  # local import: keep module import light
-        from ... import _lib
-        import ctypes as C
-
-        x = _req(x, "x")
+        x = sa.contiguous(x, "x")
         if x.dim() != 3 or x.shape[1] != self.channels:
             raise RuntimeError(f"expected (B, {self.channels}, N), got {tuple(x.shape)}")
-        w = _lib.NwsWeights()
-        keep = []
-
-        def P(t, n):
-            t = _req(t.detach(), "shaping_fn", n)
-            keep.append(t)
-            return t.data_ptr()
-
-        if self.depth != 4 or self.width != 8 or self.channels != 64:
-            raise RuntimeError("kernels are specialised for 64 shapers, width 8, depth 4")
-        w.shaper_in_scale = P(self.input_scale, 64)
-        w.shaper_w0, w.shaper_b0 = P(self.net[0].weight, 512), P(self.net[0].bias, 512)
-        w.shaper_w2, w.shaper_b2 = P(self.net[2].weight, 4096), P(self.net[2].bias, 512)
-        w.shaper_w4, w.shaper_b4 = P(self.net[4].weight, 4096), P(self.net[4].bias, 512)
-        w.shaper_w6, w.shaper_b6 = P(self.net[6].weight, 512), P(self.net[6].bias, 64)
-        w.lut = None
-        y = torch.empty_like(x)
-        _lib.check(_lib.lib().nws_shaper_apply(C.byref(w), x.data_ptr(), x.shape[0], x.shape[2], y.data_ptr(),
-                                               _lib.stream_ptr()), "nws_shaper_apply")
-        return y
+        if not all(isinstance(m, Sine) for m in list(self.net)[1::2]):
+            raise RuntimeError("kernels implement the sine activations NEWT configures (nonlinearity=Sine)")
+        return _shaper_apply(x, self._desc.get(sa.shaper_fields(self)))
 
 
 @gin.configurable
@@ -76,9 +87,40 @@ class NEWT(nn.Module):
         self.shaping_fn = TrainableNonlinearity(n_waveshapers, shaping_fn_size, nonlinearity=Sine)
         self.normalising_coeff = FiLM()
         self.mixer = nn.Sequential(nn.Conv1d(n_waveshapers, out_channels, 1))
+        self._newt_desc = sa.Desc()
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_newt_desc"] = sa.Desc()
+        return d
+
+    def _apply_fields(self):
+        return sa.shaper_fields(self._modules["shaping_fn"]), {}
 
     def forward(self, exciter, control_embedding):
-        raise fused_only("NEWT", "NeuralWaveshaping.forward (frame_mlps_kernel + exciter_newt_kernel)")
+        """(B, 64, N) exciter, (B, 128, T) control embedding -> (B, 1, N) (reference shaping.py:67-79): the FiLM-parameter
+        MLP (one launch) then FiLM -> shaper -> FiLM -> Conv1d(64 -> 1) on the materialised exciter (one launch)."""
+        exciter = sa.contiguous(exciter, "exciter")
+        if self.n_waveshapers != sa._lib.N_SHAPERS or self.mixer[0].out_channels != 1:
+            raise RuntimeError("kernels are specialised for 64 waveshapers, one output channel (gin/models/newt.gin)")
+        if exciter.dim() != 3 or exciter.shape[1] != self.n_waveshapers:
+            raise RuntimeError(f"NEWT: expected an exciter of shape (B, {self.n_waveshapers}, N), got {tuple(exciter.shape)}")
+        film = self.mlp(control_embedding)                       # (B, 256, T), channel-major like the reference's Conv1d stack
+        T = film.shape[2]
+        if exciter.shape[0] != film.shape[0] or exciter.shape[2] != T * sa._lib.HOP:
+            raise RuntimeError(f"NEWT: exciter {tuple(exciter.shape)} does not match {T} control frames x {sa._lib.HOP}")
+        tensors, scalars = self._apply_fields()
+        tensors = dict(tensors, newt_out_w=self.mixer[0].weight, newt_out_b=self.mixer[0].bias)
+        w, _, wdesc = self._newt_desc.get(tensors, scalars)
+
+        def c_call(L):
+            with torch.cuda.device(exciter.device):
+                out = torch.empty((exciter.shape[0], 1, exciter.shape[2]), dtype=torch.float32, device=exciter.device)
+                sa.checked(L.nws_newt_apply(C.byref(w), exciter.data_ptr(), film.data_ptr(), exciter.shape[0], T, out.data_ptr(),
+                                            sa.stream_ptr(exciter.device)), "nws_newt_apply")
+            return out
+
+        return sa.call("newt_apply", "nws_newt_apply", (wdesc, exciter, film), c_call)
 
 
 class FastNEWT(NEWT):
@@ -102,13 +144,15 @@ class FastNEWT(NEWT):
         self.mixer = newt.mixer
         self._modules["shaping_fn"] = newt._modules["shaping_fn"]
         self.lookup_table = self._init_lookup_table(newt, table_size, self.n_waveshapers, table_min, table_max)
+        self._lut_desc = sa.Desc()
+
+    def __getstate__(self):
+        d = super().__getstate__()
+        d["_lut_desc"] = sa.Desc()
+        return d
 
     @staticmethod
     def _init_lookup_table(newt, table_size, n_waveshapers, table_min, table_max):
-        import ctypes as C
-        from ... import _lib
-        from ...engine import _req
-
         sh = newt._modules["shaping_fn"]
         home = sh.input_scale.device
         if home.type == "cuda":
@@ -118,43 +162,39 @@ class FastNEWT(NEWT):
             # the table is still computed by the HIP kernel, then parked next to the module
             dev = torch.device("cuda", torch.cuda.current_device())
         else:
-            raise _lib.NwsError("FastNEWT needs an AMD GPU to evaluate its lookup table (no CPU fallback)")
-        if sh.depth != 4 or sh.width != 8 or n_waveshapers != 64:
+            raise sa._lib.NwsError("FastNEWT needs an AMD GPU to evaluate its lookup table (no CPU fallback)")
+        if n_waveshapers != 64:
             raise RuntimeError("kernels are specialised for 64 shapers, width 8, depth 4")
-        w = _lib.NwsWeights()
-        keep = []
+        fields = {k: v.detach().to(dev).contiguous() for k, v in sa.shaper_fields(sh).items()}
+        w, keep, wdesc = sa.Desc().get(fields)
+        like = keep[0]
 
-        def P(t, n):
-            t = _req(t.detach().to(dev).contiguous(), "shaping_fn", n)
-            keep.append(t)
-            return t.data_ptr()
+        def c_call(L):
+            with torch.cuda.device(dev):
+                table = torch.empty((n_waveshapers, table_size), dtype=torch.float32, device=dev)
+                sa.checked(L.nws_shaper_table(C.byref(w), int(table_size), float(table_min), float(table_max), table.data_ptr(),
+                                              sa.stream_ptr(dev)), "nws_shaper_table")
+            return table
 
-        w.shaper_in_scale = P(sh.input_scale, 64)
-        w.shaper_w0, w.shaper_b0 = P(sh.net[0].weight, 512), P(sh.net[0].bias, 512)
-        w.shaper_w2, w.shaper_b2 = P(sh.net[2].weight, 4096), P(sh.net[2].bias, 512)
-        w.shaper_w4, w.shaper_b4 = P(sh.net[4].weight, 4096), P(sh.net[4].bias, 512)
-        w.shaper_w6, w.shaper_b6 = P(sh.net[6].weight, 512), P(sh.net[6].bias, 64)
-        table = torch.empty((n_waveshapers, table_size), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
-            _lib.check(_lib.lib().nws_shaper_table(C.byref(w), int(table_size), float(table_min), float(table_max),
-                                                   table.data_ptr(), _lib.stream_ptr()), "nws_shaper_table")
-            torch.cuda.current_stream().synchronize()
+        table = sa.call("shaper_table", "nws_shaper_table", (wdesc, like, int(table_size), float(table_min), float(table_max)), c_call)
+        torch.cuda.current_stream(dev).synchronize()
         return nn.Parameter(table.to(home))
+
+    def _lut_fields(self):
+        return {"lut": self.lookup_table}, {"lut_size": int(self.table_size), "lut_min": float(self.table_min),
+                                            "lut_max": float(self.table_max)}
+
+    def _apply_fields(self):
+        return self._lut_fields()
 
     def shaping_fn(self, x):
         """LUT lookup with the reference's index quirks, on a (B, 64, N) CUDA tensor (nws_shaper_apply)."""
-        import ctypes as C
-        from ... import _lib
-        from ...engine import _req
-
-        x = _req(x, "x")
-        w = _lib.NwsWeights()
-        table = _req(self.lookup_table.detach(), "lookup_table", 64 * self.table_size)
-        w.lut, w.lut_size, w.lut_min, w.lut_max = table.data_ptr(), self.table_size, self.table_min, self.table_max
-        y = torch.empty_like(x)
-        _lib.check(_lib.lib().nws_shaper_apply(C.byref(w), x.data_ptr(), x.shape[0], x.shape[2], y.data_ptr(),
-                                               _lib.stream_ptr()), "nws_shaper_apply")
-        return y
+        x = sa.contiguous(x, "x")
+        if x.dim() != 3 or x.shape[1] != self.n_waveshapers:
+            raise RuntimeError(f"expected (B, {self.n_waveshapers}, N), got {tuple(x.shape)}")
+        if self.lookup_table.numel() != 64 * self.table_size:
+            raise RuntimeError("lookup_table does not match table_size")
+        return _shaper_apply(x, self._lut_desc.get(*self._lut_fields()))
 
 
 @gin.configurable
@@ -167,33 +207,44 @@ class Reverb(nn.Module):
         self.register_buffer("initial_zero", torch.zeros(1, 1))
         self._tables = {}
 
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_tables"] = {}
+        return d
+
     def forward(self, x):
         """Stand-alone reverb on a (B, N) CUDA tensor: four-step FFT kernels of csrc/reverb_fft.hip."""
-        import ctypes as C
-        from ... import _lib
-        from ...engine import _req, reverb_plan_and_tables
+        from ...engine import reverb_plan_and_tables
 
-        x = _req(x, "x")
+        x = sa.contiguous(x, "x")
         if x.dim() != 2:
             raise RuntimeError(f"expected (B, N), got {tuple(x.shape)}")
-        ir = _req(self.ir.detach(), "reverb.ir")
+        ir = sa._req(self.ir.detach(), "reverb.ir")
+        if ir.device != x.device:
+            raise RuntimeError(f"x is on {x.device} but reverb.ir is on {ir.device}")
         B, N = x.shape
-        plan, tables = reverb_plan_and_tables(x.device, N, ir.numel() + 1)
-        L = _lib.lib()
+        plan, tables, plan_t = reverb_plan_and_tables(x.device, N, ir.numel() + 1)
+        L = sa._lib.lib()
         key = (plan.L, ir.data_ptr(), ir._version)
         spec = self._tables.get(key)
         if spec is None:
             self._tables.clear()
-            spec = torch.empty(L.nws_reverb_spectrum_bytes(C.byref(plan)) // 4, dtype=torch.float32, device=x.device)
-            nb = L.nws_reverb_workspace_bytes(C.byref(plan), 1)
-            ws1 = torch.empty(nb, dtype=torch.uint8, device=x.device)
-            _lib.check(L.nws_reverb_ir_spectrum(C.byref(plan), tables.data_ptr(), ir.data_ptr(), ir.numel(),
-                                                spec.data_ptr(), ws1.data_ptr(), nb, _lib.stream_ptr()),
-                       "nws_reverb_ir_spectrum")
+            with torch.cuda.device(x.device):
+                spec = torch.empty(L.nws_reverb_spectrum_bytes(C.byref(plan)) // 4, dtype=torch.float32, device=x.device)
+                nb = L.nws_reverb_workspace_bytes(C.byref(plan), 1)
+                ws1 = torch.empty(nb, dtype=torch.uint8, device=x.device)
+                sa.checked(L.nws_reverb_ir_spectrum(C.byref(plan), tables.data_ptr(), ir.data_ptr(), ir.numel(),
+                                                    spec.data_ptr(), ws1.data_ptr(), nb, sa.stream_ptr(x.device)),
+                           "nws_reverb_ir_spectrum")
             self._tables[key] = spec
-        nb = L.nws_reverb_workspace_bytes(C.byref(plan), B)
-        ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
-        y = torch.empty_like(x)
-        _lib.check(L.nws_reverb(C.byref(plan), tables.data_ptr(), spec.data_ptr(), x.data_ptr(), B, N, y.data_ptr(),
-                                ws.data_ptr(), nb, _lib.stream_ptr()), "nws_reverb")
-        return y
+
+        def c_call(L):
+            with torch.cuda.device(x.device):
+                nb = L.nws_reverb_workspace_bytes(C.byref(plan), B)
+                ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+                y = torch.empty_like(x)
+                sa.checked(L.nws_reverb(C.byref(plan), tables.data_ptr(), spec.data_ptr(), x.data_ptr(), B, N, y.data_ptr(),
+                                        ws.data_ptr(), nb, sa.stream_ptr(x.device)), "nws_reverb")
+            return y
+
+        return sa.call("reverb", "nws_reverb", (plan_t, tables, spec, x), c_call)

@@ -19,10 +19,10 @@ import torch.nn as nn
 from .. import _lib
 from .. import ginlite as gin
 from ..engine import Engine, _req
-from .modules.dynamic import TimeDistributedMLP
+from .modules import _standalone as sa
+from .modules.dynamic import TimeDistributedMLP, td_mlp_forward
 from .modules.generators import FIRNoiseSynth, HarmonicOscillator
 from .modules.shaping import NEWT, Reverb
-from .modules._fused import fused_only
 
 gin.external_configurable(nn.GRU, module="torch.nn")
 gin.external_configurable(nn.Conv1d, module="torch.nn")
@@ -39,8 +39,37 @@ class ControlModule(nn.Module):
         self.gru = nn.GRU(control_size, hidden_size, batch_first=True)
         self.proj = nn.Conv1d(hidden_size, embedding_size, 1)
 
+        self._desc = sa.Desc()
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_desc"] = sa.Desc()
+        return d
+
     def forward(self, x):
-        raise fused_only("ControlModule", "NeuralWaveshaping.get_embedding / forward (control_gru_kernel)")
+        """(B, control_size, T) -> (B, embedding_size, T): persistent GRU kernel (csrc/control_gru.hip) + Conv1d(k=1).
+        Stand-alone form of what NeuralWaveshaping.forward runs fused (GRU, then proj inside frame_mlps16_kernel)."""
+        import ctypes as C
+
+        x = sa.contiguous(x, "x")
+        g = self.gru
+        if g.input_size != 2 or g.hidden_size != sa._lib.HIDDEN or g.num_layers != 1 or g.bidirectional:
+            raise RuntimeError("kernels are specialised for GRU(2 -> 128), one layer (gin/models/newt.gin)")
+        if x.dim() != 3 or x.shape[1] != g.input_size:
+            raise RuntimeError(f"ControlModule: expected (B, {g.input_size}, T), got {tuple(x.shape)}")
+        w, _, wdesc = self._desc.get({"gru_w_ih": g.weight_ih_l0, "gru_w_hh": g.weight_hh_l0, "gru_b_ih": g.bias_ih_l0,
+                                      "gru_b_hh": g.bias_hh_l0})
+
+        def c_call(L):
+            with torch.cuda.device(x.device):
+                out = torch.empty((x.shape[0], x.shape[2], sa._lib.HIDDEN), dtype=torch.float32, device=x.device)
+                sa.checked(L.nws_control_gru(C.byref(w), x.data_ptr(), x.shape[0], x.shape[1], x.shape[2], out.data_ptr(),
+                                             sa.stream_ptr(x.device)), "nws_control_gru")
+            return out
+
+        o = sa.ops()
+        h = o.control_gru(wdesc, x, None, False)[0] if o is not None else c_call(sa._lib.lib())      # (B, T, 128)
+        return td_mlp_forward(h.transpose(1, 2).contiguous(), self.proj)
 
 
 @gin.configurable
@@ -88,8 +117,19 @@ class NeuralWaveshaping(nn.Module):
             self._engine.invalidate()
 
     def invalidate_cache(self):
-        """Call after mutating parameters in place (the engine caches raw device pointers)."""
+        """Drop the engine's cached pointer struct and derived tables.  In-place parameter updates are noticed on their own
+        (Engine._fingerprint); needed only after writes through `p.data` or after changing `exciter_opts`."""
         self._engine.invalidate()
+
+    # a copy / an unpickled model gets its own engine (the cache holds raw device pointers of THIS model's tensors)
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d.pop("_engine", None)
+        return d
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        object.__setattr__(self, "_engine", Engine(self))
 
     # ---- public surface ----------------------------------------------------------------------------
     def render_exciter(self, f0):
@@ -101,7 +141,7 @@ class NeuralWaveshaping(nn.Module):
         f0_up = f0[:, 0]
         u = torch.rand_like(self.osc.rand_phase).reshape(-1)
         carry = eng.phase_carry(f0_up=f0_up)
-        exc, _ = eng.exciter_newt(None, f0_up, carry, u, None, want_exciter=True, want_newt=False)
+        exc, _ = eng.exciter_newt(None, f0_up.contiguous(), carry, u, None, want_exciter=True, want_newt=False)
         return exc
 
     def get_embedding(self, control):

@@ -21,12 +21,9 @@ are injected for parity testing), mirroring the reference's two hidden draws.
 """
 from __future__ import annotations
 
-import ctypes as C
-
 import torch
 
 from . import _lib
-from ._lib import check, ptr, stream_ptr
 from .engine import _req
 
 HOP = _lib.HOP
@@ -54,11 +51,10 @@ class NewtStream:
         self.finished = False
         ir = self.eng.ir()
         self.tail_len = ir.numel() + 1
-        self.plan, self.tables, self.spec = self.eng.reverb_aux(2 * self.tail_len)   # L = 64000 >= chunk + 32000 - 1
+        self._rv_aux = self.eng.reverb_aux(2 * self.tail_len)   # L = 64000 >= chunk + 32000 - 1
+        self.plan = self._rv_aux[0]
         self.tails = [torch.zeros((self.B, self.tail_len), dtype=torch.float32, device=dev) for _ in range(2)]
         self._tail_idx = 0
-        pairs = (self.B + 1) // 2
-        self._rv_ws = torch.empty((2 * pairs + self.B) * self.plan.L, dtype=torch.float32, device=dev)
 
     # ---- noise stream ---------------------------------------------------------------------------------------------
     def _noise_view(self, start: int, upto: int):
@@ -93,17 +89,11 @@ class NewtStream:
                 k1 = min(K, k0 + _MAX_CHUNK_FRAMES)
                 outs.append(self.push(f0[:, :, k0:k1], control[:, :, k0:k1], final and k1 == K))
             return torch.cat(outs, dim=1)
-        L = _lib.lib()
         eng = self.eng
-        w, _, _ = eng.weights()
         first = self.prev is None
 
         # 1. control path on the K new frames (GRU state carried)
-        gru = torch.empty((B, K, _lib.HIDDEN), dtype=torch.float32, device=self.dev)
-        h_new = torch.empty_like(self.h)
-        check(L.nws_control_gru_state(C.byref(w), ptr(control), B, control.shape[1], K, ptr(self.h), ptr(gru), ptr(h_new),
-                                      stream_ptr()), "nws_control_gru_state")
-        self.h = h_new
+        gru, self.h = eng.control_gru(control, h0=self.h, return_state=True)
         _, film, _, fir = eng.frame_mlps(gru)
 
         # 2. window = [previous frame] + new frames
@@ -144,9 +134,7 @@ class NewtStream:
             n_len = nview.numel()
         if n_len > nview.numel():
             raise RuntimeError("injected noise vector is shorter than the stream (needs 128*frames - 1 samples)")
-        noise_w = torch.empty((B, HOP * Tw), dtype=torch.float32, device=self.dev)
-        check(L.nws_fir_noise_window(ptr(fir_w), ptr(nview), int(n_len), int(origin), None, B, Tw, ptr(noise_w),
-                                     stream_ptr()), "nws_fir_noise_window")
+        noise_w = eng.fir_noise(fir_w, nview, origin=origin, noise_len=int(n_len))
         noise_new = noise_w if first else noise_w[:, HOP:]             # local hop 0 of a non-first window is not ours
         noise_all = torch.cat((self.noise_residue, noise_new), dim=1)
         cnt = hi - lo
@@ -154,11 +142,7 @@ class NewtStream:
         self.noise_residue = noise_all[:, cnt:].contiguous()
 
         # 5. linear reverb with carried tail
-        y = torch.empty_like(pre)
-        tin, tout = self.tails[self._tail_idx], self.tails[self._tail_idx ^ 1]
-        check(L.nws_reverb_linear_chunk(C.byref(self.plan), ptr(self.tables), ptr(self.spec), ptr(pre), B, cnt, ptr(tin),
-                                        ptr(tout), self.tail_len, ptr(y), ptr(self._rv_ws), self._rv_ws.numel() * 4,
-                                        stream_ptr()), "nws_reverb_linear_chunk")
+        y, self.tails[self._tail_idx ^ 1] = eng.reverb_linear_chunk(self._rv_aux, pre, self.tails[self._tail_idx])
         self._tail_idx ^= 1
 
         # 6. state for the next chunk

@@ -31,7 +31,7 @@ def test_loudness_matches_oracle(name):
     from oracle import loudness_oracle as lo
     audio, n_fft, hop = _cases()[name]
     ref = lo.extract_perceptual_loudness(audio, n_fft=n_fft, hop_length=hop)
-    got = extract_perceptual_loudness(audio.astype(np.float32), n_fft=n_fft, hop_length=hop)
+    got = extract_perceptual_loudness(audio.astype(np.float32), n_fft=n_fft, hop_length=hop, interpolate_fn=None)
     assert isinstance(got, np.ndarray) and got.shape == ref.shape == (1 + audio.size // hop,)
     err = float(np.abs(got - ref).max())
     record("loudness_" + name, max_abs_err_normalised=err, frames=int(ref.size))
@@ -57,6 +57,12 @@ def test_loudness_batched_tensor_api_interpolation_and_errors():
     up = extract_perceptual_loudness(x[0], n_fft=1024, hop_length=128, interpolate_fn=lo.linear_interpolation)
     ref_up = lo.extract_perceptual_loudness(x[0].astype(np.float64), n_fft=1024, hop_length=128, interpolate_fn=lo.linear_interpolation)
     assert up.shape == (8000,) and np.abs(up - ref_up).max() <= 2e-5
+    # the reference's DEFAULT is sample-rate loudness (interpolate_fn=linear_interpolation, loudness_extraction.py:49)
+    dflt = extract_perceptual_loudness(x[0], n_fft=1024, hop_length=128)
+    assert dflt.shape == (8000,) and np.abs(dflt - ref_up).max() <= 2e-5
+    # hop / n_fft pairs whose 31 hop + n_fft sample tile exceeds the 160 KB of LDS are refused with a clear message
+    with pytest.raises(RuntimeError, match="LDS"):
+        loudness_frames(torch.rand(1, 70000, device="cuda"), 2048, 2048)
     # throughput on the synthesis bench's shape (64 clips of 4 s) and on one 5-minute file
     big = torch.rand(64, 64000, device="cuda") - 0.5
     long1 = torch.rand(1, 16000 * 300, device="cuda") - 0.5

@@ -550,8 +550,10 @@ def test_errors_are_loud(models):
         m(torch.zeros(1, 1, 8, device="cuda"), torch.zeros(2, 2, 8, device="cuda"))
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 1, 8), torch.zeros(1, 2, 8))                                   # CPU tensors: no fallback
-    with pytest.raises(NotImplementedError):
-        m.embedding(torch.zeros(1, 2, 8, device="cuda"))
+    with pytest.raises(RuntimeError):
+        m.embedding(torch.zeros(1, 3, 8, device="cuda"))                                # GRU(2 -> 128): 2 input channels
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 1, 1, device="cuda"), torch.zeros(1, 2, 1, device="cuda"))     # one frame: reflect padding undefined
 
 
 def test_hipgraph_capture_replay(models):
