@@ -30,7 +30,15 @@ sys.path.insert(0, ROOT)
 @click.option("--batch-size", default=64)
 @click.option("--use-fastnewt", is_flag=True)
 @click.option("--write-targets", is_flag=True, help="also write <name>.target.wav when the dataset holds audio")
-def main(model_gin, model_checkpoint, dataset_root, dataset_split, output_path, batch_size, use_fastnewt, write_targets):
+@click.option("--seed", default=None, type=int,
+              help="seed the device generator the two hidden draws of forward() come from (phase offsets, noise excitation; "
+                   "reference generators.py:55,:30): batch k of a rank's shard draws from a generator seeded with seed + k, so "
+                   "a run is reproducible whatever the batch size of OTHER runs")
+@click.option("--draws", default=None, type=click.Path(exists=True),
+              help=".npz with `phase_u` (101,) and `noise` (>= 128*T-1,) used for EVERY batch (noise truncated to the batch's "
+                   "128*T-1 samples): renders become comparable with any other implementation fed the same two vectors")
+def main(model_gin, model_checkpoint, dataset_root, dataset_split, output_path, batch_size, use_fastnewt, write_targets, seed,
+         draws):
     nws = importlib.import_module("neural-waveshaping-synthesis_amd")
     ds_mod = importlib.import_module("neural-waveshaping-synthesis_amd.dataset")
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -47,6 +55,27 @@ def main(model_gin, model_checkpoint, dataset_root, dataset_split, output_path, 
         model.newt = nws.FastNEWT(model.newt)
     model = model.to(dev)
     mine = data.shard(rank, world)
+    fixed = None
+    if draws:
+        import numpy as np
+        z = np.load(draws)
+        fixed = (torch.from_numpy(np.ascontiguousarray(z["phase_u"], dtype=np.float32)).reshape(-1).to(dev),
+                 torch.from_numpy(np.ascontiguousarray(z["noise"], dtype=np.float32)).reshape(-1).to(dev))
+        if fixed[0].numel() != 101:
+            raise click.BadParameter("--draws: phase_u must hold 101 values")
+
+    def hidden_draws(k, T):
+        """(phase_u, noise) for batch k of T frames, or (None, None): forward() draws from the default generator itself"""
+        n = int(model.control_hop) * T - 1
+        if fixed is not None:
+            if fixed[1].numel() < n:
+                raise click.BadParameter(f"--draws: noise holds {fixed[1].numel()} samples, a batch of {T} frames needs {n}")
+            return fixed[0], fixed[1][:n].contiguous()
+        if seed is not None:
+            g = torch.Generator(device=dev).manual_seed(int(seed) + k)
+            return torch.rand(101, device=dev, generator=g), torch.rand(n, device=dev, generator=g)    # the reference's order
+        return None, None
+
     t0, n_samples = time.time(), 0
     sr = int(model.sample_rate)
     writes = []
@@ -62,10 +91,11 @@ def main(model_gin, model_checkpoint, dataset_root, dataset_split, output_path, 
 
     with torch.no_grad(), cf.ThreadPoolExecutor(max_workers=4) as pool:
         in_flight = None
-        for batch in data.batches(mine, batch_size):
+        for k, batch in enumerate(data.batches(mine, batch_size)):
             f0 = torch.from_numpy(batch["f0"]).to(dev, non_blocking=True)
             control = torch.from_numpy(batch["control"]).to(dev, non_blocking=True)
-            nxt = (model(f0, control), batch)      # asynchronous: only enqueues the kernels
+            pu, nz = hidden_draws(k, f0.shape[-1])
+            nxt = (model(f0, control, phase_u=pu, noise=nz), batch)      # asynchronous: only enqueues the kernels
             if in_flight is not None:
                 n_samples += collect(in_flight, pool)
             in_flight = nxt

@@ -317,6 +317,28 @@ def test_frame_mlps_fp32_fallback_kernel(models, oracle):
     assert rms(y - g["y_newt"]) <= 1e-4
 
 
+def test_fp16_mlp_guard_trips_on_real_weights(weights):
+    """Engine.fp16_mlp_safe with weights that really break the fp16 two-term split: the h_generator's last LayerNorm gain is
+    scaled so that its outputs (|gamma| sqrt(C-1) ~ 2e5) leave fp16 range.  The guard must pick the exact-fp32 kernel by
+    itself, and the result must match the oracle run on the SAME modified weights."""
+    from oracle.newt_oracle import OracleNEWT
+    w2 = {k: np.array(v, copy=True) for k, v in weights.items()}
+    w2["h_generator.net.7.layer_norm.weight"] = w2["h_generator.net.7.layer_norm.weight"] * 2.0e4
+    w2["h_generator.net.9.weight"] = w2["h_generator.net.9.weight"] / 2.0e4          # keep H (hence the audio) in a sane range
+    m = build_model(False)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in w2.items()})
+    m = m.cuda()
+    assert not m._engine.fp16_mlp_safe()                      # the guard itself, no monkey-patching
+    assert not m._engine.weights()[0].mlp_frags               # -> exact-fp32 MFMA kernel
+    assert build_model(False)._engine.weights()[0].mlp_frags  # the shipped weights take the fp16 path
+    g = load_npz("g1_realistic.npz")
+    ref = OracleNEWT(w2, fast=False)(g["f0"], g["control"], g["phase_u"], g["noise"]).numpy()
+    y = m(dev(g["f0"]), dev(g["control"]), phase_u=dev(g["phase_u"]), noise=dev(g["noise"])).cpu().numpy()
+    e = rms(y - ref)
+    record("fp16_mlp_guard_tripped", rms_err=e, out_rms=rms(ref))
+    assert e <= 1e-4, e
+
+
 def test_fir_noise_stage(models, oracle):
     m, _ = models
     g1 = load_npz("g1_realistic.npz")
@@ -675,8 +697,10 @@ def test_multi_stream_forwards_and_strided_inputs(models, oracle):
     assert rms(y2.cpu().numpy() - ref2) <= 1e-4
 
 
-def test_offline_render_cli(tmp_path):
-    """scripts/resynthesise_dataset.py on a tiny synthetic dataset: one wav per item, right length, finite."""
+def test_offline_render_cli(tmp_path, oracle):
+    """scripts/resynthesise_dataset.py (reference scripts/resynthesise_dataset.py:55-76) on a small synthetic dataset with
+    ragged lengths: every wav against the oracle on the same controls and the same injected draws (--draws), target wavs
+    (--write-targets), reproducibility of --seed."""
     import subprocess
     import sys
     from scipy.io import wavfile
@@ -685,22 +709,53 @@ def test_offline_render_cli(tmp_path):
 
     root = tmp_path / "data"
     (root / "test" / "control").mkdir(parents=True)
+    (root / "test" / "audio").mkdir(parents=True)
     w = load_npz("weights_vn.npz")
     mean, std = np.zeros((19, 1)), np.ones((19, 1))
     mean[:2, 0], std[:2, 0] = w["__data_mean__"], w["__data_std__"]
     np.save(root / "data_mean.npy", mean)
     np.save(root / "data_std.npy", std)
     rng = np.random.default_rng(1)
-    for i, T in enumerate([16, 16, 9, 16, 9]):
-        np.save(root / "test" / "control" / f"control_clip{i}.npy", rng.normal(size=(19, T)).astype(np.float32))
+    lengths = [16, 16, 9, 16, 9]
+    controls = {}
+    for i, T in enumerate(lengths):
+        c = rng.normal(size=(19, T)).astype(np.float32)
+        c[0] = 0.3 * c[0]                                   # F0 around the data mean (a few hundred Hz)
+        controls[f"clip{i}"] = c
+        np.save(root / "test" / "control" / f"control_clip{i}.npy", c)
+    target = (0.1 * rng.normal(size=16 * 128)).astype(np.float32)
+    np.save(root / "test" / "audio" / "audio_clip1.npy", target)
+    pu, nz = rng.random(101).astype(np.float32), rng.random(16 * 128 - 1).astype(np.float32)
+    np.savez(tmp_path / "draws.npz", phase_u=pu, noise=nz)
+    cli = [sys.executable, os.path.join(ROOT, "scripts", "resynthesise_dataset.py"), "--model-checkpoint",
+           os.path.join(ROOT, "tests", "golden", "weights_vn.npz"), "--dataset-root", str(root), "--use-fastnewt", "--batch-size", "2"]
     out = tmp_path / "wav"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "resynthesise_dataset.py"), "--model-checkpoint",
-                        os.path.join(ROOT, "tests", "golden", "weights_vn.npz"), "--dataset-root", str(root),
-                        "--output-path", str(out), "--use-fastnewt", "--batch-size", "2"], capture_output=True, text=True)
+    r = subprocess.run(cli + ["--output-path", str(out), "--draws", str(tmp_path / "draws.npz"), "--write-targets"],
+                       capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    for i, T in enumerate([16, 16, 9, 16, 9]):
-        sr, audio = wavfile.read(out / f"clip{i}.output.wav")
-        assert sr == 16000 and audio.shape == (128 * T,) and np.isfinite(audio).all() and np.abs(audio).max() > 0
+    worst = 0.0
+    for i, T in enumerate(lengths):
+        sr, y = wavfile.read(out / f"clip{i}.output.wav")
+        assert sr == 16000 and y.dtype == np.float32 and y.shape == (128 * T,)
+        c = controls[f"clip{i}"]
+        f0_hz = (c[0:1].astype(np.float64) * std[0, 0] + mean[0, 0]).astype(np.float32)        # general.py:49
+        ref = oracle[1](torch.from_numpy(f0_hz)[None], torch.from_numpy(c)[None], torch.from_numpy(pu),
+                        torch.from_numpy(nz[:128 * T - 1].copy())).numpy()[0]
+        e = rms(y - ref)
+        worst = max(worst, e)
+        assert e <= 1e-4, (i, e)
+    record("offline_render_cli", worst_rms_err_vs_oracle=worst, clips=len(lengths))
+    sr, tgt = wavfile.read(out / "clip1.target.wav")
+    assert np.array_equal(tgt, target) and not (out / "clip0.target.wav").exists()
+    # --seed: reproducible, and a different seed gives different hidden draws
+    runs = []
+    for tag, seed in (("a", 7), ("b", 7), ("c", 8)):
+        o = tmp_path / ("wav_" + tag)
+        r = subprocess.run(cli + ["--output-path", str(o), "--seed", str(seed)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs.append(np.concatenate([wavfile.read(o / f"clip{i}.output.wav")[1] for i in range(len(lengths))]))
+    assert np.array_equal(runs[0], runs[1]) and not np.array_equal(runs[0], runs[2])
+    assert np.isfinite(runs[2]).all() and np.abs(runs[2]).max() > 0
 
 
 def test_full_size_properties(models):
