@@ -68,7 +68,9 @@ def parse():
                          "live, the worst case for the oscillator); realistic: per-utterance F0 ~ U[100, 1000] Hz with 5.5 Hz "
                          "vibrato, control ~ N(0,1) (SURVEY 8(d) config 3)")
     ap.add_argument("--exciter-opts", type=int, default=None,
-                    help="NwsWeights.exciter_opts (include/nws_hip.h): 0 default, 1 round-1 VALU FiLM, 2 one-term fp16 sines")
+                    help="NwsWeights.exciter_opts (include/nws_hip.h): default auto (8 for the shipped checkpoints); 0 every "
+                         "product two-term, 1 round-1 VALU FiLM, 2 one-term sines everywhere, 4 one-term sines for harmonics >= 16, "
+                         "8 one-term sines AND weights for harmonics >= 16")
     ap.add_argument("--gather", choices=("rccl", "copy"), default="rccl",
                     help="N > 1: how the rendered waveforms are all-gathered: rccl = all_gather_into_tensor (RCCL kernels on the "
                          "CUs); copy = every rank pushes its shard into every peer's buffer with device-to-device copies on "
@@ -514,7 +516,12 @@ def main():
             pmc = None        # counters of another workload: not quoted
         st = extra.get("stage_ms", {})
         one_term = bool(opts & 2) and not a.exact
-        terms = 2 if one_term else 3
+        hybrid = bool(opts & (4 | 8)) and not one_term and not a.exact
+        # fp16 MFMAs per (M-tile, K-step): 3 with both operands two-term, 2 with one-term sines, 1 with one-term weights too;
+        # K-step 0 always 3 in the hybrid forms; 6 K-steps of 16 slots + one of 8
+        per_step = 2 if one_term else (2 if (opts & 4) else 1 if (opts & 8) else 3)
+        first = 2 if one_term else 3
+        terms = (first * 16 + per_step * (5 * 16 + 8)) / 112.0
         flops = FLOP_PER_SAMPLE_EXCITER_NEWT * B * N
         mfma_flop = exciter_mfma_flop_per_sample(terms, not (opts & 1) and not a.exact) * B * N
         dom = kernel_roofline("exciter_newt_kernel", pmc, k_ms, algo_flop=flops, mfma_flop=mfma_flop)
@@ -558,6 +565,11 @@ def main():
         elif one_term:
             dtype = ("f32 (frame MLPs, FIR noise: fp16x2-split MFMA contractions, fp32 accumulate; 101->64 mixer: weights fp16x2, "
                      "sines ONE fp16 term = 11-bit mixer inputs, fp32 accumulate)")
+        elif hybrid:
+            dtype = ("f32 (frame MLPs, FIR noise, mixer bias + harmonics 1..15: fp16x2-split MFMA contractions = 22-bit products, "
+                     "fp32 accumulate; mixer harmonics 16..101: " + ("fp16 x fp16" if opts & 8 else "fp16x2 weights x fp16 sines") +
+                     ", fp32 accumulate; FiLM interpolation bf16x3-split MFMA = exact fp32 operands; e2e 3e-7..3e-6 RMS vs the "
+                     "reference, bar 1e-4)")
         else:
             dtype = "f32 (fp16x2-split MFMA contractions = 22-bit products, fp32 accumulate; FiLM interpolation bf16x3-split MFMA = exact fp32 operands)"
         out = {

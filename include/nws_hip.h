@@ -106,6 +106,8 @@ typedef struct NwsWeights {
                                    checkpoints instead of ~3e-7 */
 #define NWS_EXCITER_HYBRID 4    /* two fp16 terms for the mixer bias + harmonics 1..15 (K-step 0: 61-85 % of the mixer's
                                    weight energy in the shipped checkpoints), one term for harmonics 16..101 */
+#define NWS_EXCITER_HYBRID_W 8  /* NWS_EXCITER_HYBRID plus: the mixer WEIGHTS of harmonics 16..101 as one fp16 term as well
+                                   (one MFMA per product there instead of two) */
 
 int nws_abi_version(void);
 /* sizeof of the C structs above as this library was compiled (0 NwsWeights, 1 NwsReverbPlan, 2 NwsForwardAux): lets a

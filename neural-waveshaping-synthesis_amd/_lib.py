@@ -15,6 +15,7 @@ ABI_VERSION = 2          # include/nws_hip.h NWS_ABI_VERSION
 EXCITER_VALU_FILM = 1    # NwsWeights.exciter_opts bits (include/nws_hip.h)
 EXCITER_ONE_TERM = 2
 EXCITER_HYBRID = 4
+EXCITER_HYBRID_W = 8
 N_HARMONICS = 101
 N_SHAPERS = 64
 HIDDEN = 128

@@ -37,6 +37,7 @@ enum Opt {
   kOptFilmMfma = 2,     // FiLM interpolation (3 parameter types x 64 shapers x 32 samples per wave) as six bf16 MFMAs
   kOptOneTerm = 4,      // sines as ONE fp16 term in EVERY K-step (drops W_hi * v_lo: 2 MFMAs per product; 11-bit activations)
   kOptHybrid = 8,       // two-term sines in K-step 0 (mixer bias + harmonics 1..15), one term in K-steps 1..6
+  kOptHybridW = 16,     // with kOptHybrid: the mixer WEIGHTS of harmonics 16..101 as one fp16 term too (1 MFMA per product)
   kOptPipelined = 8     // main loop software-pipelined: sines of K-step ks+1 beside the MFMAs of K-step ks
 };
 enum Mode { kModeLut = 0, kModeExact = 1, kModeExciterOnly = 2, kModeLutPairs = 3, kModeLutPairsDiv6 = 4, kModeExactBank = 5 };
@@ -378,6 +379,17 @@ struct ExcLds {
   float kf[kKPad];              // (float)c: harmonic numbers as packed-FMA operands, read instead of computed
 };
 
+// Where K slot kk of shaper s lives in the fragment tables (units: halfs).  K-steps 0..5 are v_mfma_f32_32x32x16_f16
+// fragments (lane (i, h) holds slots 16 ks + 8 h + 0..7); the remainder - slots 96..103: harmonics 96..101 and two zero
+// slots - is ONE v_mfma_f32_32x32x8_f16 step (lane (i, h) holds slots 96 + 4 h + 0..3, the first 8 bytes of a 16-byte
+// row); slots 104..111 do not exist, their table positions (the unused upper halves of those rows) are written as zeros.
+__host__ __device__ inline int mixer_frag_index(int s, int kk) {
+  const int m = s >> 5, i = s & 31;
+  if (kk < 96) return ((((kk >> 4) * 2 + m) * 2 + ((kk >> 3) & 1)) * 32 + i) * 8 + (kk & 7);
+  const int r = kk - 96;   // 0..15
+  return (((6 * 2 + m) * 2 + ((r >> 2) & 1)) * 32 + i) * 8 + (r & 3) + 4 * (r >> 3);
+}
+
 // harmonic_mixer as K-slot weights: slot 0 = bias, slots 1..101 = weight[:, c-1], padding slots = 0
 __device__ __forceinline__ float mixer_slot_weight(const float* __restrict__ mixer_w, const float* __restrict__ mixer_b, int s,
                                                    int c) {
@@ -534,8 +546,8 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
     for (int e = tid; e < kS * kKPad; e += kThreads) {
       const int s = e / kKPad, kk = e - s * kKPad;
       const float wv = mixer_slot_weight(w.mixer_w, w.mixer_b, s, kk);
-      const int frag = (((kk >> 4) * 2 + (s >> 5)) * 2 + ((kk >> 3) & 1)) * 32 + (s & 31);
-      split_f16(wv, whi[frag * 8 + (kk & 7)], wlo[frag * 8 + (kk & 7)]);
+      const int at = mixer_frag_index(s, kk);
+      split_f16(wv, whi[at], wlo[at]);
     }
   }
   // FiLM slots (one shaper per lane), bias sums, phase shifts and harmonic numbers, spread over the waves:
@@ -659,8 +671,12 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
   const bool small_args = __all(fabsf(phase) * (float)kKPad + 4.0f < 6.0e6f);
   // anti-alias mask (generators.py:50-52): harmonic k is live iff fl(f0*k) < sr/2.  fl(f0*k) is monotone in k for
   // f0 > 0, so the live set is a prefix 1..kmax; count it once per lane with the exact comparison.
+  // every harmonic of every sample of the wave below Nyquist (e.g. the timing script's sub-1 Hz "F0"): no masks, no counting
+  const bool all_live = __all((f0n * (float)kK) < nyquist);
   int kmax;
-  if (!(f0n > 0.0f)) {
+  if (all_live) {
+    kmax = kK;
+  } else if (!(f0n > 0.0f)) {
     kmax = f0n == f0n ? kK : 0;  // f0 <= 0: every product is <= 0 < sr/2;  NaN: nothing is live
   } else {
     // the quotient estimate is within one of the answer (both are small integers); settle it with the exact test
@@ -676,11 +692,25 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
   // one K-step; the first one starts the accumulators from the MFMA's inline-zero C operand (no 32 v_mov per wave)
   // how many fp16 terms the sines of K-step ks travel as (compile-time after unrolling): see Opt
   auto two_terms = [](const int ks) { return (OPT & kOptOneTerm) ? false : ((OPT & kOptHybrid) ? ks == 0 : true); };
+  // weights: W_hi and W_lo everywhere, or (kOptHybridW) W_lo in K-step 0 only
+  auto two_wterms = [](const int ks) { return (OPT & kOptHybridW) ? ks == 0 : true; };
+  // sines of one pair of K slots: arg = fl(fl(k*phase) + shift), the reference's own rounding chain, then sin
+  auto sine_pair = [&](const f32x2 kfp, const f32x2 shp) -> f32x2 {
+    if (DBG == 1) return kfp * ph2 + shp;
+    if (small_args && (OPT & kOptScalarSines)) {
+      // the same arithmetic, instruction for instruction, in scalar fp32 (-ffp-contract=off: k*phase and + shift round apart)
+      const float a0 = kfp.x * phase + shp.x, a1 = kfp.y * phase + shp.y;
+      return f32x2{sin_turns_fract(a0), sin_turns_fract(a1)};
+    }
+    if (small_args) return sin_turns2_fract(kfp * ph2 + shp);
+    const f32x2 arg2 = kfp * ph2 + shp;
+    return f32x2{nws_sin_wide(arg2.x), nws_sin_wide(arg2.y)};
+  };
   auto sines = [&](const int ks, auto first_tag, f16x8& vhi, f16x8& vlo) {
     constexpr bool kFirst = decltype(first_tag)::value;
     const int kk0 = 16 * ks + 8 * half;
     const int rem = kmax + 1 - kk0;    // this lane's live slots in the step: e < rem  (slot c = kk0 + e is live iff c <= kmax)
-    const bool full = __all(rem >= 8);
+    const bool full = all_live || __all(rem >= 8);
     const float4 sh0 = *reinterpret_cast<const float4*>(&L.shift[kk0]);
     const float4 sh1 = *reinterpret_cast<const float4*>(&L.shift[kk0 + 4]);
     const float4 kf0 = *reinterpret_cast<const float4*>(&L.kf[kk0]);
@@ -688,26 +718,8 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
     const f32x2 sh2[4] = {{sh0.x, sh0.y}, {sh0.z, sh0.w}, {sh1.x, sh1.y}, {sh1.z, sh1.w}};
     const f32x2 kf2[4] = {{kf0.x, kf0.y}, {kf0.z, kf0.w}, {kf1.x, kf1.y}, {kf1.z, kf1.w}};
     f32x2 v2[4];
-    if (DBG == 1) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) v2[p] = kf2[p] * ph2 + sh2[p];
-    } else if (small_args && (OPT & kOptScalarSines)) {
-      // the same arithmetic, instruction for instruction, in scalar fp32 (-ffp-contract=off: k*phase and + shift round apart)
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const float a0 = kf2[p].x * phase + sh2[p].x, a1 = kf2[p].y * phase + sh2[p].y;
-        v2[p] = f32x2{sin_turns_fract(a0), sin_turns_fract(a1)};
-      }
-    } else if (small_args) {
-#pragma unroll
-      for (int p = 0; p < 4; ++p) v2[p] = sin_turns2_fract(kf2[p] * ph2 + sh2[p]);  // fl(fl(k*phase) + shift): the reference's own rounding chain
-    } else {
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const f32x2 arg2 = kf2[p] * ph2 + sh2[p];
-        v2[p] = f32x2{nws_sin_wide(arg2.x), nws_sin_wide(arg2.y)};
-      }
-    }
+    for (int p = 0; p < 4; ++p) v2[p] = sine_pair(kf2[p], sh2[p]);
     if (!full) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
@@ -734,15 +746,59 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const f16x8 ahi = L.whi[(ks * 2 + m) * 64 + frag_lane];
-      const f16x8 alo = L.wlo[(ks * 2 + m) * 64 + frag_lane];
       f32x16& acc = m == 0 ? acc0 : acc1;
       if (DBG == 4) {
+        const f16x8 alo = L.wlo[(ks * 2 + m) * 64 + frag_lane];
         if (kFirst) acc = f32x16{};
         acc[ks] += (float)ahi[0] * (float)vhi[0] + (float)alo[1] * (float)vlo[1];
       } else {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, vhi, kFirst ? f32x16{} : acc, 0, 0, 0);
         if (two_terms(ks)) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, vlo, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, vhi, acc, 0, 0, 0);
+        if (two_wterms(ks)) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(L.wlo[(ks * 2 + m) * 64 + frag_lane], vhi, acc, 0, 0, 0);
+      }
+    }
+  };
+  // K-step 6 = slots 96..103 (harmonics 96..101): ONE K=8 MFMA per term instead of a K=16 one whose upper half would be
+  // padding - half the sines of a full step.  Lane (col, half) evaluates slots 96 + 4 half + 0..3.
+  auto last_step = [&] {
+    constexpr int ks = kKSteps - 1;
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    const int kk0 = 16 * ks + 4 * half;
+    const int rem = kmax + 1 - kk0;
+    const bool full = all_live || __all(rem >= 4);
+    const float4 sh = *reinterpret_cast<const float4*>(&L.shift[kk0]);
+    const float4 kf = *reinterpret_cast<const float4*>(&L.kf[kk0]);
+    f32x2 v2[2] = {sine_pair(f32x2{kf.x, kf.y}, f32x2{sh.x, sh.y}), sine_pair(f32x2{kf.z, kf.w}, f32x2{sh.z, sh.w})};
+    if (!full) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        v2[p].x = 2 * p < rem ? v2[p].x : 0.0f;
+        v2[p].y = 2 * p + 1 < rem ? v2[p].y : 0.0f;
+      }
+    }
+    f16x4 vhi, vlo;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const f16x2 h2 = __builtin_convertvector(v2[p], f16x2);
+      vhi[2 * p] = h2.x;
+      vhi[2 * p + 1] = h2.y;
+      if (two_terms(ks)) {
+        const f16x2 l2 = split_lo2(h2, v2[p]);
+        vlo[2 * p] = l2.x;
+        vlo[2 * p + 1] = l2.y;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const f16x4 ahi = *reinterpret_cast<const f16x4*>(&L.whi[(ks * 2 + m) * 64 + frag_lane]);   // first 8 bytes of the row
+      f32x16& acc = m == 0 ? acc0 : acc1;
+      if (DBG == 4) {
+        acc[ks] += (float)ahi[0] * (float)vhi[0];
+      } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x8f16(ahi, vhi, acc, 0, 0, 0);
+        if (two_terms(ks)) acc = __builtin_amdgcn_mfma_f32_32x32x8f16(ahi, vlo, acc, 0, 0, 0);
+        if (two_wterms(ks))
+          acc = __builtin_amdgcn_mfma_f32_32x32x8f16(*reinterpret_cast<const f16x4*>(&L.wlo[(ks * 2 + m) * 64 + frag_lane]), vhi, acc, 0, 0, 0);
       }
     }
   };
@@ -755,11 +811,16 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
       mix(ks, first_tag, vhi, vlo);
     };
     kstep(0, std::true_type{});
+    bool more = true;
 #pragma unroll
-    for (int ks = 1; ks < kKSteps; ++ks) {
-      if (!__any(kmax + 1 - (16 * ks + 8 * half) > 0)) break;
+    for (int ks = 1; ks < kKSteps - 1; ++ks) {
+      if (!all_live && !__any(kmax + 1 - (16 * ks + 8 * half) > 0)) {
+        more = false;
+        break;
+      }
       kstep(ks, std::false_type{});
     }
+    if (more && (all_live || __any(kmax + 1 - (16 * (kKSteps - 1) + 4 * half) > 0))) last_step();
   }
 
   // accumulator element r of M-tile m: shaper 32m + (r&3) + 8(r>>2) + 4*half, sample `col`
@@ -1057,11 +1118,11 @@ __global__ void mixer_frags_kernel(const float* __restrict__ mixer_w, const floa
   if (e >= kS * kKPad) return;
   const int s = e / kKPad, kk = e - s * kKPad;
   const float wv = mixer_slot_weight(mixer_w, mixer_b, s, kk);
-  const int frag = (((kk >> 4) * 2 + (s >> 5)) * 2 + ((kk >> 3) & 1)) * 32 + (s & 31);
+  const int at = mixer_frag_index(s, kk);
   _Float16 h, l;
   split_f16(wv, h, l);
-  out[frag * 8 + (kk & 7)] = h;
-  out[kKSteps * 2 * 2 * 32 * 8 + frag * 8 + (kk & 7)] = l;
+  out[at] = h;
+  out[kKSteps * 2 * 2 * 32 * 8 + at] = l;
 }
 
 __global__ void lut_pairs_kernel(const float* __restrict__ table, int size, float2* __restrict__ pairs) {
@@ -1225,6 +1286,7 @@ int nws_exciter_newt(const NwsWeights* w, const float* f0, const float* f0_up, c
             *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out)
         if (opts & NWS_EXCITER_VALU_FILM) NWS_HOT(0);
         else if (opts & NWS_EXCITER_ONE_TERM) NWS_HOT(kOptFilmMfma | kOptOneTerm);
+        else if (opts & NWS_EXCITER_HYBRID_W) NWS_HOT(kOptFilmMfma | kOptHybrid | kOptHybridW);
         else if (opts & NWS_EXCITER_HYBRID) NWS_HOT(kOptFilmMfma | kOptHybrid);
         else NWS_HOT(kOptFilmMfma);
 #undef NWS_HOT
@@ -1266,6 +1328,7 @@ int nws_debug_exciter_newt(int variant, const NwsWeights* w, const float* f0, co
       case 2: NWS_OPT_LAUNCH(2); break;
       case 6: NWS_OPT_LAUNCH(6); break;
       case 10: NWS_OPT_LAUNCH(10); break;
+      case 26: NWS_OPT_LAUNCH(26); break;
       default: return NWS_ERR_BAD_ARG;
     }
     NWS_CHECK_LAUNCH();

@@ -271,11 +271,12 @@ class Engine:
 
     def exciter_opts(self) -> int:
         """NwsWeights.exciter_opts.  `model.exciter_opts` if set, else the NWS_EXCITER_OPTS environment variable, else
-        "auto": the sines of harmonics 16..101 travel as ONE fp16 term (EXCITER_HYBRID: 2 instead of 3 MFMAs per product
-        there, no residual split) when the mixer bias + harmonics 1..15 hold at least 55 % of the harmonic mixer's weight
-        energy - true for the three shipped checkpoints (61 / 67 / 85 %), where it costs 2e-7 .. 2e-6 RMS end to end
-        (tests/test_gpu_parity.py holds it to 1e-5 on every golden vector; the bar is 1e-4); otherwise (e.g. random
-        initialisation) every sine keeps two terms."""
+        "auto": when the mixer bias + harmonics 1..15 hold at least 55 % of the harmonic mixer's weight energy - true for the
+        three shipped checkpoints (61 / 67 / 85 %) - only THAT part of the 101 -> 64 contraction keeps the two-term fp16
+        split of both operands (22-bit products); harmonics 16..101 run as plain fp16 x fp16 with fp32 accumulation
+        (EXCITER_HYBRID_W: 1 instead of 3 MFMAs per product there, no residual split of those sines).  Cost on the golden
+        vectors: 3e-7 .. 3e-6 RMS end to end instead of 2-6e-7 (tests/test_gpu_parity.py holds it to 1e-5, a tenth of the
+        1e-4 bar); otherwise (e.g. random initialisation) every product keeps both terms."""
         v = getattr(self._model_ref, "exciter_opts", None)
         if v is None:
             v = os.environ.get("NWS_EXCITER_OPTS")
@@ -284,7 +285,7 @@ class Engine:
         with torch.no_grad():
             e = self._model_ref.harmonic_mixer.weight.detach().float().pow(2).sum(dim=(0, 2))     # per harmonic
             share = float(e[:15].sum() / e.sum().clamp_min(1e-30))
-        return _lib.EXCITER_HYBRID if share >= 0.55 else 0
+        return _lib.EXCITER_HYBRID_W if share >= 0.55 else 0
 
     def fp16_mlp_safe(self, limit: float = 3.0e4) -> bool:
         """Worst-case magnitude of every frame-MLP layer input, from weight norms (one-time host check).

@@ -107,6 +107,13 @@ class ForwardPipeline:
             nz = _req(nz, "noise", m.control_hop * T - 1)
             self.eng.forward_control(f0, control, slot.ws, batched_gru=batched)
             slot.ev_control.record(cs)
+            # the draws were allocated on THIS control stream but are consumed on the audio stream: tell the caching
+            # allocator, or a later torch.rand on another control stream could be handed the block while the audio half of
+            # this batch still reads it (control_streams > 1 with a depth that is not a multiple of it)
+            if phase_u is None:
+                pu.record_stream(au)
+            if noise is None:
+                nz.record_stream(au)
         with torch.cuda.stream(au):
             au.wait_event(ready)
             au.wait_event(slot.ev_control)

@@ -470,8 +470,8 @@ def test_e2e_g7_other_instruments(inst):
     fast.newt = nws.FastNEWT(fast.newt)
     g = load_npz(f"g7_{inst}.npz")
     _e2e((exact, fast), None, g, g, f"g7_{inst}")
-    assert fast._engine.exciter_opts() == 4          # shipped checkpoints: the automatic choice is the hybrid
-    for opts, tag, tol in ((0, "two_term", 2e-6), (4, "hybrid", 1e-5), (2, "one_term", 1e-4), (1, "valu_film", 2e-6)):
+    assert fast._engine.exciter_opts() == 8          # shipped checkpoints: the automatic choice is the hybrid
+    for opts, tag, tol in ((0, "two_term", 2e-6), (4, "hybrid", 1e-5), (8, "hybrid_w", 1e-5), (2, "one_term", 1e-4), (1, "valu_film", 2e-6)):
         fast.exciter_opts = opts
         fast.invalidate_cache()
         y = fast(dev(g["f0"]), dev(g["control"]), phase_u=dev(g["phase_u"]), noise=dev(g["noise"])).cpu().numpy()
@@ -489,7 +489,8 @@ def test_exciter_options_on_golden_vectors(models):
     try:
         for name in ("g1_realistic", "g2_rand", "g6_highf0"):
             g = load_npz(name + ".npz")
-            for opts, tag, tol in ((0, "two_term", 2e-6), (1, "valu_film", 2e-6), (4, "hybrid", 1e-5), (2, "one_term", 1e-4)):
+            for opts, tag, tol in ((0, "two_term", 2e-6), (1, "valu_film", 2e-6), (4, "hybrid", 1e-5), (8, "hybrid_w", 1e-5),
+                                   (2, "one_term", 1e-4)):
                 fast.exciter_opts = opts
                 fast.invalidate_cache()
                 y = fast(dev(g["f0"]), dev(g["control"]), phase_u=dev(d["phase_u"]), noise=dev(d["noise"])).cpu().numpy()

@@ -16,7 +16,7 @@ nws.ensure_default_config()
 m = nws.NeuralWaveshaping.load_from_checkpoint(os.path.join(ROOT, "tests/golden/weights_vn.npz")).cuda().eval()
 m.newt = nws.FastNEWT(m.newt)
 B, T = int(os.environ.get("B", 64)), int(os.environ.get("T", 500))
-variants = [int(v) for v in os.environ.get("VARIANTS", "10,12,16,20").split(",")]
+variants = [int(v) for v in os.environ.get("VARIANTS", "12,20,36").split(",")]
 eng = m._engine
 w, _, _ = eng.weights()
 for kind in ("rand", "real"):
