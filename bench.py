@@ -87,10 +87,10 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=1,
                     help="1: ForwardPipeline (control half = carries + GRU of batch i+1 on a side stream under the audio "
                          "half of batch i, --streams audio streams); 0: whole forwards round-robin on --streams streams")
-    ap.add_argument("--control-streams", type=int, default=1,
-                    help="side streams for the control half (two change nothing for rand inputs, help the GRU-bound realistic-"
-                         "input case by 7 %% (0.392 -> 0.364 ms/step) and hurt beside RCCL: 0.62 vs 0.48 ms/step with the "
-                         "all-gather in the loop)")
+    ap.add_argument("--control-streams", type=int, default=0,
+                    help="side streams for the control half; 0 = auto: two on one GPU (two recurrences in flight: 0.407 -> 0.401 "
+                         "ms/step for the timing-script inputs, 0.383 -> 0.349 for realistic ones, where the GRU is the longer "
+                         "half), one beside RCCL's own streams (two measured slower there: 0.62 vs 0.48 ms/step in round 1)")
     ap.add_argument("--gru", choices=("batched", "per-utterance"), default="per-utterance",
                     help="GRU kernel of the pipeline's control half (the plain forward always uses per-utterance)")
     return ap.parse_args()
@@ -278,8 +278,9 @@ def main():
     pipe = None
     if use_pipe:
         pmod = importlib.import_module("neural-waveshaping-synthesis_amd.pipeline")
+        n_control = a.control_streams if a.control_streams > 0 else (1 if distributed else 2)
         pipe = pmod.ForwardPipeline(model, depth=a.depth if a.depth > 0 else len(streams) + 2,
-                                    audio_streams=len(streams), control_streams=max(1, a.control_streams), batched_gru=a.gru == "batched")
+                                    audio_streams=len(streams), control_streams=n_control, batched_gru=a.gru == "batched")
         streams = pipe.audio
     nbuf = len(pipe.slots) if use_pipe else len(streams)
     full, peer = None, None
