@@ -14,7 +14,8 @@ from collections import defaultdict
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"\(.*", "", name)
-    return re.sub(r"^void ", "", name)[:24]
+    name = re.sub(r"^void ", "", name)
+    return name[:40] if name.startswith("exciter_newt_kernel<") else name[:24]
 
 
 def counters(root, sub):
@@ -56,6 +57,13 @@ def main(root):
         for r in csv.DictReader(open(path)):
             stats[short(r["Name"])] = float(r["AverageNs"])
     kernels = {}
+    opt_bits = None
+    for k in out:
+        mm = re.match(r"exciter_newt_kernel<4, 0, 2, (\d+)", k)
+        if mm:
+            opt_bits = int(mm.group(1))
+    # template OPT bits of the hot-path kernel -> NwsWeights.exciter_opts value that selects it (csrc/exciter_newt.hip)
+    eff_opts = None if opt_bits is None else (8 if opt_bits & 16 else 4 if opt_bits & 8 else 2 if opt_bits & 4 else 0 if opt_bits & 2 else 1)
     for k, m in out.items():
         w = m.get("SQ_WAVES", 0) or 1
         name = re.sub(r"<.*", "", k)
@@ -73,12 +81,14 @@ def main(root):
         if ns and gui:
             if gui / ns > 4.0:
                 gui /= 8.0
-            e.update(kernel_avg_ns_one_stream=ns, kernel_cycles=gui, clock_ghz_during_pass=gui / ns,
-                     valu_busy_frac=w * e["valu_active_quad_cycles_per_wave"] * 4.0 / (1024.0 * gui))
+            e.update(kernel_avg_ns_one_stream=ns)
+            if 1.0 <= gui / ns <= 2.6:       # a plausible shader clock: GRBM_GUI_ACTIVE of short kernels includes idle gaps
+                e.update(kernel_cycles=gui, clock_ghz_during_pass=gui / ns,
+                         valu_busy_frac=w * e["valu_active_quad_cycles_per_wave"] * 4.0 / (1024.0 * gui))
         kernels[name] = e
     json.dump({"source": "rocprofv3 --pmc, separate passes, one stream, whole forwards (tools/collect_profiles.sh, tools/pmc_digest.py)",
                "batch_per_gpu": int(os.environ.get("NWS_PROFILE_BATCH", 64)), "frames": int(os.environ.get("NWS_PROFILE_FRAMES", 500)),
-               "exciter_opts": int(os.environ.get("NWS_EXCITER_OPTS", 0)),
+               "exciter_opts": eff_opts if eff_opts is not None else int(os.environ.get("NWS_EXCITER_OPTS", 0)),
                "correction": "FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md HBM "
                              "section); WRITE_SIZE as reported", "kernels": kernels},
               open(os.path.join(root, "pmc_kernels.json"), "w"), indent=1)
