@@ -532,7 +532,8 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
       __builtin_amdgcn_global_load_lds((gptr_t)(src + 4096), (lptr_t)(dst + 4096), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)(src + 4096), (lptr_t)(dst + 4096), 16, 1024, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)(src + 4096), (lptr_t)(dst + 4096), 16, 2048, 0);
-    } else if (wave < 7) {
+    } else if (wave < ((OPT & kOptHybridW) ? 4 : 7)) {
+      // (kOptHybridW reads W_hi and the K-step-0 part of W_lo only: the first 16 of the 28 KB)
       const char* src = static_cast<const char*>(w.mixer_frags) + wave * 4096 + lane * 16;
       char* dst = reinterpret_cast<char*>(L.whi) + wave * 4096;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
@@ -662,6 +663,10 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (!hop_live) return;
+  if (DBG == 5) {   // prologue only (timing): what staging + phase + the barrier cost per launch
+    if (half == 0) newt_out[(size_t)b * N + n] = phase + L.shift[lane] + L.bsum[0];
+    return;
+  }
 
   // ---- 101 harmonics -> 64 shapers on the matrix cores (fp16 two-term split, fp32 accumulate) ----
   // K-step ks covers harmonics 16ks+1 .. 16ks+16; lane (col, half) evaluates the 8 sines of harmonics
@@ -1326,6 +1331,12 @@ int nws_debug_exciter_newt(int variant, const NwsWeights* w, const float* f0, co
 #define NWS_OPT_LAUNCH(O)                                                                                          \
   exciter_newt_kernel<kModeLutPairsDiv6, 0, 2, O><<<dim3((T + 1) / 2, B), 512, base, st>>>(*w, f0, nullptr, carry, phase_u, \
                                                             rand_phase, film, T, sample_rate, nullptr, newt_out)
+  if (variant == 5) {   // prologue only, product configuration
+    exciter_newt_kernel<kModeLutPairsDiv6, 5, 2, kOptFilmMfma | kOptHybrid | kOptHybridW><<<dim3((T + 1) / 2, B), 512, base, st>>>(
+        *w, f0, nullptr, carry, phase_u, rand_phase, film, T, sample_rate, nullptr, newt_out);
+    NWS_CHECK_LAUNCH();
+    return NWS_OK;
+  }
   if (variant >= 10) {   // 10 + OPT bits: the product kernel's compile-time options (two hops per workgroup)
     switch (variant - 10) {
       case 0: NWS_OPT_LAUNCH(0); break;
