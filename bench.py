@@ -91,6 +91,9 @@ def parse():
                     help="side streams for the control half; 0 = auto: two on one GPU (two recurrences in flight: 0.407 -> 0.401 "
                          "ms/step for the timing-script inputs, 0.383 -> 0.349 for realistic ones, where the GRU is the longer "
                          "half), one beside RCCL's own streams (two measured slower there: 0.62 vs 0.48 ms/step in round 1)")
+    ap.add_argument("--chain-exciters", type=int, default=0,
+                    help="1: the oscillator kernels of neighbouring batches (two audio streams) run one after the other, the other "
+                         "kernels overlap them (ForwardPipeline chain_exciters; measured: no difference, 0.3919 vs 0.3932 ms/step)")
     ap.add_argument("--gru", choices=("batched", "per-utterance"), default="per-utterance",
                     help="GRU kernel of the pipeline's control half (the plain forward always uses per-utterance)")
     return ap.parse_args()
@@ -280,7 +283,8 @@ def main():
         pmod = importlib.import_module("neural-waveshaping-synthesis_amd.pipeline")
         n_control = a.control_streams if a.control_streams > 0 else (1 if distributed else 2)
         pipe = pmod.ForwardPipeline(model, depth=a.depth if a.depth > 0 else len(streams) + 2,
-                                    audio_streams=len(streams), control_streams=n_control, batched_gru=a.gru == "batched")
+                                    audio_streams=len(streams), control_streams=n_control, batched_gru=a.gru == "batched",
+                                    chain_exciters=bool(a.chain_exciters))
         streams = pipe.audio
     nbuf = len(pipe.slots) if use_pipe else len(streams)
     full, peer = None, None

@@ -303,6 +303,14 @@ int nws_forward_audio(const NwsWeights* w, const NwsForwardAux* aux, const float
                       const float* phase_u, const float* rand_phase, const float* noise, float* out, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* nws_forward_audio with two optional hipEvent_t hooks around the oscillator + waveshaper kernel (NULL = none): the stream
+ * waits for `wait_before_exciter` right before that kernel and records `record_after_exciter` right after it.  A pipeline
+ * that alternates batches over several streams chains them so that the VALU-saturated kernels of neighbouring batches run
+ * one after the other while their matrix / memory kernels (frame MLPs, noise, reverb) overlap it (pipeline.py). */
+int nws_forward_audio_ev(const NwsWeights* w, const NwsForwardAux* aux, const float* f0, int B, int T, float sample_rate,
+                         const float* phase_u, const float* rand_phase, const float* noise, float* out, void* workspace,
+                         size_t workspace_bytes, void* stream, void* wait_before_exciter, void* record_after_exciter);
+
 /*
  * Perceptual-loudness feature, the step before the synthesis path:
  * neural_waveshaping_synthesis/data/utils/loudness_extraction.py:10-67 (extract_perceptual_loudness) with the shipped

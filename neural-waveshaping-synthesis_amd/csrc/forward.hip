@@ -117,12 +117,21 @@ int control_half(const NwsWeights* w, const float* f0, const float* control, int
 }
 
 int audio_half(const NwsWeights* w, const NwsForwardAux* aux, const float* f0, int B, int T, float sample_rate,
-               const float* phase_u, const float* rand_phase, const float* noise, float* out, const Arena& a, void* stream) {
+               const float* phase_u, const float* rand_phase, const float* noise, float* out, const Arena& a, void* stream,
+               void* wait_before_exciter = nullptr, void* record_after_exciter = nullptr) {
   hipStream_t st = (hipStream_t)stream;
   int rc = NWS_OK;
   const size_t N = (size_t)T * NWS_HOP;
   NWS_STAGE(2, nws_frame_mlps(w, a.gru_out, aux->fir_design, B, T, nullptr, a.film, nullptr, a.fir, stream));
+  if (wait_before_exciter != nullptr) {
+    const hipError_t e = hipStreamWaitEvent(st, (hipEvent_t)wait_before_exciter, 0);
+    if (e != hipSuccess) return (int)e;
+  }
   NWS_STAGE(3, nws_exciter_newt(w, f0, nullptr, a.carry, phase_u, rand_phase, a.film, B, T, sample_rate, nullptr, a.newt_out, stream));
+  if (record_after_exciter != nullptr) {
+    const hipError_t e = hipEventRecord((hipEvent_t)record_after_exciter, st);
+    if (e != hipSuccess) return (int)e;
+  }
   NWS_STAGE(4, nws_fir_noise(a.fir, noise, a.newt_out, B, T, a.pre, stream));
   NWS_STAGE(5, nws_reverb(aux->plan, aux->reverb_tables, aux->reverb_spectrum, a.pre, B, (int)N, out, a.rv_ws, a.rv_bytes, stream));
   if (g_prof.ev != nullptr && g_prof.used < g_prof.slots) ++g_prof.used;
@@ -187,6 +196,19 @@ int nws_forward_audio(const NwsWeights* w, const NwsForwardAux* aux, const float
   const Arena a = carve_arena(aux->plan, workspace, workspace_bytes, B, T, false);
   if (!a.ok) return NWS_ERR_WORKSPACE;
   return audio_half(w, aux, f0, B, T, sample_rate, phase_u, rand_phase, noise, out, a, stream);
+}
+
+int nws_forward_audio_ev(const NwsWeights* w, const NwsForwardAux* aux, const float* f0, int B, int T, float sample_rate,
+                         const float* phase_u, const float* rand_phase, const float* noise, float* out, void* workspace,
+                         size_t workspace_bytes, void* stream, void* wait_before_exciter, void* record_after_exciter) {
+  if (!w || !aux_ok(aux)) return NWS_ERR_BAD_ARG;
+  if (!f0 || !phase_u || !rand_phase || !noise || !out || !workspace) return NWS_ERR_BAD_ARG;
+  if (B <= 0 || T < 2) return NWS_ERR_BAD_ARG;
+  if ((long long)T * NWS_HOP > aux->plan->L) return NWS_ERR_BAD_ARG;
+  const Arena a = carve_arena(aux->plan, workspace, workspace_bytes, B, T, false);
+  if (!a.ok) return NWS_ERR_WORKSPACE;
+  return audio_half(w, aux, f0, B, T, sample_rate, phase_u, rand_phase, noise, out, a, stream, wait_before_exciter,
+                    record_after_exciter);
 }
 
 int nws_profile_begin(int slots, unsigned stage_mask) {

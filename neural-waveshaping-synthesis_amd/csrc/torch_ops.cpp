@@ -140,7 +140,7 @@ void forward_control(const Tensor& wdesc, const Tensor& f0, const Tensor& contro
 
 Tensor forward_audio(const Tensor& wdesc, const Tensor& f0, const Tensor& phase_u, const Tensor& rand_phase, const Tensor& noise,
                      const Tensor& fir_design, const Tensor& plan, const Tensor& reverb_tables, const Tensor& reverb_spectrum,
-                     Tensor& workspace, double sample_rate, const OptTensor& out_opt) {
+                     Tensor& workspace, double sample_rate, const OptTensor& out_opt, int64_t wait_event, int64_t record_event) {
   const NwsWeights* w = weights_of(wdesc);
   check_dev(f0, "f0");
   TORCH_CHECK(f0.dim() == 3 && f0.size(1) == 1 && f0.size(2) >= 2, "f0: expected (B, 1, T>=2), got ", f0.sizes());
@@ -159,9 +159,11 @@ Tensor forward_audio(const Tensor& wdesc, const Tensor& f0, const Tensor& phase_
   } else {
     out = at::empty({B, T * NWS_HOP}, f0.options());
   }
-  nws_check(nws_forward_audio(w, &a.aux, f0.data_ptr<float>(), (int)B, (int)T, (float)sample_rate, phase_u.data_ptr<float>(),
-                              rand_phase.data_ptr<float>(), noise.data_ptr<float>(), out.data_ptr<float>(), workspace.data_ptr(),
-                              (size_t)workspace.numel(), L.stream),
+  // wait_event / record_event: raw hipEvent_t handles (torch.cuda.Event.cuda_event) or 0, see nws_forward_audio_ev
+  nws_check(nws_forward_audio_ev(w, &a.aux, f0.data_ptr<float>(), (int)B, (int)T, (float)sample_rate, phase_u.data_ptr<float>(),
+                                 rand_phase.data_ptr<float>(), noise.data_ptr<float>(), out.data_ptr<float>(), workspace.data_ptr(),
+                                 (size_t)workspace.numel(), L.stream, reinterpret_cast<void*>(wait_event),
+                                 reinterpret_cast<void*>(record_event)),
             "nws_forward_audio");
   return out;
 }
@@ -517,7 +519,8 @@ TORCH_LIBRARY(newt_hip, m) {
         "Tensor plan, Tensor reverb_tables, Tensor reverb_spectrum, Tensor(a!) workspace, float sample_rate) -> Tensor", &forward);
   m.def("forward_control(Tensor wdesc, Tensor f0, Tensor control, Tensor(a!) workspace, bool batched_gru) -> ()", &forward_control);
   m.def("forward_audio(Tensor wdesc, Tensor f0, Tensor phase_u, Tensor rand_phase, Tensor noise, Tensor fir_design, Tensor plan, "
-        "Tensor reverb_tables, Tensor reverb_spectrum, Tensor(a!) workspace, float sample_rate, Tensor? out) -> Tensor", &forward_audio);
+        "Tensor reverb_tables, Tensor reverb_spectrum, Tensor(a!) workspace, float sample_rate, Tensor? out, int wait_event, "
+        "int record_event) -> Tensor", &forward_audio);
   m.def("phase_carry(Tensor? f0, Tensor? f0_up) -> Tensor", &phase_carry);
   m.def("exciter_newt(Tensor wdesc, Tensor? f0, Tensor? f0_up, Tensor carry, Tensor phase_u, Tensor rand_phase, Tensor? film, "
         "float sample_rate, bool want_exciter, bool want_newt) -> (Tensor, Tensor)", &exciter_newt);

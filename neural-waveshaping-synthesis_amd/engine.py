@@ -518,8 +518,9 @@ class Engine:
             check(_lib.lib().nws_forward_control(C.byref(w), ptr(f0), ptr(control), B, Cc, T, 1 if batched_gru else 0, ptr(ws),
                                                  ws.numel(), stream_ptr(dev)), "nws_forward_control")
 
-    def forward_audio(self, f0, B, T, phase_u, noise, ws, out=None):
-        """frame MLPs .. reverb from the head of `ws` (forward_control must have completed in stream order / by event)"""
+    def forward_audio(self, f0, B, T, phase_u, noise, ws, out=None, wait_event=None, record_event=None):
+        """frame MLPs .. reverb from the head of `ws` (forward_control must have completed in stream order / by event).
+        wait_event / record_event: torch.cuda.Event hooks right before / after the oscillator kernel (nws_forward_audio_ev)"""
         w, _, dev, wdesc = self._wd()
         same_device(dev, f0=f0, phase_u=phase_u, noise=noise, workspace=ws, out=out)
         N = T * _lib.HOP
@@ -527,7 +528,9 @@ class Engine:
         sr = float(self._model_ref.sample_rate)
         o = ops()
         if o is not None:
-            return o.forward_audio(wdesc, f0, phase_u, self._w[1][-2], noise, self._fir_design, plan_t, tables, spec, ws, sr, out)
+            return o.forward_audio(wdesc, f0, phase_u, self._w[1][-2], noise, self._fir_design, plan_t, tables, spec, ws, sr, out,
+                                   wait_event.cuda_event if wait_event is not None else 0,
+                                   record_event.cuda_event if record_event is not None else 0)
         with torch.cuda.device(dev):
             if out is None:
                 out = torch.empty((B, N), dtype=torch.float32, device=dev)
@@ -536,8 +539,11 @@ class Engine:
             aux.plan = C.pointer(plan)
             aux.reverb_tables = ptr(tables)
             aux.reverb_spectrum = ptr(spec)
-            check(_lib.lib().nws_forward_audio(C.byref(w), C.byref(aux), ptr(f0), B, T, sr, ptr(phase_u), ptr(self._w[1][-2]),
-                                               ptr(noise), ptr(out), ptr(ws), ws.numel(), stream_ptr(dev)), "nws_forward_audio")
+            check(_lib.lib().nws_forward_audio_ev(C.byref(w), C.byref(aux), ptr(f0), B, T, sr, ptr(phase_u), ptr(self._w[1][-2]),
+                                                  ptr(noise), ptr(out), ptr(ws), ws.numel(), stream_ptr(dev),
+                                                  wait_event.cuda_event if wait_event is not None else None,
+                                                  record_event.cuda_event if record_event is not None else None),
+                  "nws_forward_audio_ev")
         return out
 
     # ---- the whole forward: ONE op / ONE C-ABI call --------------------------------------------------------

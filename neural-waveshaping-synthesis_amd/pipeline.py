@@ -37,18 +37,20 @@ from .engine import _req
 
 
 class _Slot:
-    __slots__ = ("ws", "ev_control", "ev_audio", "used", "keep")
+    __slots__ = ("ws", "ev_control", "ev_audio", "ev_exciter", "used", "keep")
 
     def __init__(self):
         self.ws = None
         self.ev_control = torch.cuda.Event()
         self.ev_audio = torch.cuda.Event()
+        self.ev_exciter = torch.cuda.Event()       # recorded right after this batch's oscillator + waveshaper kernel
         self.used = False
         self.keep = None
 
 
 class ForwardPipeline:
-    def __init__(self, model, depth: int = 4, audio_streams: int = 2, control_streams: int = 1, batched_gru: bool = False):
+    def __init__(self, model, depth: int = 4, audio_streams: int = 2, control_streams: int = 1, batched_gru: bool = False,
+                 chain_exciters: bool = False):
         if depth < 2 or audio_streams < 1 or control_streams < 1:
             raise ValueError("need depth >= 2 and at least one stream of each kind")
         self.model = model
@@ -61,6 +63,13 @@ class ForwardPipeline:
         self.control = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(control_streams)]
         self.slots = [_Slot() for _ in range(depth)]
         self.batched_gru = batched_gru
+        # The oscillator + waveshaper kernel saturates vector issue on every CU: two of them side by side (the audio halves
+        # of neighbouring batches on two streams) only stretch each other, while the matrix / memory kernels of the OTHER
+        # batch (frame MLPs before it, noise and reverb after it) fill the gaps it leaves.  With chain_exciters the oscillator
+        # kernel of batch i+1 waits (stream-side, nws_forward_audio_ev) for the one of batch i.  Measured: no difference
+        # (0.3919 vs 0.3932 ms/step) - the chip is work-bound, co-running kernels just share it - hence off by default.
+        self.chain_exciters = bool(chain_exciters) and audio_streams > 1
+        self._last_exciter = None
         self._n = 0
         self._shape = None
         self._outstanding = []
@@ -117,7 +126,12 @@ class ForwardPipeline:
         with torch.cuda.stream(au):
             au.wait_event(ready)
             au.wait_event(slot.ev_control)
-            out = self.eng.forward_audio(f0, B, T, pu, nz, slot.ws, out=out)
+            if self.chain_exciters:
+                out = self.eng.forward_audio(f0, B, T, pu, nz, slot.ws, out=out, wait_event=self._last_exciter,
+                                             record_event=slot.ev_exciter)
+                self._last_exciter = slot.ev_exciter
+            else:
+                out = self.eng.forward_audio(f0, B, T, pu, nz, slot.ws, out=out)
             slot.ev_audio.record(au)
         slot.used = True
         slot.keep = (f0, control, pu, nz)        # inputs stay alive until the slot is reused
