@@ -541,6 +541,10 @@ def main():
                     "frac_at_clock_of_pmc_pass": vi["frac_at_clock_of_pmc_pass"] if vi else None,
                     "traffic": (dom.get("hbm") or {}).get("traffic"), "kernel_ms": k_ms,
                     "kernel_ms_isolated": st.get("exciter_newt"),
+                    # the same ratio for the undisturbed launch (one stream, nothing overlapping): inside the timed region
+                    # the kernel shares the chip with the other streams' kernels, which stretches the launch it is timed over
+                    "frac_isolated": (vi["achieved"] * k_ms / st["exciter_newt"] / (N_SIMD * MAX_CLOCK_GHZ))
+                    if vi and st.get("exciter_newt") else None,
                     "algorithmic": {"flop_per_launch": flops, "achieved": flops / (k_ms * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS,
                                     "unit": "TFLOP/s", "frac": flops / (k_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
                                     "note": "14 969 flop/sample (86 % in the 101->64 contraction, which runs on the fp16 matrix "

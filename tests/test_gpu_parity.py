@@ -188,6 +188,7 @@ def test_forward_pipeline_matches_plain_forward(models, oracle):
     for batched, kw in ((False, dict()),                                              # defaults: one audio, one control stream
                         (False, dict(depth=4, audio_streams=1, control_streams=2)),
                         (False, dict(depth=4, audio_streams=2, control_streams=1)),
+                        (False, dict(depth=4, audio_streams=2, control_streams=2, chain_exciters=True)),   # nws_forward_audio_ev hooks
                         (True, dict(depth=2, audio_streams=1, control_streams=2))):
         pipe = nws_amd.ForwardPipeline(fast, batched_gru=batched, **kw)
         outs = [pipe.submit(f0, c, phase_u=pu, noise=nz) for f0, c, pu, nz in jobs]
