@@ -17,7 +17,8 @@ m.newt = nws.FastNEWT(m.newt)
 K = int(os.environ.get("K", 20))
 cs = int(os.environ.get("CS", 2))
 f0, control = torch.rand(64, 1, 500, device="cuda"), torch.rand(64, 2, 500, device="cuda")
-pipe = nws.ForwardPipeline(m, depth=4, audio_streams=2, control_streams=cs)
+pipe = nws.ForwardPipeline(m, depth=int(os.environ.get("DEPTH", 4)), audio_streams=int(os.environ.get("AS", 2)), control_streams=cs,
+                           chain_exciters=os.environ.get("CHAIN", "0") == "1")
 with torch.no_grad():
     for _ in range(125):
         pipe.submit(f0, control)
