@@ -333,6 +333,11 @@ int nws_debug_exciter_newt(int variant, const NwsWeights* w, const float* f0, co
                            const float* rand_phase, const float* film, int B, int T, float sample_rate,
                            float* newt_out, void* stream);
 
+/* Diagnostics only: timing ablations of control_gru_kernel (0 product; 1 half the LDS reads of h, 2 half the FMAs, 3 no
+ * transcendentals in the gates, 4 no per-step barrier, 5 no LDS reads of h).  Outputs of variants != 0 are meaningless. */
+int nws_debug_control_gru(int variant, const NwsWeights* w, const float* control, int B, int C, int T, float* gru_out,
+                          void* stream);
+
 /* Diagnostics only: candidate sine implementations (0 = nws_sinf as shipped, 1 = v_sin_f32 after an exact-product
  * reduction to turns, 2 = single odd polynomial after the same reduction); y[i] = sum of `reps` sines (reps = 1: sin(x[i])). */
 int nws_debug_sin(int mode, const float* x, float* y, int64_t n, int reps, void* stream);

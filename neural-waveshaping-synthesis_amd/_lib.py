@@ -109,6 +109,7 @@ _PROTOTYPES = {
                                C.c_size_t, _fp]),
     "nws_debug_exciter_newt": (C.c_int, [C.c_int, C.POINTER(NwsWeights), _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_float,
                                          _fp, _fp]),
+    "nws_debug_control_gru": (C.c_int, [C.c_int, C.POINTER(NwsWeights), _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "nws_debug_sin": (C.c_int, [C.c_int, _fp, _fp, C.c_int64, C.c_int, _fp]),
     "nws_oscillator": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_float, _fp, _fp]),
     "nws_newt_apply": (C.c_int, [C.POINTER(NwsWeights), _fp, _fp, C.c_int, C.c_int, _fp, _fp]),

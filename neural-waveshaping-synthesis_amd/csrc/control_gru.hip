@@ -5,18 +5,23 @@
 //   r = sigmoid(W_ir x + b_ir + W_hr h + b_hr),  z likewise,
 //   n = tanh(W_in x + b_in + r * (W_hn h + b_hn)),  h' = (h - n) * z + n.
 //
-// Design: the recurrence is strictly sequential, so one workgroup owns one
-// utterance for all T steps and W_hh (384x128 fp32 = 192 KB, more than the 160 KB LDS) lives in
-// VGPRs.  Wave w owns hidden units [32w, 32w+32); lane (j = l&31, kh = l>>5) holds the three gate
-// rows of unit 32w+j restricted to columns [64kh, 64kh+64): 192 weights per lane.  Per step a lane
-// reads its 64 h values (16 broadcast ds_read_b128), does 96 packed FMAs (v_pk_fma_f32), meets its
-// other K-half with one v_permlane32_swap per gate, evaluates the gates with v_exp/v_rcp (1 ulp) and
-// writes h' into the other half of a ping-pong LDS buffer: ONE workgroup barrier per step that waits
-// on LDS only (raw s_barrier + lgkmcnt(0); the 512 B h_t global store is never drained on the critical
-// path), control values staged in LDS 1024 frames at a time.
-// Measured alternatives (MI355X, 500 steps): 4 K-slices + LDS partial-sum exchange + libm gates + two
-// __syncthreads per step 0.457 ms; this kernel 0.271 ms; an 8-wave variant (2 waves/SIMD, lane = unit x
-// K-quarter) 0.290 ms -- the step is bound by VALU issue (96 v_pk_fma_f32 + gate math per lane), not latency.
+// Design: the recurrence is strictly sequential, so one workgroup owns one utterance for all T steps and
+// W_hh (384x128 fp32 = 192 KB, more than the 160 KB LDS) lives in VGPRs.  Wave w owns hidden units [32w, 32w+32); lane
+// l = 32a + 16s + p holds the three gate rows of the unit PAIR (32w + 2p, +1) restricted to the K-quarter 2a + s (columns
+// [32(2a+s), +32)): 192 weights per lane.  Per step a lane reads its 32 h values (8 broadcast ds_read_b128), does 96
+// packed FMAs (v_pk_fma_f32; each h value serves six outputs), reduces over the four K-quarters with one
+// v_permlane32_swap per gate - which also separates the two units: lanes a=0 keep the first, a=1 the second - and one
+// self v_permlane16_swap, then evaluates the gates of ITS unit (two replicas) with v_exp/v_rcp (1 ulp) and writes h'
+// into the other half of a ping-pong LDS buffer: ONE workgroup barrier per step that waits on LDS only (raw s_barrier +
+// lgkmcnt(0); the 512 B h_t global store is never drained on the critical path), control values staged in LDS 1024
+// frames at a time.
+// Measured (MI355X, 500 steps, tools/gru_variants.py): this kernel 0.229 ms (0.458 us/step).  Round 1's layout - lane =
+// (unit, K-half), 16 ds_read_b128 per lane - 0.276 ms, of which the ablations price 0.29 us/step for the 96 packed FMAs
+// (one wave per SIMD issues one vector instruction per ~7 cycles whatever its class: 192 v_fmac_f32 instead took 1.05
+// us/step), 0.13 for the LDS broadcast of h, 0.04 for the transcendentals, 0.04 for the barrier.  Four units per lane
+// (4 reads, a longer reduction) 0.236 ms; eight waves (two per SIMD: the FMAs drop to 0.20 us/step, but reduction and
+// gate math are issued twice per SIMD) 0.285 ms; K-quarters interleaved at 16 B (the four addresses of a read in one 64 B
+// line) 0.238 ms; 4 K-slices + LDS partial-sum exchange + libm gates 0.457 ms (round 1).
 #include "nws_common.h"
 
 namespace {
@@ -24,9 +29,9 @@ namespace {
 constexpr int kH = NWS_HIDDEN;  // 128
 constexpr int kXChunk = 1024;   // control frames staged in LDS at a time
 
-// cross-half (lane l <-> l^32) sum on the VALU (v_permlane32_swap), no LDS round trip
-__device__ __forceinline__ float sum_halves(float v) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+// sum over the 16-lane row pairs (lane l <-> l^16) on the VALU (v_permlane16_swap), no LDS round trip
+__device__ __forceinline__ float sum_rows16(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
@@ -36,20 +41,13 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// sigmoid / tanh from the hardware exp2 + reciprocal (each ~1 ulp): same error class as the
-// libm forms inside torch's CPU GRU, a fraction of their latency on the sequential critical path
-__device__ __forceinline__ float fast_sigmoid(float x) {
-  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
-}
-__device__ __forceinline__ float fast_tanh(float x) {
-  // tanh(x) = 1 - 2 / (exp(2x) + 1); saturates correctly for |x| large (exp2 -> inf or 0)
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
-}
-
-__global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const float* __restrict__ control, int C,
-                                                             int T, const float* __restrict__ h0,
-                                                             float* __restrict__ gru_out, float* __restrict__ hT,
-                                                             const float* __restrict__ f0, double* __restrict__ carry) {
+// DBG != 0: timing ablations for nws_debug_control_gru (results wrong by design): 1 half the LDS reads of h, 2 half the
+// FMAs, 3 gates without transcendentals, 4 no workgroup barrier, 5 no LDS reads of h at all
+template <int DBG = 0>
+__global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const float* __restrict__ control, int C, int T,
+                                                             const float* __restrict__ h0, float* __restrict__ gru_out,
+                                                             float* __restrict__ hT, const float* __restrict__ f0,
+                                                             double* __restrict__ carry) {
   // latency-bound and usually sharing its SIMDs with throughput kernels of other streams (ForwardPipeline): ask for issue
   // priority, the recurrence is the critical path of the pipelined step
   __builtin_amdgcn_s_setprio(3);
@@ -57,34 +55,43 @@ __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int kh = lane >> 5;
-  const int unit = 32 * wave + (lane & 31);
+  const int a = lane >> 5;
+  const int sl = 2 * a + ((lane >> 4) & 1);    // K-slice
+  const int ua = 32 * wave + 2 * (lane & 15);  // FMA phase: units ua and ua + 1
+  const int unit = ua + a;                     // gate phase: this lane's unit
+  const bool writer = (lane & 16) == 0;        // one of the two replicas stores
 
   __shared__ __attribute__((aligned(16))) float h_lds[2][kH];
-  __shared__ __attribute__((aligned(16))) float x_lds[2][kXChunk];  // control[:, 0:2] of the current chunk of frames
+  __shared__ __attribute__((aligned(16))) float x_lds[2][kXChunk];
   // fused control-rate prologue of a forward: this utterance's oscillator phase carries (nws_control_gru_carry).  ~8 us here
   // instead of a separate 64-workgroup launch in front of the recurrence on the control stream (70 us under load)
   if (carry != nullptr) nws_phase_carry_block<4>(f0, nullptr, T, carry, b, tid, reinterpret_cast<double*>(&x_lds[0][0]));
 
-  // wreg[g][c] = W_hh[g*128 + unit][64 kh + c]
-  f32x2 wreg[3][32];
+  // wreg[u][g][c] = W_hh[g*128 + ua + u][32 sl + 2c, +1] (times the gate's constant, below)
+  constexpr float kSig = -1.4426950408889634f, kTanh = 2.8853900817779268f;
+  f32x2 wreg[2][3][16];
 #pragma unroll
-  for (int g = 0; g < 3; ++g) {
-    const float4* src = reinterpret_cast<const float4*>(w.gru_w_hh + (size_t)(g * kH + unit) * kH + 64 * kh);
+  for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const float4 v = src[q];
-      wreg[g][2 * q + 0] = f32x2{v.x, v.y};
-      wreg[g][2 * q + 1] = f32x2{v.z, v.w};
+    for (int g = 0; g < 3; ++g) {
+      const float4* src = reinterpret_cast<const float4*>(w.gru_w_hh + (size_t)(g * kH + ua + u) * kH + 32 * sl);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 v = src[q];
+        const float gs = g == 2 ? kTanh : kSig;
+        wreg[u][g][2 * q + 0] = f32x2{gs * v.x, gs * v.y};
+        wreg[u][g][2 * q + 1] = f32x2{gs * v.z, gs * v.w};
+      }
     }
-  }
-  const float wi_r0 = w.gru_w_ih[unit * 2 + 0], wi_r1 = w.gru_w_ih[unit * 2 + 1];
-  const float wi_z0 = w.gru_w_ih[(kH + unit) * 2 + 0], wi_z1 = w.gru_w_ih[(kH + unit) * 2 + 1];
-  const float wi_n0 = w.gru_w_ih[(2 * kH + unit) * 2 + 0], wi_n1 = w.gru_w_ih[(2 * kH + unit) * 2 + 1];
-  const float bi_r = w.gru_b_ih[unit], bi_z = w.gru_b_ih[kH + unit], bi_n = w.gru_b_ih[2 * kH + unit];
-  const float bh_r = w.gru_b_hh[unit], bh_z = w.gru_b_hh[kH + unit], bh_n = w.gru_b_hh[2 * kH + unit];
+  // every gate's weights and biases carry the constant its nonlinearity multiplies the argument with anyway (-log2 e for
+  // the sigmoids, 2 log2 e for tanh): the sums feed v_exp_f32 directly (one rounding per weight, the class of the FMA
+  // roundings of the row sums themselves; same yard-stick against a float64 GRU as before)
+  const float wi_r0 = kSig * w.gru_w_ih[unit * 2 + 0], wi_r1 = kSig * w.gru_w_ih[unit * 2 + 1];
+  const float wi_z0 = kSig * w.gru_w_ih[(kH + unit) * 2 + 0], wi_z1 = kSig * w.gru_w_ih[(kH + unit) * 2 + 1];
+  const float wi_n0 = kTanh * w.gru_w_ih[(2 * kH + unit) * 2 + 0], wi_n1 = kTanh * w.gru_w_ih[(2 * kH + unit) * 2 + 1];
+  const float b_r = kSig * (w.gru_b_ih[unit] + w.gru_b_hh[unit]), b_z = kSig * (w.gru_b_ih[kH + unit] + w.gru_b_hh[kH + unit]);
+  const float bi_n = kTanh * w.gru_b_ih[2 * kH + unit], bh_n = kTanh * w.gru_b_hh[2 * kH + unit];
 
-  // h0 == nullptr: zero initial state (the reference's stateless forward); streaming passes the carried state
   float h_prev = h0 != nullptr ? h0[(size_t)b * kH + unit] : 0.0f;
   if (tid < kH) h_lds[0][tid] = h0 != nullptr ? h0[(size_t)b * kH + tid] : 0.0f;
   const float* x0p = control + ((size_t)b * C + 0) * T;
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const
 
   for (int t0 = 0; t0 < T; t0 += kXChunk) {
     const int nt = T - t0 < kXChunk ? T - t0 : kXChunk;
-    __syncthreads();  // previous chunk fully consumed (and h_lds[0] initialised on the first pass)
+    __syncthreads();
     for (int i = tid; i < nt; i += 256) {
       x_lds[0][i] = x0p[t0 + i];
       x_lds[1][i] = x1p[t0 + i];
@@ -102,42 +109,55 @@ __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const
       const int t = t0 + tt;
       const int cur = t & 1;
       const float x0 = x_lds[0][tt], x1 = x_lds[1][tt];
-      // input-side gate terms: independent of h, overlap the h reads
-      const float ir = fmaf(wi_r1, x1, fmaf(wi_r0, x0, bi_r)) + bh_r;
-      const float iz = fmaf(wi_z1, x1, fmaf(wi_z0, x0, bi_z)) + bh_z;
+      const float ir = fmaf(wi_r1, x1, fmaf(wi_r0, x0, b_r));
+      const float iz = fmaf(wi_z1, x1, fmaf(wi_z0, x0, b_z));
       const float in = fmaf(wi_n1, x1, fmaf(wi_n0, x0, bi_n));
-      const float4* hp = reinterpret_cast<const float4*>(&h_lds[cur][64 * kh]);
-      f32x2 ar = {0.0f, 0.0f}, az = {0.0f, 0.0f}, an = {0.0f, 0.0f};
-      f32x2 br = {0.0f, 0.0f}, bz = {0.0f, 0.0f}, bn = {0.0f, 0.0f};
+      const float4* hp = reinterpret_cast<const float4*>(&h_lds[cur][32 * sl]);
+      f32x2 acc[2][3];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float4 hv = hp[q];
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[u][g] = f32x2{0.0f, 0.0f};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 hv = DBG == 5 ? float4{h_prev, x0, x1, h_prev} : hp[DBG == 1 ? (q & ~1) : q];
         const f32x2 h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
-        ar = __builtin_elementwise_fma(wreg[0][2 * q], h01, ar);
-        az = __builtin_elementwise_fma(wreg[1][2 * q], h01, az);
-        an = __builtin_elementwise_fma(wreg[2][2 * q], h01, an);
-        br = __builtin_elementwise_fma(wreg[0][2 * q + 1], h23, br);
-        bz = __builtin_elementwise_fma(wreg[1][2 * q + 1], h23, bz);
-        bn = __builtin_elementwise_fma(wreg[2][2 * q + 1], h23, bn);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int g = 0; g < 3; ++g) acc[u][g] = __builtin_elementwise_fma(wreg[u][g][2 * q], h01, acc[u][g]);
+        if (DBG == 2) continue;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int g = 0; g < 3; ++g) acc[u][g] = __builtin_elementwise_fma(wreg[u][g][2 * q + 1], h23, acc[u][g]);
       }
-      // horizontal sums kept scalar: "a.x + a.y" on a register pair becomes a packed add with a swizzled src1 otherwise
-      const float sr = sum_halves(nws_add_scalar(ar.x, ar.y) + nws_add_scalar(br.x, br.y));
-      const float sz = sum_halves(nws_add_scalar(az.x, az.y) + nws_add_scalar(bz.x, bz.y));
-      const float sn = sum_halves(nws_add_scalar(an.x, an.y) + nws_add_scalar(bn.x, bn.y));
-      // both K-halves now hold the full sums; both evaluate the gates (no divergence), half 0 stores
-      const float r = fast_sigmoid(ir + sr);
-      const float z = fast_sigmoid(iz + sz);
-      const float nn = fast_tanh(in + r * (sn + bh_n));
-      const float hnew = (h_prev - nn) * z + nn;
+      float sg[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const float pa = nws_add_scalar(acc[0][g].x, acc[0][g].y), pb = nws_add_scalar(acc[1][g].x, acc[1][g].y);
+        // lanes a=0 receive both halves of the first unit's partial sums, lanes a=1 of the second's
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(pa), __float_as_uint(pb), false, false);
+        sg[g] = sum_rows16(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+      }
+      // sigmoid(x) = 1 / (1 + 2^(-x log2 e));  tanh(x) = 1 - 2 / (1 + 2^(2 x log2 e)) (saturates correctly: exp2 -> inf or 0);
+      // hardware exp2 + reciprocal (each ~1 ulp): the error class of the libm forms inside torch's CPU GRU, a fraction of
+      // their latency on the sequential critical path
+      auto ex2 = [](float v) { return DBG == 3 ? 0.01f * v : __builtin_amdgcn_exp2f(v); };
+      auto rcp = [](float v) { return DBG == 3 ? 0.5f * v : __builtin_amdgcn_rcpf(v); };
+      const float r = rcp(1.0f + ex2(ir + sg[0]));
+      const float z = rcp(1.0f + ex2(iz + sg[1]));
+      const float nn = fmaf(-2.0f, rcp(1.0f + ex2(fmaf(r, sg[2] + bh_n, in))), 1.0f);
+      const float hnew = fmaf(h_prev - nn, z, nn);
       h_prev = hnew;
-      if (kh == 0) {
+      if (writer) {
         h_lds[cur ^ 1][unit] = hnew;
         gru_out[((size_t)b * T + t) * kH + unit] = hnew;
       }
-      lds_barrier();
+      if (DBG != 4) lds_barrier();
     }
   }
-  if (hT != nullptr && kh == 0) hT[(size_t)b * kH + unit] = h_prev;
+  if (hT != nullptr && writer) hT[(size_t)b * kH + unit] = h_prev;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -333,7 +353,7 @@ extern "C" int nws_control_gru_state(const NwsWeights* w, const float* control, 
                                      float* gru_out, float* hT, void* stream) {
   if (!w || !w->gru_w_ih || !w->gru_w_hh || !w->gru_b_ih || !w->gru_b_hh || !control || !gru_out) return NWS_ERR_BAD_ARG;
   if (B <= 0 || T <= 0 || C < 2) return NWS_ERR_BAD_ARG;
-  control_gru_kernel<<<B, 256, 0, (hipStream_t)stream>>>(*w, control, C, T, h0, gru_out, hT, nullptr, nullptr);
+  control_gru_kernel<0><<<B, 256, 0, (hipStream_t)stream>>>(*w, control, C, T, h0, gru_out, hT, nullptr, nullptr);
   NWS_CHECK_LAUNCH();
   return NWS_OK;
 }
@@ -343,7 +363,25 @@ extern "C" int nws_control_gru_carry(const NwsWeights* w, const float* control, 
   if (!w || !w->gru_w_ih || !w->gru_w_hh || !w->gru_b_ih || !w->gru_b_hh || !control || !gru_out || !f0 || !carry_out)
     return NWS_ERR_BAD_ARG;
   if (B <= 0 || T <= 0 || C < 2) return NWS_ERR_BAD_ARG;
-  control_gru_kernel<<<B, 256, 0, (hipStream_t)stream>>>(*w, control, C, T, nullptr, gru_out, nullptr, f0, carry_out);
+  control_gru_kernel<0><<<B, 256, 0, (hipStream_t)stream>>>(*w, control, C, T, nullptr, gru_out, nullptr, f0, carry_out);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+extern "C" int nws_debug_control_gru(int variant, const NwsWeights* w, const float* control, int B, int C, int T,
+                                     float* gru_out, void* stream) {
+  if (!w || !w->gru_w_hh || !control || !gru_out || B <= 0 || T <= 0 || C < 2) return NWS_ERR_BAD_ARG;
+#define NWS_GRU_DBG(V) control_gru_kernel<V><<<B, 256, 0, (hipStream_t)stream>>>(*w, control, C, T, nullptr, gru_out, nullptr, nullptr, nullptr)
+  switch (variant) {
+    case 0: NWS_GRU_DBG(0); break;
+    case 1: NWS_GRU_DBG(1); break;
+    case 2: NWS_GRU_DBG(2); break;
+    case 3: NWS_GRU_DBG(3); break;
+    case 4: NWS_GRU_DBG(4); break;
+    case 5: NWS_GRU_DBG(5); break;
+    default: return NWS_ERR_BAD_ARG;
+  }
+#undef NWS_GRU_DBG
   NWS_CHECK_LAUNCH();
   return NWS_OK;
 }
