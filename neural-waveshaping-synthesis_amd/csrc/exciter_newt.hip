@@ -442,14 +442,16 @@ __device__ __forceinline__ f16x2 split_lo2(f16x2 hi, f32x2 v) {
   return __builtin_bit_cast(f16x2, lp);
 }
 
-// hot-loop form: v_fract_f32 instead of rint + subtract (one instruction less per pair; the reduced argument lives in
-// [0,1) instead of [-1/2,1/2], i.e. one bit coarser: ~1.9e-7 instead of ~0.9e-7 absolute on the sine, see tools/measure_sin.py)
+// hot-loop form: n = rint(x C_hi), then t = fma(x, C_hi, -n) - the EXACT product minus an integer, rounded once: |t| <= 1/2,
+// so the rounding costs <= 3e-8 turns - and t += x C_lo.  Three packed instructions and two v_rndne_f32 per pair; the
+// v_fract form before it (p, its exact rounding error e, fract(p) + (x C_lo + e)) needed four and two v_fract_f32, and
+// its reduced argument in [0,1) was one bit coarser (~1.9e-7 against ~0.9e-7 absolute on the sine, tools/measure_sin.py).
+// Same box, B=64, all harmonics live: 0.2232 against 0.2279 ms (hybrid-W), 0.2872 against 0.2939 ms (two-term).
 __device__ __forceinline__ f32x2 sin_turns2_fract(f32x2 x) {
   const f32x2 c_hi = splat2(0.15915493667125702f), c_lo = splat2(6.4206382432985265e-09f);
   const f32x2 p = x * c_hi;
-  const f32x2 e = fma2(x, c_hi, -p);
-  const f32x2 f = {__builtin_amdgcn_fractf(p.x), __builtin_amdgcn_fractf(p.y)};
-  const f32x2 t = f + fma2(x, c_lo, e);
+  const f32x2 n = {__builtin_rintf(p.x), __builtin_rintf(p.y)};
+  const f32x2 t = fma2(x, c_lo, fma2(x, c_hi, -n));
   return f32x2{__builtin_amdgcn_sinf(t.x), __builtin_amdgcn_sinf(t.y)};
 }
 
@@ -457,9 +459,7 @@ __device__ __forceinline__ f32x2 sin_turns2_fract(f32x2 x) {
 // and, unlike those, beside the matrix pipe (tools/ubench/valu_rate.hip)
 __device__ __forceinline__ float sin_turns_fract(float x) {
   const float c_hi = 0.15915493667125702f, c_lo = 6.4206382432985265e-09f;
-  const float p = x * c_hi;
-  const float e = fmaf(x, c_hi, -p);
-  return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(p) + fmaf(x, c_lo, e));
+  return __builtin_amdgcn_sinf(fmaf(x, c_lo, fmaf(x, c_hi, -__builtin_rintf(x * c_hi))));
 }
 
 // two sines at once: every step except rint and v_sin_f32 is a packed-fp32 instruction
