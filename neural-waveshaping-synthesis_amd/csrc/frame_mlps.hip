@@ -316,37 +316,6 @@ __device__ __forceinline__ void mma_tile(const AFrag<KS>& A, const char* xt, int
   for (int r = 0; r < 16; ++r) acc[r] += cross[r];
 }
 
-// two independent tiles at once (different weights, same or different inputs): four accumulator chains interleaved, so no
-// MFMA waits on its predecessor
-template <int KS>
-__device__ __forceinline__ void mma_tile2(const AFrag<KS>& A, const char* xa, f32x16& acc_a, const AFrag<KS>& B,
-                                          const char* xb, f32x16& acc_b, int lane) {
-  const int half = lane >> 5, col = lane & 31;
-  f32x16 cross_a, cross_b;
-  const char* ah = xa + col * kRowB + half * 16;
-  const char* al = ah + kXtBytes;
-  const char* bh = xb + col * kRowB + half * 16;
-  const char* bl = bh + kXtBytes;
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const f16x8 ph = *reinterpret_cast<const f16x8*>(ah + ks * 32);
-    const f16x8 pl = *reinterpret_cast<const f16x8*>(al + ks * 32);
-    const f16x8 qh = *reinterpret_cast<const f16x8*>(bh + ks * 32);
-    const f16x8 ql = *reinterpret_cast<const f16x8*>(bl + ks * 32);
-    acc_a = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.hi[ks], ph, ks == 0 ? f32x16{} : acc_a, 0, 0, 0);
-    acc_b = __builtin_amdgcn_mfma_f32_32x32x16_f16(B.hi[ks], qh, ks == 0 ? f32x16{} : acc_b, 0, 0, 0);
-    cross_a = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.hi[ks], pl, ks == 0 ? f32x16{} : cross_a, 0, 0, 0);
-    cross_b = __builtin_amdgcn_mfma_f32_32x32x16_f16(B.hi[ks], ql, ks == 0 ? f32x16{} : cross_b, 0, 0, 0);
-    cross_a = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.lo[ks], ph, cross_a, 0, 0, 0);
-    cross_b = __builtin_amdgcn_mfma_f32_32x32x16_f16(B.lo[ks], qh, cross_b, 0, 0, 0);
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    acc_a[r] += cross_a[r];
-    acc_b[r] += cross_b[r];
-  }
-}
-
 // write a 32-channel x 32-frame tile held in the D layout into an XT buffer (4 consecutive channels per store)
 __device__ __forceinline__ void store_tile_xt(char* xt, int c0, const float v[16], int lane) {
   const int half = lane >> 5, col = lane & 31;
@@ -407,66 +376,73 @@ __device__ __forceinline__ void ln_finish(float (&v)[16], float mean, float rstd
   }
 }
 
-// One hidden-layer PAIR (newt.mlp layer l | h_generator layer l).  The order of the global loads is the point: VMEM loads
-// return in order, so a parameter load issued behind the next layer's 32 fragment loads would make the whole epilogue wait
-// for those.  Biases are therefore requested before the MFMAs (they arrive under them); the gains / offsets (2 values per
-// thread) right after the MFMAs, on their way to LDS; and only then the next pair's fragments, whose registers became free
-// when the MFMAs were issued: the fragments stream in under the statistics exchange, the normalisation and the barriers.
-template <int FA_NEXT, int FB_NEXT>
-__device__ __forceinline__ void hidden_pair(MlpLds16& L, const f16x8* __restrict__ F, AFrag<8>& A0, AFrag<8>& A1,
-                                            const char* in_a, const char* in_b, char* out_a, char* out_b,
-                                            const float* bias_a, const float* g_a, const float* bt_a, const float* bias_b,
-                                            const float* g_b, const float* bt_b, int mt_next_a, int mt_next_b, int wave,
-                                            int lane) {
+// one accumulator chain for all three products (dependent 32x32x16 MFMAs issue back to back at full rate; the small cross
+// terms meet the same fp32 additions either way): 16 registers less than mma_tile, no merge pass
+template <int KS>
+__device__ __forceinline__ void mma_tile1(const AFrag<KS>& A, const char* xt, int lane, f32x16& acc) {
   const int half = lane >> 5, col = lane & 31;
-  const int tid = 64 * wave + lane;
-  float va[16], vb[16];
-  load_lane_params(va, bias_a, wave, lane);
-  load_lane_params(vb, bias_b, wave, lane);
-  f32x16 acc_a, acc_b;
-  mma_tile2<8>(A0, in_a, acc_a, A1, in_b, acc_b, lane);
-  // thread t fetches gb[t >> 7][t & 127] and gb[2 + (t >> 7)][t & 127]
-  const float p0 = ((tid >> 7) == 0 ? g_a : bt_a)[tid & 127];
-  const float p1 = ((tid >> 7) == 0 ? g_b : bt_b)[tid & 127];
+  const char* bh = xt + col * kRowB + half * 16;
+  const char* bl = bh + kXtBytes;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    va[r] += acc_a[r];
-    vb[r] += acc_b[r];
+  for (int ks = 0; ks < KS; ++ks) {
+    const f16x8 xh = *reinterpret_cast<const f16x8*>(bh + ks * 32);
+    const f16x8 xl = *reinterpret_cast<const f16x8*>(bl + ks * 32);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.hi[ks], xl, ks == 0 ? f32x16{} : acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.lo[ks], xh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.hi[ks], xh, acc, 0, 0, 0);
   }
-  load_frags<8>(A0, F + frag_map(FA_NEXT).base, mt_next_a, lane);
-  load_frags<8>(A1, F + frag_map(FB_NEXT).base, mt_next_b, lane);
-  L.gb[tid >> 7][tid & 127] = p0;
-  L.gb[2 + (tid >> 7)][tid & 127] = p1;
-  float mw_a, m2_a, mw_b, m2_b;
-  ln_partials(va, mw_a, m2_a);
-  ln_partials(vb, mw_b, m2_b);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// newt.mlp and h_generator are independent after the embedding.  8 waves: wave = (M-tile mt, path), path 0 = newt.mlp,
+// path 1 = h_generator, ONE 32 x 32 tile per wave and layer; the LayerNorm statistics of both paths travel in one exchange,
+// and each wave requests the weight fragments of its next layer as soon as the current layer's MFMAs have been issued
+// (their registers are free from then on), so they arrive under the epilogue.  80 KB of LDS (two workgroups per CU) and
+// <= 128 registers: four waves per SIMD.  Buffers: E (embedding, later hgen L2), X, Y, Z.
+//   proj: waves 0-3: X(gru) -> E        L1: E -> X | E -> Y        L2: X -> Z | Y -> E        L3: Z -> X | E -> Y
+//   out : waves 0-3: X -> film tiles mt, mt+4;   waves 4-7: Y -> H tile mt -> Z (wave 4 also row 128)
+//   fir : all 8 waves: Z -> fir tile `wave`
+// 10 workgroup barriers per 32 frames.  Measured (B=64, T=500, one stream): 0.065 ms; the round-2 form with four waves
+// and two tiles per wave (252 registers, two waves per SIMD) 0.066-0.067 ms; with the W_lo fragment loads skipped
+// (wrong results, timing only) 0.055 ms: ~30 % of the time is the 819 KB of fragments every workgroup streams from L2
+// (13 TB/s aggregate), the rest latency between the ten phases.
+template <int FA_NEXT, int FB_NEXT>
+__device__ __forceinline__ void hidden_w8(MlpLds16& L, const f16x8* __restrict__ F, AFrag<8>& A, const char* in, char* out,
+                                          const float* bias, const float* g_a, const float* bt_a, const float* g_b,
+                                          const float* bt_b, int mt, int path, int tid, int lane) {
+  const int half = lane >> 5, col = lane & 31;
+  float v[16];
+  load_lane_params(v, bias, mt, lane);
+  f32x16 acc;
+  mma_tile1<8>(A, in, lane, acc);
+  // thread t fetches gb[t >> 7][t & 127]: [g_a | beta_a | g_b | beta_b]
+  const int row = tid >> 7;
+  const float p0 = (row == 0 ? g_a : row == 1 ? bt_a : row == 2 ? g_b : bt_b)[tid & 127];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] += acc[r];
+  __builtin_amdgcn_sched_barrier(0);   // the fragments reuse registers the MFMAs above have just released
+  load_frags<8>(A, F + (path ? frag_map(FB_NEXT).base : frag_map(FA_NEXT).base), mt, lane);
+  L.gb[row][tid & 127] = p0;
+  float mw, m2;
+  ln_partials(v, mw, m2);
   if (half == 0) {
-    L.red[0][0][wave][col] = mw_a;
-    L.red[0][1][wave][col] = m2_a;
-    L.red[1][0][wave][col] = mw_b;
-    L.red[1][1][wave][col] = m2_b;
+    L.red[path][0][mt][col] = mw;
+    L.red[path][1][mt][col] = m2;
   }
   __syncthreads();
   float mean, rstd;
-  ln_merge(L.red[0], col, mean, rstd);
-  ln_finish(va, mean, rstd, L.gb[0], L.gb[1], wave, lane);
-  store_tile_xt(out_a, 32 * wave, va, lane);
-  ln_merge(L.red[1], col, mean, rstd);
-  ln_finish(vb, mean, rstd, L.gb[2], L.gb[3], wave, lane);
-  store_tile_xt(out_b, 32 * wave, vb, lane);
+  ln_merge(L.red[path], col, mean, rstd);
+  ln_finish(v, mean, rstd, L.gb[2 * path], L.gb[2 * path + 1], mt, lane);
+  store_tile_xt(out, 32 * mt, v, lane);
   __syncthreads();
 }
 
-// newt.mlp and h_generator are independent after the embedding: their layers are issued as PAIRS.  Each wave runs four
-// accumulator chains per layer pair, the LayerNorm statistics of both paths travel in one exchange, and the weight
-// fragments of the next pair are requested as soon as the current pair's MFMAs have been issued (their registers are
-// free from then on), so they arrive under the epilogue.  Buffers: E (embedding, later hgen L2), X, Y, Z.
-//   proj: X(gru) -> E          L1: E -> X | E -> Y          L2: X -> Z | Y -> E          L3: Z -> X | E -> Y
-//   out : X -> film (2 tiles) | Y -> H -> Z        fir: Z -> fir (2 tiles)
-// 9 workgroup barriers per 32 frames (the one-path-at-a-time version of this kernel: 22) at the same 80 KB of LDS.
-__global__ __launch_bounds__(256, 2) void frame_mlps16_kernel(NwsWeights w, const float* __restrict__ gru_out, int T,
-                                                              float* __restrict__ emb_out, float* __restrict__ film_out,
-                                                              float* __restrict__ H_out, float* __restrict__ fir_out) {
+// TAPS: also store the embedding and H (stage tests, get_embedding); the forward's instantiation carries neither the code nor
+// its address registers
+template <bool TAPS>
+__global__ __launch_bounds__(512, 4) void frame_mlps16_kernel(NwsWeights w, const float* __restrict__ gru_out, int T,
+                                                                float* __restrict__ emb_out, float* __restrict__ film_out,
+                                                                float* __restrict__ H_out, float* __restrict__ fir_out) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   MlpLds16& L = *reinterpret_cast<MlpLds16*>(smem_raw);
   char* const E = L.xt[0][0];
@@ -474,115 +450,118 @@ __global__ __launch_bounds__(256, 2) void frame_mlps16_kernel(NwsWeights w, cons
   char* const Y = L.xt[2][0];
   char* const Z = L.xt[3][0];
   const f16x8* F = reinterpret_cast<const f16x8*>(w.mlp_frags);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the branches on mt / path below are uniform
+  const int mt = wave & 3, path = wave >> 2;
   const int half = lane >> 5, col = lane & 31;
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * kFT;
   const int frames_valid = T - t0 < kFT ? T - t0 : kFT;
-  AFrag<8> A0, A1;
-  f32x16 acc_a, acc_b;
+  AFrag<8> A;
+  f32x16 acc;
 
-  load_frags<8>(A0, F + frag_map(0).base, wave, lane);  // proj
+  __builtin_amdgcn_sched_barrier(0);   // the fragments reuse registers the MFMAs above have just released
+  load_frags<8>(A, F + (path ? frag_map(5).base : frag_map(0).base), mt, lane);  // proj | hgen hidden 0
   // ---- gru_out tile -> X (4 channels per thread per pass) ----
-  for (int e = tid; e < kFT * (NWS_HIDDEN / 4); e += 256) {
+  for (int e = tid; e < kFT * (NWS_HIDDEN / 4); e += 512) {
     const int f = e >> 5, c4 = (e & 31) * 4;
     float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (f < frames_valid) v = *reinterpret_cast<const float4*>(&gru_out[((size_t)b * T + t0 + f) * NWS_HIDDEN + c4]);
     split4_store(X, X + kXtBytes, f, c4, v.x, v.y, v.z, v.w);
   }
   // zero the K padding (channels 128..143) of Z, which will hold H for the FIR-design contraction
-  for (int e = tid; e < kFT * 2 * 2; e += 256) {
-    const int f = e >> 2, part = e & 3;
+  if (tid < kFT * 2 * 2) {
+    const int f = tid >> 2, part = tid & 3;
     *reinterpret_cast<float4*>(Z + (part >> 1) * kXtBytes + f * kRowB + 256 + (part & 1) * 16) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
   __syncthreads();
 
-  // ---- emb = proj(gru_out) -> E ----
-  {
+  // ---- emb = proj(gru_out) -> E (waves 0-3; the other four already hold their first hidden layer's fragments) ----
+  if (path == 0) {
     float v[16];
-    load_lane_params(v, w.proj_b, wave, lane);  // requested before the fragments of the first pair (in-order returns)
-    mma_tile<8>(A0, X, lane, acc_a);
-    load_frags<8>(A0, F + frag_map(1).base, wave, lane);  // newt hidden 0
-    load_frags<8>(A1, F + frag_map(5).base, wave, lane);  // hgen hidden 0
+    load_lane_params(v, w.proj_b, mt, lane);
+    mma_tile1<8>(A, X, lane, acc);
+    __builtin_amdgcn_sched_barrier(0);   // the fragments reuse registers the MFMAs above have just released
+  load_frags<8>(A, F + frag_map(1).base, mt, lane);  // newt hidden 0
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] += acc_a[r];
-    store_tile_xt(E, 32 * wave, v, lane);
-    if (emb_out != nullptr && col < frames_valid) {
+    for (int r = 0; r < 16; ++r) v[r] += acc[r];
+    store_tile_xt(E, 32 * mt, v, lane);
+    if (TAPS && emb_out != nullptr && col < frames_valid) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) emb_out[((size_t)b * NWS_HIDDEN + 32 * wave + frag_row(r, half)) * T + t0 + col] = v[r];
+      for (int r = 0; r < 16; ++r) emb_out[((size_t)b * NWS_HIDDEN + 32 * mt + frag_row(r, half)) * T + t0 + col] = v[r];
     }
   }
   __syncthreads();
 
-  // ---- three hidden layer pairs (each requests the fragments of the one that follows) ----
-  hidden_pair<2, 6>(L, F, A0, A1, E, E, X, Y, w.newt_mlp_b[0], w.newt_ln_g[0], w.newt_ln_b[0], w.hgen_b[0], w.hgen_ln_g[0],
-                    w.hgen_ln_b[0], wave, wave, wave, lane);
-  hidden_pair<3, 7>(L, F, A0, A1, X, Y, Z, E, w.newt_mlp_b[1], w.newt_ln_g[1], w.newt_ln_b[1], w.hgen_b[1], w.hgen_ln_g[1],
-                    w.hgen_ln_b[1], wave, wave, wave, lane);
-  hidden_pair<4, 8>(L, F, A0, A1, Z, E, X, Y, w.newt_mlp_b[2], w.newt_ln_g[2], w.newt_ln_b[2], w.hgen_b[2], w.hgen_ln_g[2],
-                    w.hgen_ln_b[2], wave, wave, wave, lane);
+  // ---- three hidden layers per path (each requests the fragments of the one that follows) ----
+  hidden_w8<2, 6>(L, F, A, E, path ? Y : X, path ? w.hgen_b[0] : w.newt_mlp_b[0], w.newt_ln_g[0], w.newt_ln_b[0],
+                  w.hgen_ln_g[0], w.hgen_ln_b[0], mt, path, tid, lane);
+  hidden_w8<3, 7>(L, F, A, path ? Y : X, path ? E : Z, path ? w.hgen_b[1] : w.newt_mlp_b[1], w.newt_ln_g[1], w.newt_ln_b[1],
+                  w.hgen_ln_g[1], w.hgen_ln_b[1], mt, path, tid, lane);
+  hidden_w8<4, 8>(L, F, A, path ? E : Z, path ? Y : X, path ? w.hgen_b[2] : w.newt_mlp_b[2], w.newt_ln_g[2], w.newt_ln_b[2],
+                  w.hgen_ln_g[2], w.hgen_ln_b[2], mt, path, tid, lane);
 
-  // ---- output layers: film (256 channels = M-tiles w, w+4) from X; H (129 = M-tiles 0..3 + row 128 by wave 0) from Y ----
-  float* patch = reinterpret_cast<float*>(E) + wave * (kFT * kPS);  // E is dead: per-wave transposition patch
-  AFrag<9> A9a, A9b;
-  {
-    float v[16], vh[16];
-    load_lane_params(v, w.newt_mlp_b[3], wave, lane);       // output biases requested before the fragment prefetch
-    load_lane_params(vh, w.hgen_b[3], wave, lane);
+  // ---- output layers.  E is dead: transposition patches of waves 0-3 ----
+  float* patch = reinterpret_cast<float*>(E) + mt * (kFT * kPS);
+  if (path == 0) {
+    // film (256 channels): M-tiles mt and mt + 4 from X
+    float v[16];
+    load_lane_params(v, w.newt_mlp_b[3], mt, lane);
+    mma_tile1<8>(A, X, lane, acc);
+    __builtin_amdgcn_sched_barrier(0);   // the fragments reuse registers the MFMAs above have just released
+  load_frags<8>(A, F + frag_map(4).base, mt + 4, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] += acc[r];
+    store_tile_frame_major(patch, v, lane, film_out + ((size_t)b * T + t0) * NWS_FILM_CH + 32 * mt, NWS_FILM_CH, frames_valid);
+    load_lane_params(v, w.newt_mlp_b[3], mt + 4, lane);
+    mma_tile1<8>(A, X, lane, acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] += acc[r];
+    store_tile_frame_major(patch, v, lane, film_out + ((size_t)b * T + t0) * NWS_FILM_CH + 32 * (mt + 4), NWS_FILM_CH,
+                           frames_valid);
+  } else {
+    // H (129 bands): M-tiles 0..3 from Y -> Z channels 0..127; wave 4 also M-tile 4 = row 128 (129..143 stay zero)
+    float vh[16];
+    load_lane_params(vh, w.hgen_b[3], mt, lane);
     const float b128 = w.hgen_b[3][128];
-    mma_tile2<8>(A0, X, acc_a, A1, Y, acc_b, lane);
-    load_frags<8>(A0, F + frag_map(4).base, wave + 4, lane);  // newt out, M-tile wave+4
-    if (wave == 0) load_frags<8>(A1, F + frag_map(8).base, 4, lane);  // hgen out, M-tile 4 = row 128
+    mma_tile1<8>(A, Y, lane, acc);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      v[r] += acc_a[r];
-      vh[r] += acc_b[r];
-    }
-    store_tile_frame_major(patch, v, lane, film_out + ((size_t)b * T + t0) * NWS_FILM_CH + 32 * wave, NWS_FILM_CH,
-                           frames_valid);
-    store_tile_xt(Z, 32 * wave, vh, lane);  // H -> Z channels 0..127 (129..143 stay zero: zero weights, zero bias)
-    if (H_out != nullptr && col < frames_valid) {
+    for (int r = 0; r < 16; ++r) vh[r] += acc[r];
+    store_tile_xt(Z, 32 * mt, vh, lane);
+    if (TAPS && H_out != nullptr && col < frames_valid) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) H_out[((size_t)b * T + t0 + col) * NWS_N_BANDS + 32 * wave + frag_row(r, half)] = vh[r];
+      for (int r = 0; r < 16; ++r) H_out[((size_t)b * T + t0 + col) * NWS_N_BANDS + 32 * mt + frag_row(r, half)] = vh[r];
     }
-    load_lane_params(v, w.newt_mlp_b[3], wave + 4, lane);   // behind the tile w+4 fragments, which the MFMAs below wait for anyway
-    if (wave == 0) {
-      mma_tile2<8>(A0, X, acc_a, A1, Y, acc_b, lane);
-    } else {
-      mma_tile<8>(A0, X, lane, acc_a);
-    }
-    load_frags<9>(A9a, F + frag_map(9).base, wave, lane);      // FIR design, M-tiles wave and wave+4
-    load_frags<9>(A9b, F + frag_map(9).base, wave + 4, lane);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] += acc_a[r];
-    store_tile_frame_major(patch, v, lane, film_out + ((size_t)b * T + t0) * NWS_FILM_CH + 32 * (wave + 4), NWS_FILM_CH,
-                           frames_valid);
-    if (wave == 0) {
+    if (mt == 0) {
+      // (its own fragment registers, live inside this block only: a conditional reload of A would keep the old contents alive)
+      AFrag<8> A4;
+      __builtin_amdgcn_sched_barrier(0);   // not above the MFMAs that still read A
+      load_frags<8>(A4, F + frag_map(8).base, 4, lane);
+      mma_tile1<8>(A4, Y, lane, acc);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = 128 + frag_row(r, half);
-        v[r] = c < NWS_N_BANDS ? acc_b[r] + b128 : 0.0f;   // only row 128 is real
-        if (H_out != nullptr && c < NWS_N_BANDS && col < frames_valid) H_out[((size_t)b * T + t0 + col) * NWS_N_BANDS + c] = v[r];
+        vh[r] = c < NWS_N_BANDS ? acc[r] + b128 : 0.0f;   // only row 128 is real
+        if (TAPS && H_out != nullptr && c < NWS_N_BANDS && col < frames_valid) H_out[((size_t)b * T + t0 + col) * NWS_N_BANDS + c] = vh[r];
       }
 #pragma unroll
       for (int g = 0; g < 2; ++g)  // rows 128..143 only: the XT row holds 144 channels
-        split4_store(Z, Z + kXtBytes, col, 128 + 8 * g + 4 * half, v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+        split4_store(Z, Z + kXtBytes, col, 128 + 8 * g + 4 * half, vh[4 * g], vh[4 * g + 1], vh[4 * g + 2], vh[4 * g + 3]);
     }
   }
+  AFrag<9> A9;
+  __builtin_amdgcn_sched_barrier(0);   // the fragments reuse registers the MFMAs above have just released
+  load_frags<9>(A9, F + frag_map(9).base, wave, lane);   // FIR design, M-tile `wave`
   __syncthreads();
 
-  // ---- fir = D * H  (256 taps = M-tiles w and w+4, K = 144 padded) ----
+  // ---- fir = D * H  (256 taps = 8 M-tiles, K = 144 padded); X is dead too: patches of waves 4-7 ----
   {
+    float* patch9 = path ? reinterpret_cast<float*>(X) + mt * (kFT * kPS) : patch;
     float v[16];
-    mma_tile2<9>(A9a, Z, acc_a, A9b, Z, acc_b, lane);
+    mma_tile1<9>(A9, Z, lane, acc);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = acc_a[r];
-    store_tile_frame_major(patch, v, lane, fir_out + ((size_t)b * T + t0) * NWS_FIR_LEN + 32 * wave, NWS_FIR_LEN,
-                           frames_valid);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = acc_b[r];
-    store_tile_frame_major(patch, v, lane, fir_out + ((size_t)b * T + t0) * NWS_FIR_LEN + 32 * (wave + 4), NWS_FIR_LEN,
-                           frames_valid);
+    for (int r = 0; r < 16; ++r) v[r] = acc[r];
+    store_tile_frame_major(patch9, v, lane, fir_out + ((size_t)b * T + t0) * NWS_FIR_LEN + 32 * wave, NWS_FIR_LEN, frames_valid);
   }
 }
 
@@ -670,14 +649,20 @@ int nws_frame_mlps(const NwsWeights* w, const float* gru_out, const float* fir_d
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_mlps_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpLds));
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_mlps16_kernel),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_mlps16_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpLds16));
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_mlps16_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpLds16));
     if (e != hipSuccess) return (int)e;
   }
   const dim3 grid((T + kFT - 1) / kFT, B);
-  if (w->mlp_frags != nullptr)
-    frame_mlps16_kernel<<<grid, 256, sizeof(MlpLds16), (hipStream_t)stream>>>(*w, gru_out, T, emb_out, film_out, H_out,
-                                                                              fir_out);
+  if (w->mlp_frags != nullptr && !emb_out && !H_out)
+    frame_mlps16_kernel<false><<<grid, 512, sizeof(MlpLds16), (hipStream_t)stream>>>(*w, gru_out, T, nullptr, film_out,
+                                                                                       nullptr, fir_out);
+  else if (w->mlp_frags != nullptr)
+    frame_mlps16_kernel<true><<<grid, 512, sizeof(MlpLds16), (hipStream_t)stream>>>(*w, gru_out, T, emb_out, film_out,
+                                                                                      H_out, fir_out);
   else
     frame_mlps_kernel<<<grid, 256, sizeof(MlpLds), (hipStream_t)stream>>>(*w, gru_out, fir_design, T, emb_out, film_out,
                                                                           H_out, fir_out);
