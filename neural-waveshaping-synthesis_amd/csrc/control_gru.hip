@@ -48,11 +48,21 @@ __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const
                                                              const float* __restrict__ h0, float* __restrict__ gru_out,
                                                              float* __restrict__ hT, const float* __restrict__ f0,
                                                              double* __restrict__ carry) {
+  const int tid = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float h_lds[2][kH];
+  __shared__ __attribute__((aligned(16))) float x_lds[2][kXChunk];  // control[:, 0:2] of the current chunk of frames
+  // fused control-rate prologue of a forward (nws_control_gru_carry): the oscillator phase carries of utterance b are the
+  // work of the EXTRA workgroup B + b of the same launch, on a CU of its own beside the recurrences (8 us there; as a
+  // prologue of the recurrence's own workgroup they delayed its first step by 19 us, as a separate 64-workgroup launch in
+  // front of it on the control stream by 70 us under load)
+  if (carry != nullptr && blockIdx.x >= gridDim.x / 2) {
+    nws_phase_carry_block<4>(f0, nullptr, T, carry, blockIdx.x - gridDim.x / 2, tid, reinterpret_cast<double*>(&x_lds[0][0]));
+    return;
+  }
   // latency-bound and usually sharing its SIMDs with throughput kernels of other streams (ForwardPipeline): ask for issue
   // priority, the recurrence is the critical path of the pipelined step
   __builtin_amdgcn_s_setprio(3);
   const int b = blockIdx.x;
-  const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int a = lane >> 5;
@@ -60,12 +70,6 @@ __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const
   const int ua = 32 * wave + 2 * (lane & 15);  // FMA phase: units ua and ua + 1
   const int unit = ua + a;                     // gate phase: this lane's unit
   const bool writer = (lane & 16) == 0;        // one of the two replicas stores
-
-  __shared__ __attribute__((aligned(16))) float h_lds[2][kH];
-  __shared__ __attribute__((aligned(16))) float x_lds[2][kXChunk];
-  // fused control-rate prologue of a forward: this utterance's oscillator phase carries (nws_control_gru_carry).  ~8 us here
-  // instead of a separate 64-workgroup launch in front of the recurrence on the control stream (70 us under load)
-  if (carry != nullptr) nws_phase_carry_block<4>(f0, nullptr, T, carry, b, tid, reinterpret_cast<double*>(&x_lds[0][0]));
 
   // wreg[u][g][c] = W_hh[g*128 + ua + u][32 sl + 2c, +1] (times the gate's constant, below)
   constexpr float kSig = -1.4426950408889634f, kTanh = 2.8853900817779268f;
@@ -363,7 +367,7 @@ extern "C" int nws_control_gru_carry(const NwsWeights* w, const float* control, 
   if (!w || !w->gru_w_ih || !w->gru_w_hh || !w->gru_b_ih || !w->gru_b_hh || !control || !gru_out || !f0 || !carry_out)
     return NWS_ERR_BAD_ARG;
   if (B <= 0 || T <= 0 || C < 2) return NWS_ERR_BAD_ARG;
-  control_gru_kernel<0><<<B, 256, 0, (hipStream_t)stream>>>(*w, control, C, T, nullptr, gru_out, nullptr, f0, carry_out);
+  control_gru_kernel<0><<<2 * B, 256, 0, (hipStream_t)stream>>>(*w, control, C, T, nullptr, gru_out, nullptr, f0, carry_out);
   NWS_CHECK_LAUNCH();
   return NWS_OK;
 }
