@@ -21,6 +21,7 @@ rocprofv3 --output-format csv --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_l2" --
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -- $P > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write" -- $P > "$OUT/pmc_write.log" 2>&1
 python tools/pmc_digest.py "$OUT" > "$OUT/digest.log" 2>&1
+python tools/rocprof_summary.py "$OUT/rocprofv3_kernel_stats_1stream.csv" "$OUT/rocprofv3_kernel_stats_default.csv" > "$OUT/rocprofv3_summary.txt" 2>> "$OUT/digest.log"
 # keep the merge-back small: the raw per-dispatch csv files are dropped, the digests stay
 find "$OUT" -name "*.db" -delete; find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*counter_collection.csv" -size +8M -delete
 ls -la "$OUT"

@@ -1,43 +1,31 @@
 #!/usr/bin/env python
-"""Condense rocprofv3 CSV output (kernel trace / counter collection) into a small text summary for profiles/."""
+"""rocprofv3 --kernel-trace --stats csv files of the two bench commands (one stream / default pipeline) -> one table of
+average kernel durations.  Usage: python tools/rocprof_summary.py <1stream.csv> <pipeline.csv> > rocprofv3_summary.txt"""
 import csv
-import glob
-import os
 import re
 import sys
-from collections import defaultdict
 
 
-def short(name):
-    name = re.sub(r"\(anonymous namespace\)::", "", name)
-    name = re.sub(r"\(.*", "", name)
-    name = re.sub(r"^void ", "", name)
-    return name[:70]
+def load(path):
+    rows = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            name = re.sub(r"^void ", "", r["Name"])
+            name = name.replace("(anonymous namespace)::", "")
+            name = name.split("(")[0][:60]
+            rows[name] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3,
+                          float(r["TotalDurationNs"]))
+    return rows
 
 
-def main(root, out):
-    lines = []
-    for path in sorted(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)):
-        agg = defaultdict(list)
-        for r in csv.DictReader(open(path)):
-            agg[(short(r["Kernel_Name"]), r.get("Grid_Size_X", "?"), r.get("Grid_Size_Y", "?"))].append(
-                (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-        lines.append(f"# kernel trace: {os.path.relpath(path, root)}  (durations in us)")
-        lines.append(f"{'kernel':70s} {'grid':>14s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'total_ms':>9s}")
-        for (k, gx, gy), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
-            lines.append(f"{k:70s} {gx + 'x' + gy:>14s} {len(v):6d} {sum(v) / len(v):10.2f} {min(v):10.2f} {max(v):10.2f} {sum(v) / 1e3:9.3f}")
-        lines.append("")
-    for path in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
-        agg = defaultdict(list)
-        for r in csv.DictReader(open(path)):
-            agg[(short(r["Kernel_Name"]), r.get("Grid_Size", "?"), r["Counter_Name"])].append(float(r["Counter_Value"]))
-        lines.append(f"# counters: {os.path.relpath(path, root)}  (per-dispatch averages)")
-        for (k, g, c), v in sorted(agg.items()):
-            lines.append(f"{k:70s} grid {g:>10s} {c:>14s} avg {sum(v) / len(v):16.1f} over {len(v)} dispatches")
-        lines.append("")
-    open(out, "w").write("\n".join(lines) + "\n")
-    print("\n".join(lines[:60]))
-
-
-if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+one, pipe = load(sys.argv[1]), load(sys.argv[2])
+print("# rocprofv3 --kernel-trace --stats, B=64 x T=500, vn checkpoint, FastNEWT, torch.rand inputs (tools/collect_profiles.sh)")
+print("# average kernel duration in us: one stream (undisturbed) | default pipeline (2 audio + 2 control streams, kernels of "
+      "neighbouring batches overlap)")
+for name in sorted(one, key=lambda n: -one[n][4]):
+    a = one[name]
+    b = pipe.get(name)
+    line = f"{name:60s} 1-stream: calls {a[0]:4d} avg {a[1]:8.1f} min {a[2]:8.1f} max {a[3]:8.1f}"
+    if b:
+        line += f" | pipeline: calls {b[0]:4d} avg {b[1]:8.1f} min {b[2]:8.1f} max {b[3]:8.1f}"
+    print(line)
