@@ -694,6 +694,15 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
   }
   const int frag_lane = half * 32 + col;
   const f32x2 ph2 = splat2(phase);
+  // rint(e P) for e = 0..7, P = phase / 2 pi = turns per harmonic number (shared integer parts of the sine reduction, below)
+  // (the FiLM-on-the-matrix-pipe variants, i.e. the product path; the round-1 VALU-FiLM form at 72 registers has no room)
+  constexpr bool kSharedTurns = (OPT & kOptFilmMfma) && !(OPT & kOptScalarSines);
+  f32x2 turns_e[4];
+  if (kSharedTurns) {
+    const float P = phase * 0.15915493667125702f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) turns_e[p] = f32x2{__builtin_rintf((float)(2 * p) * P), __builtin_rintf((float)(2 * p + 1) * P)};
+  }
   // one K-step; the first one starts the accumulators from the MFMA's inline-zero C operand (no 32 v_mov per wave)
   // how many fp16 terms the sines of K-step ks travel as (compile-time after unrolling): see Opt
   auto two_terms = [](const int ks) { return (OPT & kOptOneTerm) ? false : ((OPT & kOptHybrid) ? ks == 0 : true); };
@@ -723,8 +732,26 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
     const f32x2 sh2[4] = {{sh0.x, sh0.y}, {sh0.z, sh0.w}, {sh1.x, sh1.y}, {sh1.z, sh1.w}};
     const f32x2 kf2[4] = {{kf0.x, kf0.y}, {kf0.z, kf0.w}, {kf1.x, kf1.y}, {kf1.z, kf1.w}};
     f32x2 v2[4];
+    if (kSharedTurns && small_args && DBG != 1) {
+      // the lane's 8 consecutive harmonics: turns(k0 + e) = turns(k0) + e P + (shift differences, |.| < 1 turn), so
+      // n_e = rint(x_0 C_hi) + rint(e P) is within 2 of every x_e C_hi: one rint per K-step instead of eight, the reduced
+      // argument t_e = fma(x_e, C_hi, -n_e) + x_e C_lo is still the exact product minus an integer, now |t_e| < 2 (fp32
+      // spacing 2.4e-7 turns at worst; v_sin_f32 takes +-256 turns).  Against the per-sine rint of sin_turns2_fract:
+      // 0.2061 instead of 0.2212 ms (hybrid-W), 0.2713 instead of 0.2889 (two-term), outputs 5e-9 RMS apart (signal 2.9e-3)
+      const f32x2 c_hi = splat2(0.15915493667125702f), c_lo = splat2(6.4206382432985265e-09f);
+      f32x2 a2[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) v2[p] = sine_pair(kf2[p], sh2[p]);
+      for (int p = 0; p < 4; ++p) a2[p] = kf2[p] * ph2 + sh2[p];
+      const f32x2 n0 = splat2(__builtin_rintf(a2[0].x * 0.15915493667125702f));
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const f32x2 t = fma2(a2[p], c_lo, fma2(a2[p], c_hi, -(n0 + turns_e[p])));
+        v2[p] = f32x2{__builtin_amdgcn_sinf(t.x), __builtin_amdgcn_sinf(t.y)};
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) v2[p] = sine_pair(kf2[p], sh2[p]);
+    }
     if (!full) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
@@ -773,7 +800,20 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
     const bool full = all_live || __all(rem >= 4);
     const float4 sh = *reinterpret_cast<const float4*>(&L.shift[kk0]);
     const float4 kf = *reinterpret_cast<const float4*>(&L.kf[kk0]);
-    f32x2 v2[2] = {sine_pair(f32x2{kf.x, kf.y}, f32x2{sh.x, sh.y}), sine_pair(f32x2{kf.z, kf.w}, f32x2{sh.z, sh.w})};
+    f32x2 v2[2];
+    if (kSharedTurns && small_args && DBG != 1) {
+      const f32x2 c_hi = splat2(0.15915493667125702f), c_lo = splat2(6.4206382432985265e-09f);
+      const f32x2 a2[2] = {f32x2{kf.x, kf.y} * ph2 + f32x2{sh.x, sh.y}, f32x2{kf.z, kf.w} * ph2 + f32x2{sh.z, sh.w}};
+      const f32x2 n0 = splat2(__builtin_rintf(a2[0].x * 0.15915493667125702f));
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const f32x2 t = fma2(a2[p], c_lo, fma2(a2[p], c_hi, -(n0 + turns_e[p])));
+        v2[p] = f32x2{__builtin_amdgcn_sinf(t.x), __builtin_amdgcn_sinf(t.y)};
+      }
+    } else {
+      v2[0] = sine_pair(f32x2{kf.x, kf.y}, f32x2{sh.x, sh.y});
+      v2[1] = sine_pair(f32x2{kf.z, kf.w}, f32x2{sh.z, sh.w});
+    }
     if (!full) {
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
