@@ -1,0 +1,14 @@
+#!/bin/bash
+# Copy what tools/evidence_run.sh left under gpurun_out/ (merged back from the GPU box) into profiles/<round>/ (tracked).
+R=${1:-r02}
+D=profiles/$R
+mkdir -p "$D"
+for f in bench_default bench_two_term bench_realistic_inputs bench_exact_shapers bench_world1_rccl bench_world1_copy bench_driver_k20; do
+  tail -1 gpurun_out/ev/$f.json > "$D/$f.json"
+done
+cp gpurun_out/ev/exciter_variants.txt gpurun_out/ev/gru_variants.txt "$D/"
+cp gpurun_out/parity_report.json "$D/parity_report.json"
+cp gpurun_out/prof_$R/pmc_kernels.json gpurun_out/prof_$R/pmc_digest.txt gpurun_out/prof_$R/pmc_traffic.json gpurun_out/prof_$R/rocprofv3_summary.txt "$D/"
+cp gpurun_out/prof_$R/rocprofv3_kernel_stats_1stream.csv "$D/rocprofv3_kernel_stats_1stream.csv"
+cp gpurun_out/prof_$R/rocprofv3_kernel_stats_default.csv "$D/rocprofv3_kernel_stats_default_pipeline.csv"
+grep -E "passed|failed" gpurun_out/ev/pytest_gpu.txt | tail -1 > "$D/pytest_gpu_summary.txt"
