@@ -157,8 +157,8 @@ int nws_control_gru(const NwsWeights* w, const float* control, int B, int C, int
  * stateful streaming; the reference's forward is the h0 = 0 case */
 int nws_control_gru_state(const NwsWeights* w, const float* control, int B, int C, int T, const float* h0, float* gru_out,
                           float* hT, void* stream);
-/* nws_control_gru + nws_phase_carry in ONE launch (each GRU workgroup first computes its utterance's carries): the
- * control-rate half of a forward; f0 (B,T) Hz, carry_out (B, 4T) doubles */
+/* nws_control_gru + nws_phase_carry in ONE launch (grid 2B: B workgroups run the recurrences, B more compute the carries
+ * beside them): the control-rate half of a forward; f0 (B,T) Hz, carry_out (B, 4T) doubles */
 int nws_control_gru_carry(const NwsWeights* w, const float* control, const float* f0, int B, int C, int T, float* gru_out,
                           double* carry_out, void* stream);
 /* the same recurrence, 16 utterances per workgroup on the matrix cores (fp16 two-term split, fp32 accumulate): ~2x the
