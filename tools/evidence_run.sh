@@ -11,6 +11,9 @@ NWS_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --gather rccl > gpurun_
 NWS_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --gather copy > gpurun_out/ev/bench_world1_copy.json 2>/dev/null
 VARIANTS=12,20,36 python tools/exciter_variants.py > gpurun_out/ev/exciter_variants.txt 2>&1
 python tools/gru_variants.py > gpurun_out/ev/gru_variants.txt 2>&1
+python scripts/time_buffer_sizes.py --use-fast-newt --checkpoint tests/golden/weights_vn.npz 2>/dev/null | grep '^buffer' > gpurun_out/ev/buffer_fast.txt
+python scripts/time_buffer_sizes.py --checkpoint tests/golden/weights_vn.npz 2>/dev/null | grep '^buffer' > gpurun_out/ev/buffer_exact.txt
+python scripts/time_streaming.py 2>/dev/null | grep '^stateful' > gpurun_out/ev/streaming_stateful.txt
 bash tools/collect_profiles.sh r02 > gpurun_out/ev/collect.log 2>&1
 ls gpurun_out/prof_r02 | head -30
 du -sh gpurun_out

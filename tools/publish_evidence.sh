@@ -12,3 +12,5 @@ cp gpurun_out/prof_$R/pmc_kernels.json gpurun_out/prof_$R/pmc_digest.txt gpurun_
 cp gpurun_out/prof_$R/rocprofv3_kernel_stats_1stream.csv "$D/rocprofv3_kernel_stats_1stream.csv"
 cp gpurun_out/prof_$R/rocprofv3_kernel_stats_default.csv "$D/rocprofv3_kernel_stats_default_pipeline.csv"
 grep -E "passed|failed" gpurun_out/ev/pytest_gpu.txt | tail -1 > "$D/pytest_gpu_summary.txt"
+cat gpurun_out/ev/buffer_fast.txt gpurun_out/ev/buffer_exact.txt gpurun_out/ev/streaming_stateful.txt > "$D/buffer_sizes_summary.txt"
+python tools/buffer_sizes_digest.py gpurun_out/ev/buffer_fast.txt gpurun_out/ev/buffer_exact.txt > "$D/buffer_sizes.csv"
