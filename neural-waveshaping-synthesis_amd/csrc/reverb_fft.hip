@@ -460,6 +460,45 @@ __global__ void reverb_tail_kernel(const float* __restrict__ x, const float* __r
   }
 }
 
+// ---- short buffers: the circular convolution in the time domain ----
+// y[n] = x[n] + sum_{k<N} x[k] irz[(n - k) mod L], irz = [0, ir] zero-padded to L (kept behind the spectrum).  For the
+// short streaming buffers of scripts/time_buffer_sizes.py (N <= 1024 << L = 32000) that is N^2 MACs from LDS in ONE launch
+// instead of three latency-bound FFT passes over 32000 points.  Four partial sums per thread; a direct fp32 sum of <= 1024
+// products is at least as close to the reference's result as a fp32 FFT.
+constexpr int kDirectMaxN = 1024;
+__global__ __launch_bounds__(256) void reverb_direct_kernel(const float* __restrict__ x, const float* __restrict__ irz, int N,
+                                                            int L, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* xs = reinterpret_cast<float*>(smem_raw);   // N inputs
+  float* hs = xs + N;                               // hs[d + N] = irz[d mod L] for the lags d = n - k in (-N, N)
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int n = blockIdx.x * 256 + tid;
+  for (int i = tid; i < N; i += 256) xs[i] = x[(size_t)b * N + i];
+  for (int i = tid; i < 2 * N; i += 256) {
+    const int d = i - N;
+    hs[i] = irz[d >= 0 ? d : d + L];
+  }
+  __syncthreads();
+  if (n >= N) return;
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  const float* h = hs + n + N;   // h[-k] = irz[(n - k) mod L]
+  int k = 0;
+  for (; k + 3 < N; k += 4) {
+    a0 = fmaf(xs[k], h[-k], a0);
+    a1 = fmaf(xs[k + 1], h[-k - 1], a1);
+    a2 = fmaf(xs[k + 2], h[-k - 2], a2);
+    a3 = fmaf(xs[k + 3], h[-k - 3], a3);
+  }
+  for (; k < N; ++k) a0 = fmaf(xs[k], h[-k], a0);
+  y[(size_t)b * N + n] = xs[n] + ((a0 + a1) + (a2 + a3));
+}
+
+// irz = [0, ir] zero-padded to L
+__global__ void build_irz_kernel(const float* __restrict__ ir, int ir_len, int L, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < L) out[i] = (i >= 1 && i <= ir_len) ? ir[i - 1] : 0.0f;
+}
+
 bool plan_ok(const NwsReverbPlan* p) {
   return p && p->L > 0 && p->N1 > 0 && p->N2 >= 32 && p->N2 <= 1024 && (p->N2 & (p->N2 - 1)) == 0 &&
          (long long)p->N1 * p->N2 == p->L;
@@ -491,7 +530,7 @@ size_t nws_reverb_table_bytes(const NwsReverbPlan* plan) {
 
 size_t nws_reverb_spectrum_bytes(const NwsReverbPlan* plan) {
   if (!plan_ok(plan)) return 0;
-  return 2 * (size_t)plan->L * sizeof(float);
+  return 3 * (size_t)plan->L * sizeof(float);   // Sre | Sim | irz (time domain, for the direct form of short buffers)
 }
 
 size_t nws_reverb_workspace_bytes(const NwsReverbPlan* plan, int B) {
@@ -550,6 +589,8 @@ int nws_reverb_ir_spectrum(const NwsReverbPlan* plan, const void* tables, const 
   float* Sim = Sre + d.L;
   build_ir_kernel<<<(ir_len + 1 + 255) / 256, 256, 0, st>>>(ir, ir_len, irp);
   NWS_CHECK_LAUNCH();
+  build_irz_kernel<<<(d.L + 255) / 256, 256, 0, st>>>(ir, ir_len, d.L, Sim + d.L);
+  NWS_CHECK_LAUNCH();
   if (d.N1 == 125) {
     col125_fwd_kernel<<<dim3(d.N2 / 32, 1), 256, kCol125Lds, st>>>(d, reinterpret_cast<const float2*>(t + off_tw125(d)),
                                                                     irp, 1, ir_len + 1, 0, Ure, Uim);
@@ -580,6 +621,11 @@ int nws_reverb(const NwsReverbPlan* plan, const void* tables, const void* spectr
   float* Uim = Ure + (size_t)pairs * d.L;
   const float* Sre = static_cast<const float*>(spectrum);
   const float* Sim = Sre + d.L;
+  if (N <= kDirectMaxN && B <= 65535) {
+    reverb_direct_kernel<<<dim3((N + 255) / 256, B), 256, (size_t)3 * N * sizeof(float), st>>>(x, Sim + d.L, N, d.L, y);
+    NWS_CHECK_LAUNCH();
+    return NWS_OK;
+  }
 
   const float2* tw125 = reinterpret_cast<const float2*>(t + off_tw125(d));
   if (d.N1 == 125) {
