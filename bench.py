@@ -551,7 +551,11 @@ def main():
                                             "pipe): algorithmic flop / live kernel time against the dense fp16 MFMA peak"},
                     "mfma_f16_executed": dom.get("mfma_f16_executed"), "hbm": dom.get("hbm"),
                     "valu_insts_per_wave": (vi or {}).get("insts_per_wave"), "counters": pmc_src if pmc else None,
-                    "gru_ms_in_timed_region": gru_ms_live}
+                    "gru_ms_in_timed_region": gru_ms_live,
+                    "note": "frac = VALU-busy SIMD-cycles per launch (PMC pass of the committed profile) / the kernel's LIVE "
+                            "duration inside the pipelined timed region (HIP events on its launch stream), where it shares the "
+                            "chip with the neighbouring batch's kernels; frac_isolated = the same cycles over the undisturbed "
+                            "one-stream duration; frac_at_clock_of_pmc_pass = busy share of the kernel's own cycles in the PMC pass"}
         roofline_all = [dom]
         if st:
             roofline_all += [
