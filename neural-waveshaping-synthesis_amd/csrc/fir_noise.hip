@@ -164,17 +164,15 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_f32(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
 }
-// maximum of non-negative values over the wave, valid in lane 63 (DPP: no LDS round trips; 0 is the identity)
-__device__ __forceinline__ float wave_max_to_lane63(float v) {
+// maximum of non-negative values over each 32-lane half of the wave, in every lane of the half
+__device__ __forceinline__ float half_max(float v) {
   v = fmaxf(v, dpp_f32<0xb1, 0xf>(v));   // quad_perm [1,0,3,2]
   v = fmaxf(v, dpp_f32<0x4e, 0xf>(v));   // quad_perm [2,3,0,1]
   v = fmaxf(v, dpp_f32<0x141, 0xf>(v));  // row_half_mirror
-  v = fmaxf(v, dpp_f32<0x140, 0xf>(v));  // row_mirror
-  v = fmaxf(v, dpp_f32<0x142, 0xa>(v));  // row_bcast15 -> rows 1, 3
-  v = fmaxf(v, dpp_f32<0x143, 0xc>(v));  // row_bcast31 -> rows 2, 3
-  return v;
+  v = fmaxf(v, dpp_f32<0x140, 0xf>(v));  // row_mirror: every lane holds its 16-lane row's maximum
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));   // rows 0|1 and 2|3 exchanged: the half's maximum
 }
-
 __global__ __launch_bounds__(256, 4) void fir_noise_mfma_kernel(const float* __restrict__ fir, const float* __restrict__ noise,
                                                                 const float* __restrict__ add_in, int B, int T, int len,
                                                                 int origin, float* __restrict__ out) {
@@ -184,14 +182,20 @@ __global__ __launch_bounds__(256, 4) void fir_noise_mfma_kernel(const float* __r
   const int t = blockIdx.x, b0 = blockIdx.y * kUtt;
   const int N = T * kHop;
 
-  // taps: wave w covers rows r = w + 4 it (it = 0..7), one float4 per lane: coalesced 1 KB rows
+  // taps: wave w covers rows r = w + 4 q (q = 0..7).  One load instruction fetches HALF rows of TWO rows: lanes 0..31 the
+  // taps [128 h + 4 p, +4) of row w + 4 (2 it), lanes 32..63 the same taps of row w + 4 (2 it + 1); v[it] holds the first
+  // halves (h = 0), v[it + 4] the second.  Staging a half frame then has all 64 lanes busy (a row per instruction left 32
+  // idle in every one of the 416 staging instructions), and the per-row scale search runs on two rows at once.
+  const int p32 = lane & 31;
+  const int my_row = wave + 4 * kh;   // this lane's row of it = 0; row(it) = wave + 4 (2 it + kh) = my_row + 8 it
   auto load_rows = [&](int frame, float4 (&v)[8]) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int b = b0 + wave + 4 * it;
-      v[it] = (frame >= 0 && frame < T && b < B)
-                  ? *reinterpret_cast<const float4*>(&fir[((size_t)b * T + frame) * kL + 4 * lane])
-                  : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int it = 0; it < 4; ++it) {
+      const int b = b0 + my_row + 8 * it;
+      const bool ok = frame >= 0 && frame < T && b < B;
+      const float* src = &fir[((size_t)b * T + frame) * kL + 4 * p32];
+      v[it] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      v[it + 4] = ok ? *reinterpret_cast<const float4*>(src + kL / 2) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
   };
   float4 cur[8], prv[8];
@@ -206,16 +210,16 @@ __global__ __launch_bounds__(256, 4) void fir_noise_mfma_kernel(const float* __r
 
   // one power-of-two scale per utterance (both frames): largest |tap| -> [2^14, 2^15).  Keeps hi AND lo of every tap that
   // matters clear of the fp16 subnormals whatever the filter gain (-120 dB noise floors included); exact to undo.
-  float scale[8];
+  float scale[4];   // of row my_row + 8 it (each 32-lane half has its own rows)
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    float mx = fmaxf(fmaxf(fmaxf(fabsf(cur[it].x), fabsf(cur[it].y)), fmaxf(fabsf(cur[it].z), fabsf(cur[it].w))),
-                     fmaxf(fmaxf(fabsf(prv[it].x), fabsf(prv[it].y)), fmaxf(fabsf(prv[it].z), fabsf(prv[it].w))));
-    mx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_max_to_lane63(mx)), 63));
-    int ex = (int)((__float_as_uint(mx) >> 23) & 0xff);  // biased exponent of the row maximum (wave-uniform)
+  for (int it = 0; it < 4; ++it) {
+    auto amax4 = [](const float4& a) { return fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))); };
+    float mx = fmaxf(fmaxf(amax4(cur[it]), amax4(cur[it + 4])), fmaxf(amax4(prv[it]), amax4(prv[it + 4])));
+    mx = half_max(mx);   // over the 32 lanes that hold this row
+    int ex = (int)((__float_as_uint(mx) >> 23) & 0xff);  // biased exponent of the row maximum
     ex = ex < 16 ? 16 : (ex > 250 ? 250 : ex);
     scale[it] = __uint_as_float((unsigned)(268 - ex) << 23);          // 2^(14 - e)
-    if (lane == 0) L.unscale[wave + 4 * it] = __uint_as_float((unsigned)(ex - 14) << 23) * (1.0f / kNoiseScale);  // 2^(e - 14) / 2^10
+    if (p32 == 0) L.unscale[my_row + 8 * it] = __uint_as_float((unsigned)(ex - 14) << 23) * (1.0f / kNoiseScale);  // 2^(e - 14) / 2^10
   }
   __syncthreads();  // win complete
 
@@ -240,17 +244,17 @@ __global__ __launch_bounds__(256, 4) void fir_noise_mfma_kernel(const float* __r
     *reinterpret_cast<f16x8*>(&L.rhi[fr][c][v0]) = h8;
     *reinterpret_cast<f16x8*>(&L.rlo[fr][c][v0]) = l8;
   }
-  auto stage_rows = [&](const float4 (&v)[8], const int khalf) {  // taps [128 khalf, 128 khalf + 128): lanes 32 khalf .. +31
-    if ((lane >> 5) != khalf) return;
+  auto stage_rows = [&](const float4 (&v)[8], const int khalf) {  // taps [128 khalf, 128 khalf + 128) of all 32 rows
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int r = wave + 4 * it;
+    for (int it = 0; it < 4; ++it) {
+      const int r = my_row + 8 * it;
+      const float4 t4 = v[it + 4 * khalf];
       f16x2 h01, l01, h23, l23;
-      split16x2(v[it].x * scale[it], v[it].y * scale[it], h01, l01);
-      split16x2(v[it].z * scale[it], v[it].w * scale[it], h23, l23);
+      split16x2(t4.x * scale[it], t4.y * scale[it], h01, l01);
+      split16x2(t4.z * scale[it], t4.w * scale[it], h23, l23);
       const f16x4 h = {h01.x, h01.y, h23.x, h23.y}, l = {l01.x, l01.y, l23.x, l23.y};
-      *reinterpret_cast<f16x4*>(&L.hhi[r][4 * (lane & 31)]) = h;
-      *reinterpret_cast<f16x4*>(&L.hlo[r][4 * (lane & 31)]) = l;
+      *reinterpret_cast<f16x4*>(&L.hhi[r][4 * p32]) = h;
+      *reinterpret_cast<f16x4*>(&L.hlo[r][4 * p32]) = l;
     }
   };
   stage_rows(cur, 0);
