@@ -22,6 +22,7 @@ m = nws.NeuralWaveshaping.load_from_checkpoint(os.path.join(ROOT, "tests/golden/
 m.newt = nws.FastNEWT(m.newt)
 B, T, K = 64, 500, int(os.environ.get("K", 200))
 what = os.environ.get("WHAT", "none")
+NSLOT = int(os.environ.get("NSLOT", 4))
 n_audio = int(os.environ.get("AUDIO_STREAMS", 2))
 eng = m._engine
 torch.manual_seed(0)
@@ -49,7 +50,7 @@ with torch.no_grad():
                     if what in ("gru", "all"):
                         eng.forward_control(f0, control, spare[i % 4], batched_gru=False)
             with torch.cuda.stream(streams[i % n_audio]):
-                eng.forward_audio(f0, B, T, pu, nz, slots[i % 4], out=outs[i % 4])
+                eng.forward_audio(f0, B, T, pu, nz, slots[i % NSLOT], out=outs[i % NSLOT])
         host = (time.perf_counter() - t0) / K * 1e3
         torch.cuda.synchronize()
         el = (time.perf_counter() - t0) / K * 1e3
