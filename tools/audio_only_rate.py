@@ -39,7 +39,11 @@ with torch.no_grad():
         eng.forward_control(f0, control, ws)
     outs = [torch.empty(B, 128 * T, device="cuda") for _ in slots]
     torch.cuda.synchronize()
+    delay_us = float(os.environ.get("DELAY_US", 0))   # once per repetition: stream 1 starts this much later (phase probe)
     for rep in range(4):
+        if delay_us and n_audio > 1:
+            with torch.cuda.stream(streams[1]):
+                torch.cuda._sleep(int(delay_us * 2400))
         t0 = time.perf_counter()
         for i in range(K):
             if side is not None:
