@@ -214,7 +214,8 @@ size_t nws_reverb_table_bytes(const NwsReverbPlan* plan);
 size_t nws_reverb_spectrum_bytes(const NwsReverbPlan* plan);
 size_t nws_reverb_workspace_bytes(const NwsReverbPlan* plan, int B);
 int nws_reverb_build_tables(const NwsReverbPlan* plan, void* tables, void* stream);
-/* spectrum of ir_ = [0, ir] zero-padded to L, in the engine's own (k1,k2) order */
+/* spectrum of ir_ = [0, ir] zero-padded to L, in the engine's own (k1,k2) order; the buffer (nws_reverb_spectrum_bytes =
+ * 3 L floats) holds Sre | Sim | ir_ itself, which nws_reverb uses for buffers of <= 1024 samples (time-domain form) */
 int nws_reverb_ir_spectrum(const NwsReverbPlan* plan, const void* tables, const float* ir, int ir_len,
                            void* spectrum, void* workspace, size_t workspace_bytes, void* stream);
 int nws_reverb(const NwsReverbPlan* plan, const void* tables, const void* spectrum, const float* x /* (B,N) */,

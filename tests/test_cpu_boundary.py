@@ -57,7 +57,7 @@ def test_reverb_plan_is_host_only(N, L, N1, N2):
     assert _lib.lib().nws_reverb_plan(N, 32000, C.byref(plan)) == 0
     assert (plan.L, plan.N1, plan.N2) == (L, N1, N2)
     assert _lib.lib().nws_reverb_workspace_bytes(C.byref(plan), 3) == max(2 * 2 * L, 3 * L) * 4
-    assert _lib.lib().nws_reverb_spectrum_bytes(C.byref(plan)) == 2 * L * 4
+    assert _lib.lib().nws_reverb_spectrum_bytes(C.byref(plan)) == 3 * L * 4   # Sre | Sim | [0, ir] in the time domain (short-buffer form)
 
 
 def test_reverb_plan_rejects_unsupported_lengths():
