@@ -119,6 +119,11 @@ __device__ __forceinline__ void dft5(float2 (&v)[5]) {
 }
 
 // three Stockham radix-5 stages over bufA -> bufB -> bufA -> bufB; returns with the result in bufB (natural order)
+// kColThreads = 800 = 25 x 32: one radix-5 butterfly per thread and stage (25 butterflies x 32 columns), 5 elements per
+// thread for the loads and stores - the tile's work divides exactly, and a CU holds 2 x 12.5 waves instead of 2 x 4 (the
+// 256-thread form ran the 25 butterflies of a column on 8 thread groups: 4 rounds, the last one 1/8 occupied)
+constexpr int kColThreads = 800;
+constexpr int kColPer = 125 * 32 / kColThreads;   // 5
 template <bool INVERSE>
 __device__ __forceinline__ void fft125_tile(float2* bufA, float2* bufB, const float2* tw125, int tid) {
   const int c = tid & 31, g = tid >> 5;
@@ -127,7 +132,7 @@ __device__ __forceinline__ void fft125_tile(float2* bufA, float2* bufB, const fl
 #pragma unroll
   for (int Ns = 1; Ns < 125; Ns *= 5) {
     const int twstep = 25 / Ns;
-    for (int j = g; j < 25; j += 8) {
+    for (int j = g; j < 25; j += kColThreads / 32) {
       const int k = j % Ns;
       float2 v[5];
 #pragma unroll
@@ -151,7 +156,7 @@ __device__ __forceinline__ void fft125_tile(float2* bufA, float2* bufB, const fl
   }
 }
 
-__global__ __launch_bounds__(256) void col125_fwd_kernel(PlanDev d, const float2* __restrict__ tw125_g,
+__global__ __launch_bounds__(kColThreads) void col125_fwd_kernel(PlanDev d, const float2* __restrict__ tw125_g,
                                                          const float* __restrict__ x, int B, int N, long long x_stride,
                                                          float* __restrict__ Ure, float* __restrict__ Uim) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -164,35 +169,32 @@ __global__ __launch_bounds__(256) void col125_fwd_kernel(PlanDev d, const float2
   if (tid < 125) tw125[tid] = tw125_g[tid];
   const float* x0 = 2 * p < B ? x + (size_t)(2 * p) * x_stride : nullptr;
   const float* x1 = 2 * p + 1 < B ? x + (size_t)(2 * p + 1) * x_stride : nullptr;
-  // 16 rows per thread, all loads issued before the first LDS write (memory-latency bound: bytes in flight are what counts)
+  // all loads issued before the first LDS write (memory-latency bound: bytes in flight are what counts)
   {
-    float2 v[16];
+    float2 v[kColPer];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int e = tid + 256 * i;
+    for (int i = 0; i < kColPer; ++i) {
+      const int e = tid + kColThreads * i;
       const long long n = (long long)d.N2 * (e >> 5) + c0 + (e & 31);
-      const bool in = e < 125 * 32 && n < N;
+      const bool in = n < N;
       v[i] = make_float2((in && x0) ? x0[n] : 0.0f, (in && x1) ? x1[n] : 0.0f);
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-      if (tid + 256 * i < 125 * 32) bufA[tid + 256 * i] = v[i];
+    for (int i = 0; i < kColPer; ++i) bufA[tid + kColThreads * i] = v[i];
   }
   __syncthreads();
   fft125_tile<false>(bufA, bufB, tw125, tid);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int e = tid + 256 * i;
-    if (e < 125 * 32) {
-      const size_t o = ((size_t)p * 125 + (e >> 5)) * d.N2 + c0 + (e & 31);
-      const float2 v = bufB[e];
-      Ure[o] = v.x;
-      Uim[o] = v.y;
-    }
+  for (int i = 0; i < kColPer; ++i) {
+    const int e = tid + kColThreads * i;
+    const size_t o = ((size_t)p * 125 + (e >> 5)) * d.N2 + c0 + (e & 31);
+    const float2 v = bufB[e];
+    Ure[o] = v.x;
+    Uim[o] = v.y;
   }
 }
 
-__global__ __launch_bounds__(256) void col125_inv_kernel(PlanDev d, const float2* __restrict__ tw125_g,
+__global__ __launch_bounds__(kColThreads) void col125_inv_kernel(PlanDev d, const float2* __restrict__ tw125_g,
                                                          const float* __restrict__ Ure, const float* __restrict__ Uim,
                                                          const float* __restrict__ x, int B, int N,
                                                          float* __restrict__ y) {
@@ -205,24 +207,23 @@ __global__ __launch_bounds__(256) void col125_inv_kernel(PlanDev d, const float2
   const int c0 = blockIdx.x * 32;
   if (tid < 125) tw125[tid] = tw125_g[tid];
   {
-    float2 v[16];
+    float2 v[kColPer];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int e = tid + 256 * i;
+    for (int i = 0; i < kColPer; ++i) {
+      const int e = tid + kColThreads * i;
       const size_t o = ((size_t)p * 125 + (e >> 5)) * d.N2 + c0 + (e & 31);
-      v[i] = e < 125 * 32 ? make_float2(Ure[o], Uim[o]) : make_float2(0.0f, 0.0f);
+      v[i] = make_float2(Ure[o], Uim[o]);
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-      if (tid + 256 * i < 125 * 32) bufA[tid + 256 * i] = v[i];
+    for (int i = 0; i < kColPer; ++i) bufA[tid + kColThreads * i] = v[i];
   }
   const int rows_out = (N + d.N2 - 1) / d.N2;
   const bool has1 = 2 * p + 1 < B;
   // the dry signal is independent of the transform: fetch it before the FFT so that its latency hides under it
-  float dry0[16], dry1[16];
+  float dry0[kColPer], dry1[kColPer];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int e = tid + 256 * i;
+  for (int i = 0; i < kColPer; ++i) {
+    const int e = tid + kColThreads * i;
     const long long n = (long long)d.N2 * (e >> 5) + c0 + (e & 31);
     const bool in = x != nullptr && e < rows_out * 32 && n < N;
     const size_t o0 = (size_t)(2 * p) * N + n;
@@ -232,8 +233,8 @@ __global__ __launch_bounds__(256) void col125_inv_kernel(PlanDev d, const float2
   __syncthreads();
   fft125_tile<true>(bufA, bufB, tw125, tid);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int e = tid + 256 * i;
+  for (int i = 0; i < kColPer; ++i) {
+    const int e = tid + kColThreads * i;
     const long long n = (long long)d.N2 * (e >> 5) + c0 + (e & 31);
     if (e < rows_out * 32 && n < N) {
       const float2 v = bufB[e];
@@ -592,7 +593,7 @@ int nws_reverb_ir_spectrum(const NwsReverbPlan* plan, const void* tables, const 
   build_irz_kernel<<<(d.L + 255) / 256, 256, 0, st>>>(ir, ir_len, d.L, Sim + d.L);
   NWS_CHECK_LAUNCH();
   if (d.N1 == 125) {
-    col125_fwd_kernel<<<dim3(d.N2 / 32, 1), 256, kCol125Lds, st>>>(d, reinterpret_cast<const float2*>(t + off_tw125(d)),
+    col125_fwd_kernel<<<dim3(d.N2 / 32, 1), kColThreads, kCol125Lds, st>>>(d, reinterpret_cast<const float2*>(t + off_tw125(d)),
                                                                     irp, 1, ir_len + 1, 0, Ure, Uim);
   } else {
     const dim3 g1(d.N2 / 32, (d.M2 / 32 + 3) / 4, 1);
@@ -629,7 +630,7 @@ int nws_reverb(const NwsReverbPlan* plan, const void* tables, const void* spectr
 
   const float2* tw125 = reinterpret_cast<const float2*>(t + off_tw125(d));
   if (d.N1 == 125) {
-    col125_fwd_kernel<<<dim3(d.N2 / 32, pairs), 256, kCol125Lds, st>>>(d, tw125, x, B, N, (long long)N, Ure, Uim);
+    col125_fwd_kernel<<<dim3(d.N2 / 32, pairs), kColThreads, kCol125Lds, st>>>(d, tw125, x, B, N, (long long)N, Ure, Uim);
   } else {
     const dim3 g1(d.N2 / 32, (d.M2 / 32 + 3) / 4, pairs);
     col_fwd_kernel<<<g1, 256, 0, st>>>(t + off_afwd(d), d, x, B, N, (long long)N, Ure, Uim);
@@ -641,7 +642,7 @@ int nws_reverb(const NwsReverbPlan* plan, const void* tables, const void* spectr
                                                        nullptr, nullptr);
   NWS_CHECK_LAUNCH();
   if (d.N1 == 125) {
-    col125_inv_kernel<<<dim3(d.N2 / 32, pairs), 256, kCol125Lds, st>>>(d, tw125, Ure, Uim, x, B, N, y);
+    col125_inv_kernel<<<dim3(d.N2 / 32, pairs), kColThreads, kCol125Lds, st>>>(d, tw125, Ure, Uim, x, B, N, y);
   } else {
     const int rows_out = (N + d.N2 - 1) / d.N2;
     const int nt = (rows_out + 31) / 32;
@@ -672,7 +673,7 @@ int nws_reverb_linear_chunk(const NwsReverbPlan* plan, const void* tables, const
   const float* Sim = Sre + d.L;
   const float2* tw125 = reinterpret_cast<const float2*>(t + off_tw125(d));
   if (d.N1 == 125) {
-    col125_fwd_kernel<<<dim3(d.N2 / 32, pairs), 256, kCol125Lds, st>>>(d, tw125, x, B, M, (long long)M, Ure, Uim);
+    col125_fwd_kernel<<<dim3(d.N2 / 32, pairs), kColThreads, kCol125Lds, st>>>(d, tw125, x, B, M, (long long)M, Ure, Uim);
   } else {
     const dim3 g1(d.N2 / 32, (d.M2 / 32 + 3) / 4, pairs);
     col_fwd_kernel<<<g1, 256, 0, st>>>(t + off_afwd(d), d, x, B, M, (long long)M, Ure, Uim);
@@ -683,7 +684,7 @@ int nws_reverb_linear_chunk(const NwsReverbPlan* plan, const void* tables, const
                                                                       Sim, nullptr, nullptr);
   NWS_CHECK_LAUNCH();
   if (d.N1 == 125) {
-    col125_inv_kernel<<<dim3(d.N2 / 32, pairs), 256, kCol125Lds, st>>>(d, tw125, Ure, Uim, nullptr, B, d.L, wet);
+    col125_inv_kernel<<<dim3(d.N2 / 32, pairs), kColThreads, kCol125Lds, st>>>(d, tw125, Ure, Uim, nullptr, B, d.L, wet);
   } else {
     const int nt = (d.N1 + 31) / 32;
     const dim3 g3(d.N2 / 32, (2 * nt + 3) / 4, pairs);
