@@ -512,6 +512,32 @@ def main():
             extra["streaming_hop256_hipgraph"] = {"p50_us": round(float(np.percentile(lat, 50)), 2),
                                                   "p99_us": round(float(np.percentile(lat, 99)), 2),
                                                   "buffer_period_us": 16000.0}
+            # the same B=1 clip as `batch1`, the forward (its two RNG draws included) captured once into a hipGraph: what a
+            # serving loop with fixed shapes pays per clip without the seven launch gaps of the eager call
+            f1, c1 = f0[:1].contiguous(), control[:1].contiguous()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    model(f1, c1)
+            torch.cuda.current_stream().wait_stream(side)
+            graph1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph1):
+                model(f1, c1)
+            for _ in range(10):
+                graph1.replay()
+            torch.cuda.synchronize()
+            lat = []
+            for _ in range(a.batch1_iters):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                graph1.replay()
+                e1.record()
+                e1.synchronize()
+                lat.append(e0.elapsed_time(e1))
+            dur_ms = N / 16000.0 * 1e3
+            extra["batch1_hipgraph"] = {"p50_ms": round(float(np.percentile(lat, 50)), 4),
+                                        "p90_ms": round(float(np.percentile(lat, 90)), 4),
+                                        "x_realtime_p50": round(dur_ms / float(np.percentile(lat, 50)), 1)}
     if rank == 0:
         total_samples = B * world * N * a.steps
         value = total_samples / elapsed
