@@ -387,7 +387,8 @@ def test_fir_noise_batched_mfma_path(models, oracle, B, T):
     assert maxabs(out2, add.cpu().numpy() + out) <= 1e-6
 
 
-@pytest.mark.parametrize("N", [256, 4096, 32000, 64000, 128 * 501])
+# 256, 640, 1024: the time-domain form of short buffers (csrc/reverb_fft.hip reverb_direct_kernel); 1152 and up: the FFT
+@pytest.mark.parametrize("N", [256, 640, 1024, 1152, 4096, 32000, 64000, 128 * 501])
 def test_reverb_stage(models, oracle, N):
     m, _ = models
     torch.manual_seed(N)
