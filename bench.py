@@ -53,6 +53,7 @@ PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector peak
 PEAK_HBM_TBS = 8.0              # MI355X_MICROARCH.md: HBM3E spec peak (6.3 achievable)
 MAX_CLOCK_GHZ = 2.4
 N_SIMD = 1024
+FIR_ROW_FLOATS = 256     # floats per (utterance, frame) handed from the frame MLPs to the noise kernel (time-domain taps)
 
 
 def parse():
@@ -68,7 +69,7 @@ def parse():
                          "live, the worst case for the oscillator); realistic: per-utterance F0 ~ U[100, 1000] Hz with 5.5 Hz "
                          "vibrato, control ~ N(0,1) (SURVEY 8(d) config 3)")
     ap.add_argument("--exciter-opts", type=int, default=None,
-                    help="NwsWeights.exciter_opts (include/nws_hip.h): default auto (8 for the shipped checkpoints); 0 every "
+                    help="NwsWeights.exciter_opts (include/nws_hip.h): default auto (0 unless a worst-case bound admits 8, Engine.exciter_opts); 0 every "
                          "product two-term, 1 round-1 VALU FiLM, 2 one-term sines everywhere, 4 one-term sines for harmonics >= 16, "
                          "8 one-term sines AND weights for harmonics >= 16")
     ap.add_argument("--gather", choices=("rccl", "copy"), default="rccl",
@@ -96,6 +97,16 @@ def parse():
                          "kernels overlap them (ForwardPipeline chain_exciters; measured: no difference, 0.3919 vs 0.3932 ms/step)")
     ap.add_argument("--gru", choices=("batched", "per-utterance"), default="per-utterance",
                     help="GRU kernel of the pipeline's control half (the plain forward always uses per-utterance)")
+    ap.add_argument("--legs", type=int, default=1,
+                    help="1 (default, N = 1 only): after the headline region, time short extra legs of the same issue pattern and "
+                         "report them under `legs`: two_term (every mixer product 22-bit: the default arithmetic), hybrid_w (opt-in "
+                         "fp16 x fp16 products for harmonics 16..101), realistic_inputs, exact (sin-MLP shapers)")
+    ap.add_argument("--leg-steps", type=int, default=60)
+    ap.add_argument("--pmc", choices=("auto", "live", "file", "off"), default="auto",
+                    help="where the roofline's hardware counters come from: live = rocprofv3 --pmc passes over a child process of "
+                         "this script (FETCH_SIZE, WRITE_SIZE, SQ counters: separate passes, never combined with traces); file = "
+                         "the committed profiles/<round>/pmc_kernels.json; auto = live when rocprofv3 is on the box, else file")
+    ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)   # internal: the workload the PMC passes profile
     return ap.parse_args()
 
 
@@ -150,6 +161,11 @@ def cpu_baseline(weights_path, T, budget_s):
     t0 = time.time()
     fast(fb, cb)
     t_b16 = time.time() - t0
+    # "B=64 as 64 x B=1 and as one B=64 call" - one real call (about 4x the B=16 one, ~7 s)
+    fb, cb = torch.rand(64, 1, T), torch.rand(64, 2, T)
+    t0 = time.time()
+    fast(fb, cb)
+    t_b64 = time.time() - t0
     torch.set_num_threads(default_threads)
     cpu_model = "?"
     try:
@@ -166,21 +182,120 @@ def cpu_baseline(weights_path, T, budget_s):
             "exact_newt_b1": {"ms_per_utterance": mean_exact * 1e3, "samples_per_s": 128 * T / mean_exact,
                               "x_realtime": dur / mean_exact, "forwards": n_exact},
             "fastnewt_b64_as_64_sequential_b1": {"ms": 64 * mean * 1e3, "samples_per_s": 128 * T / mean},
-            "fastnewt_one_b16_call": {"ms": t_b16 * 1e3, "samples_per_s": 16 * 128 * T / t_b16,
-                                      "note": "the reference's throughput FALLS with batch (python LUT loop, BASELINE.md "
-                                              "section 2); one B=64 call would take ~4x this"}}
+            "fastnewt_one_b16_call": {"ms": t_b16 * 1e3, "samples_per_s": 16 * 128 * T / t_b16},
+            "fastnewt_one_b64_call": {"ms": t_b64 * 1e3, "samples_per_s": 64 * 128 * T / t_b64, "calls": 1,
+                                      "note": "the workload of the GPU headline (one B=64 forward) as ONE call of the port: the "
+                                              "reference's throughput FALLS with batch (python LUT loop, BASELINE.md section 2)"}}
 
 
 def load_pmc():
     """Per-kernel counters of the round's committed rocprofv3 --pmc passes (tools/collect_profiles.sh + tools/pmc_digest.py)."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd, "pmc_kernels.json")
         if os.path.exists(path):
             try:
-                return json.load(open(path)), f"profiles/{rnd}/pmc_kernels.json"
+                return json.load(open(path)), f"profiles/{rnd}/pmc_kernels.json (committed file)"
             except Exception:
                 pass
     return None, None
+
+
+PMC_PASSES = (   # separate passes (MI355X_MICROARCH.md, rocprofv3 PMC slots: FETCH_SIZE costs 3 of the 4 TCC slots, WRITE_SIZE 2)
+    ("sq", ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_VALU_TRANS_F32", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU",
+            "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"]),
+    ("fetch", ["FETCH_SIZE"]),
+    ("write", ["WRITE_SIZE"]),
+)
+
+
+def _short_kernel(name):
+    import re
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    return re.sub(r"[<(].*", "", name)
+
+
+def collect_pmc_live(a, stage_ns):
+    """rocprofv3 --pmc over a child of this script (`--pmc-child n`: n plain forwards of the bench workload on one stream),
+    one pass per counter group, counters only (never combined with a trace).  Returns the structure of
+    profiles/<round>/pmc_kernels.json, or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    from collections import defaultdict
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not on this box"
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "4", "--batch", str(a.batch), "--frames", str(a.frames)]
+    if a.exact:
+        child.append("--exact")
+    if a.exciter_opts is not None:
+        child += ["--exciter-opts", str(a.exciter_opts)]
+    if a.inputs != "rand":
+        child += ["--inputs", a.inputs]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    merged = defaultdict(lambda: defaultdict(list))
+    t_all = time.time()
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        for tag, ctrs in PMC_PASSES:
+            out = os.path.join(td, tag)
+            try:
+                r = subprocess.run([exe, "--output-format", "csv", "--pmc", *ctrs, "-d", out, "--", *child], cwd="/tmp", env=env,
+                                   capture_output=True, text=True, timeout=240)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 pass '{tag}' timed out"
+            if r.returncode != 0:
+                return None, f"rocprofv3 pass '{tag}' failed ({r.returncode}): {r.stderr[-300:]}"
+            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(path)):
+                    merged[_short_kernel(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    if not merged:
+        return None, "rocprofv3 wrote no counter_collection.csv"
+    kernels = {}
+    for k, c in merged.items():
+        m = {n: sum(v) / len(v) for n, v in c.items()}
+        w = m.get("SQ_WAVES", 0) or 1
+        e = {"waves": w, "valu_insts_per_wave": m.get("SQ_INSTS_VALU", 0) / w, "mfma_insts_per_wave": m.get("SQ_INSTS_MFMA", 0) / w,
+             "trans_insts_per_wave": m.get("SQ_INSTS_VALU_TRANS_F32", 0) / w,
+             "valu_active_quad_cycles_per_wave": m.get("SQ_ACTIVE_INST_VALU", 0) / w,
+             "wave_quad_cycles_per_wave": m.get("SQ_WAVE_CYCLES", 0) / w,
+             "wait_any_frac_of_wave_cycles": m.get("SQ_WAIT_ANY", 0) / (m.get("SQ_WAVE_CYCLES", 0) or 1),
+             "wait_inst_frac_of_wave_cycles": m.get("SQ_WAIT_INST_ANY", 0) / (m.get("SQ_WAVE_CYCLES", 0) or 1)}
+        if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+            e["fetch_kb"], e["write_kb"] = m["FETCH_SIZE"], m["WRITE_SIZE"]
+            e["hbm_bytes_per_launch"] = (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0   # gfx950: FETCH_SIZE x2 (MICROARCH guide)
+        ns, gui = stage_ns.get(k), m.get("GRBM_GUI_ACTIVE")
+        if ns and gui:
+            if gui / ns > 4.0:          # > 4 GHz: the counter is a sum over the 8 XCDs
+                gui /= 8.0
+            if 1.0 <= gui / ns <= 2.6:
+                e.update(kernel_cycles=gui, clock_ghz_during_pass=gui / ns,
+                         valu_busy_frac=w * e["valu_active_quad_cycles_per_wave"] * 4.0 / (1024.0 * gui))
+        kernels[k] = e
+    return ({"source": "rocprofv3 --pmc inside this bench run (child process, one stream, 4 forwards per pass; passes: "
+                       + ", ".join(t for t, _ in PMC_PASSES) + ")", "batch_per_gpu": a.batch, "frames": a.frames,
+             "seconds": round(time.time() - t_all, 1),
+             "correction": "FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md HBM "
+                           "section); WRITE_SIZE as reported", "kernels": kernels},
+            "rocprofv3 --pmc, live in this run")
+
+
+# algorithmic HBM bytes per launch at (B, T): what a kernel MUST move given the stage boundaries of this design (DESIGN.md
+# section 4); `traffic` (PMC) over this is the wasted-traffic ratio
+def hbm_algorithmic_bytes(B, T):
+    N = 128 * T
+    return {
+        # f0 frames + FiLM rows (B,T,256) in, carries (B, N/32) f64 in, fragment + pair tables (28 KB + 2 MB, shared), out (B,N)
+        "exciter_newt_kernel": 4 * B * T + 1024 * B * T + 8 * B * N // 32 + 28672 + 2 * 64 * 4096 * 4 + 4 * B * N,
+        "control_gru_kernel": 8 * B * T + 512 * B * T + 384 * 131 * 4,                 # control in, gru_out (B,T,128) out, weights
+        "frame_mlps16_kernel": 512 * B * T + 819200 + 1024 * B * T + 4 * B * T * FIR_ROW_FLOATS,   # gru_out in, frags, film + noise-filter rows out
+        "fir_noise_mfma_kernel": 4 * B * T * FIR_ROW_FLOATS + 4 * N + 2 * 4 * B * N,  # filter rows in, noise, add_in in + out
+        "reverb": 2 * 4 * B * N + 3 * 2 * 2 * 4 * B * N,                             # x in, y out, + 3 passes over complex planes (r+w) / 2 utt. per transform
+    }
 
 
 def kernel_roofline(name, pmc, ms, algo_flop=None, mfma_flop=None, hbm_note=None):
@@ -209,8 +324,62 @@ def kernel_roofline(name, pmc, ms, algo_flop=None, mfma_flop=None, hbm_note=None
     return e
 
 
+def pmc_child(a):
+    """The workload the PMC passes profile: n plain forwards of the bench shape on ONE stream (no pipeline, no JSON)."""
+    nws = importlib.import_module("neural-waveshaping-synthesis_amd")
+    nws.ensure_default_config()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    model = nws.NeuralWaveshaping.load_from_checkpoint(os.path.join(ROOT, "tests", "golden", "weights_vn.npz")).to(dev).eval()
+    if not a.exact:
+        model.newt = nws.FastNEWT(model.newt)
+    if a.exciter_opts is not None:
+        model.exciter_opts = a.exciter_opts
+    f0, control = make_inputs(a, dev, 0)
+    with torch.no_grad():
+        for _ in range(2 + a.pmc_child):
+            model(f0, control)
+    torch.cuda.synchronize()
+
+
+def make_inputs(a, dev, r, kind=None):
+    B, T = a.batch, a.frames
+    g = torch.Generator(device=dev).manual_seed(1000 + r)
+    if (kind or a.inputs) == "rand":
+        f0_ = torch.rand(B, 1, T, device=dev, generator=g)         # time_forward_pass.py:34-40
+        control_ = torch.rand(B, 2, T, device=dev, generator=g)    # time_forward_pass.py:27-33
+    else:
+        tt = torch.arange(T, device=dev, dtype=torch.float32) * (128.0 / 16000.0)
+        base = 100.0 + 900.0 * torch.rand(B, 1, 1, device=dev, generator=g)
+        f0_ = (base * (1.0 + 0.01 * torch.sin(2 * np.pi * 5.5 * tt).view(1, 1, T))).contiguous()
+        control_ = torch.randn(B, 2, T, device=dev, generator=g)
+    return f0_, control_
+
+
+def time_leg(model, f0, control, steps, warmup, audio_streams, control_streams):
+    """A short leg of the headline's issue pattern (ForwardPipeline, same stream counts) for another model variant / input
+    kind: ms per step, bracketed by synchronize on both sides like the headline region (fill and drain inside)."""
+    pmod = importlib.import_module("neural-waveshaping-synthesis_amd.pipeline")
+    pipe = pmod.ForwardPipeline(model, depth=audio_streams + 2, audio_streams=audio_streams, control_streams=control_streams)
+    with torch.no_grad():
+        for _ in range(2 * len(pipe.slots) + 2 + warmup):
+            pipe.submit(f0, control)
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pipe.submit(f0, control)
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    return el / steps * 1e3
+
+
 def main():
     a = parse()
+    if a.pmc_child:
+        pmc_child(a)
+        return
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and a.gpus > 1 and os.environ.get("NWS_BENCH_SHARE_GPU") != "1":
         launch_ranks(a)
@@ -261,19 +430,7 @@ def main():
 
     B, T = a.batch, a.frames
     N = 128 * T
-    def make_inputs(r):
-        g = torch.Generator(device=dev).manual_seed(1000 + r)
-        if a.inputs == "rand":
-            f0_ = torch.rand(B, 1, T, device=dev, generator=g)         # time_forward_pass.py:34-40
-            control_ = torch.rand(B, 2, T, device=dev, generator=g)    # time_forward_pass.py:27-33
-        else:
-            tt = torch.arange(T, device=dev, dtype=torch.float32) * (128.0 / 16000.0)
-            base = 100.0 + 900.0 * torch.rand(B, 1, 1, device=dev, generator=g)
-            f0_ = (base * (1.0 + 0.01 * torch.sin(2 * np.pi * 5.5 * tt).view(1, 1, T))).contiguous()
-            control_ = torch.randn(B, 2, T, device=dev, generator=g)
-        return f0_, control_
-
-    f0, control = make_inputs(rank)
+    f0, control = make_inputs(a, dev, rank)
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, a.streams))]
     shared_gen = par.make_shared_generator(dev) if distributed else None   # same draws on every rank, no broadcast
@@ -443,7 +600,7 @@ def main():
                 last = full[(len(ys) - 1) % nbuf]
                 ok = True
                 for r in range(world):
-                    y_r = ys[-1] if r == rank else model(*make_inputs(r), phase_u=draws[-1][0], noise=draws[-1][1])
+                    y_r = ys[-1] if r == rank else model(*make_inputs(a, dev, r), phase_u=draws[-1][0], noise=draws[-1][1])
                     ok = ok and bool(torch.equal(last[r * B:(r + 1) * B], y_r))
                 extra["pipeline_selfcheck"]["gathered_rows_match"] = ok
                 wrong += 0 if ok else 1
@@ -538,14 +695,56 @@ def main():
             extra["batch1_hipgraph"] = {"p50_ms": round(float(np.percentile(lat, 50)), 4),
                                         "p90_ms": round(float(np.percentile(lat, 90)), 4),
                                         "x_realtime_p50": round(dur_ms / float(np.percentile(lat, 50)), 1)}
+    if rank == 0 and world == 1 and a.legs and use_pipe:
+        # extra legs, driver-timed like the headline: the same issue pattern for the other arithmetic / inputs / shapers
+        legs = {}
+        n_audio, n_control = len(pipe.audio), len(pipe.control)
+        headline_is_two_term = (opts == 0 and not a.exact and a.inputs == "rand")
+
+        def leg(name, exciter_opts=None, inputs="rand", exact=False, steps=a.leg_steps, note=None):
+            m2 = nws.NeuralWaveshaping.load_from_checkpoint(wpath).to(dev).eval()
+            if not exact:
+                m2.newt = nws.FastNEWT(m2.newt)
+            if exciter_opts is not None:
+                m2.exciter_opts = exciter_opts
+            fi, ci = make_inputs(a, dev, rank, kind=inputs)
+            ms_leg = time_leg(m2, fi, ci, steps, 10, n_audio, n_control)
+            legs[name] = {"ms_per_step": round(ms_leg, 4), "samples_per_s": B * N / (ms_leg * 1e-3), "steps": steps,
+                          "exciter_opts": m2._engine.exciter_opts(), "inputs": inputs, "shapers": "exact sin-MLP" if exact else "FastNEWT LUT"}
+            if note:
+                legs[name]["note"] = note
+            del m2
+
+        if headline_is_two_term:
+            legs["two_term"] = {"ms_per_step": round(elapsed / a.steps * 1e3, 4), "samples_per_s": B * N * a.steps / elapsed,
+                                "steps": a.steps, "exciter_opts": 0, "inputs": "rand", "shapers": "FastNEWT LUT",
+                                "note": "= the headline region (the default arithmetic: every mixer product a two-term fp16 split, 22-bit)"}
+        else:
+            leg("two_term", exciter_opts=0, note="every mixer product a two-term fp16 split of both operands (22-bit, fp32-class)")
+        leg("hybrid_w", exciter_opts=8, note="OPT-IN (model.exciter_opts = 8): harmonics 16..101 as fp16 x fp16 products; measured "
+                                             "3e-7 .. 4e-6 RMS vs the reference on the golden vectors, no worst-case bound under 1e-5")
+        leg("realistic_inputs", inputs="realistic", note="F0 ~ U[100,1000] Hz with vibrato, control ~ N(0,1) (SURVEY 8(d) config 3)")
+        leg("exact", exact=True, steps=max(10, a.leg_steps // 3), note="exact sin-MLP shapers (the reference's default NEWT)")
+        extra["legs"] = legs
     if rank == 0:
         total_samples = B * world * N * a.steps
         value = total_samples / elapsed
         ms_per_step = elapsed / a.steps * 1e3
-        pmc, pmc_src = load_pmc()
-        if pmc and (pmc.get("batch_per_gpu") != B or pmc.get("frames") != T or a.exact or pmc.get("exciter_opts", 0) != opts):
-            pmc = None        # counters of another workload: not quoted
         st = extra.get("stage_ms", {})
+        pmc, pmc_src, pmc_note = None, None, None
+        if a.pmc in ("auto", "live") and world == 1 and st:
+            stage_ns = {"exciter_newt_kernel": st.get("exciter_newt", 0) * 1e6, "control_gru_kernel": st.get("control_gru", 0) * 1e6,
+                        "frame_mlps16_kernel": st.get("frame_mlps", 0) * 1e6, "fir_noise_mfma_kernel": st.get("fir_noise", 0) * 1e6}
+            try:
+                pmc, pmc_src = collect_pmc_live(a, stage_ns)
+            except Exception as e:   # the line must still come out
+                pmc, pmc_src = None, f"{type(e).__name__}: {e}"
+            if pmc is None:
+                pmc_note = f"live PMC collection unavailable ({pmc_src}); counters from the committed profile instead"
+        if pmc is None and a.pmc != "off":
+            pmc, pmc_src = load_pmc()
+            if pmc and (pmc.get("batch_per_gpu") != B or pmc.get("frames") != T or a.exact or pmc.get("exciter_opts", 0) != opts):
+                pmc = None        # counters of another workload: not quoted
         one_term = bool(opts & 2) and not a.exact
         hybrid = bool(opts & (4 | 8)) and not one_term and not a.exact
         # fp16 MFMAs per (M-tile, K-step): 3 with both operands two-term, 2 with one-term sines, 1 with one-term weights too;
@@ -557,31 +756,32 @@ def main():
         mfma_flop = exciter_mfma_flop_per_sample(terms, not (opts & 1) and not a.exact) * B * N
         dom = kernel_roofline("exciter_newt_kernel", pmc, k_ms, algo_flop=flops, mfma_flop=mfma_flop)
         vi = dom.get("valu_issue")
-        # Headline roofline object.  The kernel is bound by VALU issue (sines, split, table index math; every vector
-        # instruction occupies its SIMD's issue port for 2-8 cycles and an MFMA hides at most ~1/3 of its own duration under
-        # them: tools/ubench/valu_rate.hip), so `frac` is the VALU-busy share of the SIMD-cycles the launch
-        # takes; the matrix-pipe and algorithmic-flop fractions ride along.
-        roofline = {"bound": "valu_issue", "kernel": "exciter_newt_kernel",
-                    "achieved": vi["achieved"] if vi else None, "peak": N_SIMD * MAX_CLOCK_GHZ, "unit": "G VALU-busy SIMD-cycles/s",
-                    "frac": vi["frac"] if vi else None,
-                    "frac_at_clock_of_pmc_pass": vi["frac_at_clock_of_pmc_pass"] if vi else None,
-                    "traffic": (dom.get("hbm") or {}).get("traffic"), "kernel_ms": k_ms,
-                    "kernel_ms_isolated": st.get("exciter_newt"),
-                    # the same ratio for the undisturbed launch (one stream, nothing overlapping): inside the timed region
-                    # the kernel shares the chip with the other streams' kernels, which stretches the launch it is timed over
-                    "frac_isolated": (vi["achieved"] * k_ms / st["exciter_newt"] / (N_SIMD * MAX_CLOCK_GHZ))
-                    if vi and st.get("exciter_newt") else None,
-                    "algorithmic": {"flop_per_launch": flops, "achieved": flops / (k_ms * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS,
-                                    "unit": "TFLOP/s", "frac": flops / (k_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
-                                    "note": "14 969 flop/sample (86 % in the 101->64 contraction, which runs on the fp16 matrix "
-                                            "pipe): algorithmic flop / live kernel time against the dense fp16 MFMA peak"},
+        # Headline roofline object: ALGORITHMIC first.  achieved = SURVEY 8(d)'s 14 969 flop/sample x the samples one launch
+        # processes / the kernel's live average duration (HIP events on its launch stream inside the timed region); peak = the
+        # dense fp16 MFMA peak, the pipe 86 % of that work (the 101 -> 64 contraction) runs on.  WHY the fraction is what it
+        # is rides along: the kernel is bound by VALU issue (sines, their fp16 split, table index math: every vector instruction
+        # occupies its SIMD's issue port for 2-8 cycles and an MFMA hides at most ~1/3 of its own duration under them,
+        # tools/ubench/valu_rate.hip), not by the matrix pipe or HBM.
+        algo_bytes = hbm_algorithmic_bytes(B, T)
+        traffic = (dom.get("hbm") or {}).get("traffic")
+        ach = flops / (k_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "exciter_newt_kernel", "achieved": ach, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_F16_MFMA_TFLOPS, "traffic": traffic,
+                    "hbm_algorithmic_bytes": algo_bytes["exciter_newt_kernel"],
+                    "traffic_over_algorithmic": (traffic / algo_bytes["exciter_newt_kernel"]) if traffic else None,
+                    "flop_per_launch": flops, "kernel_ms": k_ms, "kernel_ms_isolated": st.get("exciter_newt"),
+                    "frac_isolated": (flops / (st["exciter_newt"] * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS) if st.get("exciter_newt") else None,
+                    "limiter": "valu_issue",
+                    "valu_issue": dict(vi, frac_isolated=(vi["achieved"] * k_ms / st["exciter_newt"] / (N_SIMD * MAX_CLOCK_GHZ))
+                                       if st.get("exciter_newt") else None) if vi else None,
                     "mfma_f16_executed": dom.get("mfma_f16_executed"), "hbm": dom.get("hbm"),
-                    "valu_insts_per_wave": (vi or {}).get("insts_per_wave"), "counters": pmc_src if pmc else None,
+                    "counters": pmc_src if pmc else None, "counters_note": pmc_note,
                     "gru_ms_in_timed_region": gru_ms_live,
-                    "note": "frac = VALU-busy SIMD-cycles per launch (PMC pass of the committed profile) / the kernel's LIVE "
-                            "duration inside the pipelined timed region (HIP events on its launch stream), where it shares the "
-                            "chip with the neighbouring batch's kernels; frac_isolated = the same cycles over the undisturbed "
-                            "one-stream duration; frac_at_clock_of_pmc_pass = busy share of the kernel's own cycles in the PMC pass"}
+                    "note": "achieved = 14 969 flop/sample (SURVEY 8(d): 2*64*101 mixer + 101*5 sines + 64*24 FiLM/LUT/mix) x B*N / "
+                            "kernel_ms, the kernel's LIVE average inside the pipelined timed region where it shares the chip with "
+                            "the neighbouring batch's kernels; frac_isolated = the same over the undisturbed one-stream duration; "
+                            "limiter: VALU issue (valu_issue.frac = VALU-busy SIMD-cycles per launch from the PMC pass / live "
+                            "duration / 1024 SIMDs x 2.4 GHz)"}
         roofline_all = [dom]
         if st:
             roofline_all += [
@@ -599,6 +799,12 @@ def main():
                 if tot and st.get("reverb"):
                     roofline_all[-1]["hbm"] = {"traffic": tot, "achieved": tot / (st["reverb"] * 1e-3) / 1e12, "peak": PEAK_HBM_TBS,
                                                "unit": "TB/s", "frac": tot / (st["reverb"] * 1e-3) / 1e12 / PEAK_HBM_TBS}
+        for e in roofline_all:
+            kb = algo_bytes.get(e["kernel"].split(" ")[0])
+            if kb:
+                e["hbm_algorithmic_bytes"] = kb
+                if (e.get("hbm") or {}).get("traffic"):
+                    e["traffic_over_algorithmic"] = e["hbm"]["traffic"] / kb
         if a.exact:
             dtype = "f32 (101->64 mixer, frame MLPs, FIR noise: fp16x2-split MFMA contractions = 22-bit products, fp32 accumulate; exact sin-MLP shapers in fp32)"
         elif one_term:

@@ -37,9 +37,9 @@ enum Opt {
   kOptFilmMfma = 2,     // FiLM interpolation (3 parameter types x 64 shapers x 32 samples per wave) as six bf16 MFMAs
   kOptOneTerm = 4,      // sines as ONE fp16 term in EVERY K-step (drops W_hi * v_lo: 2 MFMAs per product; 11-bit activations)
   kOptHybrid = 8,       // two-term sines in K-step 0 (mixer bias + harmonics 1..15), one term in K-steps 1..6
-  kOptHybridW = 16,     // with kOptHybrid: the mixer WEIGHTS of harmonics 16..101 as one fp16 term too (1 MFMA per product)
-  kOptPipelined = 8     // main loop software-pipelined: sines of K-step ks+1 beside the MFMAs of K-step ks
+  kOptHybridW = 16      // with kOptHybrid: the mixer WEIGHTS of harmonics 16..101 as one fp16 term too (1 MFMA per product)
 };
+static_assert((kOptScalarSines ^ kOptFilmMfma ^ kOptOneTerm ^ kOptHybrid ^ kOptHybridW) == 31, "Opt bits must be distinct");
 enum Mode { kModeLut = 0, kModeExact = 1, kModeExciterOnly = 2, kModeLutPairs = 3, kModeLutPairsDiv6 = 4, kModeExactBank = 5 };
 __host__ __device__ constexpr bool is_lut(int mode) {
   return mode == kModeLut || mode == kModeLutPairs || mode == kModeLutPairsDiv6;

@@ -64,6 +64,18 @@ NwsReverbPlan plan_of(const Tensor& plan) {
   return NwsReverbPlan{p[0], p[1], p[2], p[3]};
 }
 
+// the spectrum / table tensors must be the ones built for THIS plan: the kernels index them by plan.L / N1 / N2 (a tensor made
+// for another L, or for an older layout of the spectrum buffer, would be read out of bounds)
+void check_reverb_buffers(const NwsReverbPlan& plan, const Tensor& tables, const Tensor& spectrum) {
+  TORCH_CHECK(plan.L > 0 && plan.N1 > 0 && plan.N2 > 0 && (int64_t)plan.N1 * plan.N2 == plan.L, "plan: inconsistent [L, N1, N2] = [",
+              plan.L, ", ", plan.N1, ", ", plan.N2, "]");
+  TORCH_CHECK((size_t)tables.numel() * tables.element_size() == nws_reverb_table_bytes(&plan), "reverb_tables: ",
+              (size_t)tables.numel() * tables.element_size(), " bytes, the plan (L = ", plan.L, ") needs ", nws_reverb_table_bytes(&plan));
+  TORCH_CHECK((size_t)spectrum.numel() * spectrum.element_size() == nws_reverb_spectrum_bytes(&plan), "reverb_spectrum: ",
+              (size_t)spectrum.numel() * spectrum.element_size(), " bytes, the plan (L = ", plan.L, ") needs ",
+              nws_reverb_spectrum_bytes(&plan), " (Sre | Sim | ir_)");
+}
+
 struct Aux {
   NwsReverbPlan plan;
   NwsForwardAux aux;
@@ -72,6 +84,7 @@ struct Aux {
     check_dev(tables, "reverb_tables");
     check_dev(spectrum, "reverb_spectrum");
     TORCH_CHECK(fir_design.numel() == NWS_FIR_LEN * 132, "fir_design: expected (256, 132)");
+    check_reverb_buffers(plan, tables, spectrum);
     aux.fir_design = fir_design.data_ptr<float>();
     aux.plan = &plan;
     aux.reverb_tables = tables.data_ptr();
@@ -338,7 +351,9 @@ Tensor reverb(const Tensor& plan_t, const Tensor& tables, const Tensor& spectrum
   check_same_device(x, "x", tables, "reverb tables");
   check_same_device(x, "x", spectrum, "reverb.ir spectrum");
   TORCH_CHECK(x.dim() == 2, "Reverb: expected (B, N), got ", x.sizes());
+  check_reverb_buffers(plan, tables, spectrum);
   const int64_t B = x.size(0), N = x.size(1);
+  TORCH_CHECK(N <= plan.L, "Reverb: ", N, " samples do not fit the plan's circular length ", plan.L);
   Launch L(x);
   const size_t nbytes = nws_reverb_workspace_bytes(&plan, (int)B);
   Tensor ws = at::empty({(int64_t)nbytes}, x.options().dtype(at::kByte));
@@ -360,6 +375,9 @@ std::tuple<Tensor, Tensor> reverb_linear_chunk(const Tensor& plan_t, const Tenso
   check_same_device(x, "x", tables, "reverb tables");
   TORCH_CHECK(x.dim() == 2 && tail_in.dim() == 2 && tail_in.size(0) == x.size(0), "reverb_linear_chunk: x (B, M), tail_in (B, tail)");
   const int64_t B = x.size(0), M = x.size(1), tail_len = tail_in.size(1);
+  check_reverb_buffers(plan, tables, spectrum);
+  check_same_device(x, "x", spectrum, "reverb.ir spectrum");
+  TORCH_CHECK(M + tail_len <= plan.L, "reverb_linear_chunk: chunk of ", M, " + tail of ", tail_len, " samples wraps around L = ", plan.L);
   Launch L(x);
   const size_t nbytes = (size_t)(2 * ((B + 1) / 2) * plan.L + B * plan.L) * sizeof(float);
   Tensor ws = at::empty({(int64_t)nbytes}, x.options().dtype(at::kByte));

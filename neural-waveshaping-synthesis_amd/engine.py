@@ -169,7 +169,16 @@ class Engine:
         fp = self._fingerprint()
         if self._w is not None and fp == self._fp:
             return self._w
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            # building the pointer struct launches table kernels and synchronises: not legal inside a HIP-graph capture
+            raise _lib.NwsError("the model's parameters / options changed (or were never staged) and the engine's derived tables "
+                                "must be rebuilt, which cannot happen during HIP-graph capture: run one forward (or "
+                                "model._engine.weights()) before capturing")
         if self._w is not None:
+            # Other streams (ForwardPipeline, NewtStream, the caller's own) may still have kernels enqueued that read the
+            # fragment tables / spectra / workspaces dropped below; the caching allocator only orders re-use on the stream a
+            # block was allocated on.  A rebuild is rare (weights changed): drain the device first.
+            torch.cuda.synchronize(self._w[2])
             self.invalidate()
             fp = self._fingerprint()
         m = self._model_ref
@@ -269,23 +278,34 @@ class Engine:
         self._fp = fp
         return self._w
 
+    HYBRID_W_BOUND = 1e-5     # worst-case output error (a tenth of the 1e-4 parity bar) under which "auto" may drop mixer terms
+
     def exciter_opts(self) -> int:
         """NwsWeights.exciter_opts.  `model.exciter_opts` if set, else the NWS_EXCITER_OPTS environment variable, else
-        "auto": when the mixer bias + harmonics 1..15 hold at least 55 % of the harmonic mixer's weight energy - true for the
-        three shipped checkpoints (61 / 67 / 85 %) - only THAT part of the 101 -> 64 contraction keeps the two-term fp16
-        split of both operands (22-bit products); harmonics 16..101 run as plain fp16 x fp16 with fp32 accumulation
-        (EXCITER_HYBRID_W: 1 instead of 3 MFMAs per product there, no residual split of those sines).  Cost on the golden
-        vectors: 3e-7 .. 3e-6 RMS end to end instead of 2-6e-7 (tests/test_gpu_parity.py holds it to 1e-5, a tenth of the
-        1e-4 bar); otherwise (e.g. random initialisation) every product keeps both terms."""
+        "auto" = 0 (every product of the 101 -> 64 mixer as a two-term fp16 split of both operands: 22-bit, fp32-class, what
+        the reference's fp32 Conv1d at models/neural_waveshaping.py:54,66 is compared with) UNLESS the worst-case bound of
+        `precision.hybrid_w_error_bound` - from the weights alone, valid for any input - proves that running harmonics 16..101
+        as plain fp16 x fp16 products (EXCITER_HYBRID_W: 1 instead of 3 MFMAs per product there) cannot move the output by
+        more than HYBRID_W_BOUND.  The bound multiplies worst-case FiLM gains, LUT slope and ||ir||_1: for the three shipped
+        checkpoints it is 4e4 .. 9e4, so they run two-term; the hybrid forms remain an explicit opt-in (measured 3e-7 ..
+        4e-6 RMS against the reference on the golden vectors, tests/test_gpu_parity.py)."""
         v = getattr(self._model_ref, "exciter_opts", None)
         if v is None:
             v = os.environ.get("NWS_EXCITER_OPTS")
         if v is not None and str(v) != "auto":
             return int(v)
-        with torch.no_grad():
-            e = self._model_ref.harmonic_mixer.weight.detach().float().pow(2).sum(dim=(0, 2))     # per harmonic
-            share = float(e[:15].sum() / e.sum().clamp_min(1e-30))
-        return _lib.EXCITER_HYBRID_W if share >= 0.55 else 0
+        b = self.hybrid_w_bound()
+        return _lib.EXCITER_HYBRID_W if (b is not None and b["bound"] <= self.HYBRID_W_BOUND) else 0
+
+    def hybrid_w_bound(self):
+        """precision.hybrid_w_error_bound for this model (None for exact shapers: the option only exists on the LUT path)"""
+        from . import precision
+
+        m = self._model_ref
+        table = getattr(m.newt, "lookup_table", None)
+        if table is None:
+            return None
+        return precision.hybrid_w_error_bound(m, table, float(m.newt.table_min), float(m.newt.table_max))
 
     def fp16_mlp_safe(self, limit: float = 3.0e4) -> bool:
         """Worst-case magnitude of every frame-MLP layer input, from weight norms (one-time host check).

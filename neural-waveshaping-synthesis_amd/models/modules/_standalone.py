@@ -27,6 +27,7 @@ class Desc:
     def get(self, tensors: dict, scalars: dict | None = None):
         key = tuple((k, t.data_ptr(), t._version) for k, t in tensors.items()) + tuple(sorted((scalars or {}).items()))
         if key != self._key:
+            no_autograd(params=list(tensors.values()))
             w = _lib.NwsWeights()
             keep = []
             for field, t in tensors.items():
@@ -50,8 +51,33 @@ def shaper_fields(sh) -> dict:
             "shaper_b4": sh.net[4].bias, "shaper_w6": sh.net[6].weight, "shaper_b6": sh.net[6].bias}
 
 
+_WARNED_PARAM_GRAD = [False]
+
+
+def no_autograd(inputs=(), params=()):
+    """The stage kernels are inference-only: the reference's modules are differentiable, these return tensors without a
+    graph.  An INPUT that requires grad under grad mode means the caller expects gradients -> raise instead of silently
+    returning a constant; parameters that require grad (the nn.Parameter default) only warn, once."""
+    if not torch.is_grad_enabled():
+        return
+    for t in inputs:
+        if isinstance(t, torch.Tensor) and t.requires_grad:
+            raise RuntimeError("the HIP stage kernels are inference-only (no autograd): an input requires grad, so the result "
+                               "would silently carry no graph.  Detach the input or call under torch.no_grad().")
+    if not _WARNED_PARAM_GRAD[0] and any(isinstance(t, torch.Tensor) and t.requires_grad for t in params):
+        import warnings
+
+        _WARNED_PARAM_GRAD[0] = True
+        warnings.warn("NEWT HIP kernels are inference-only: outputs carry no autograd graph although the module's parameters "
+                      "require grad (wrap calls in torch.no_grad() to silence this)", stacklevel=3)
+
+
 def call(op_name: str, c_name: str, op_args: tuple, c_call):
     """Run `torch.ops.newt_hip.<op_name>(*op_args)` or, on the ctypes binding, `c_call(lib)` (which returns the result)."""
+    flat = []
+    for a in op_args:
+        flat.extend(a if isinstance(a, (list, tuple)) else (a,))
+    no_autograd(inputs=flat)
     o = ops()
     if o is not None:
         return getattr(o, op_name)(*op_args)
@@ -62,4 +88,4 @@ def checked(rc: int, what: str):
     _lib.check(rc, what)
 
 
-__all__ = ["C", "Desc", "call", "checked", "contiguous", "shaper_fields", "stream_ptr", "_req", "_lib", "ops"]
+__all__ = ["C", "Desc", "call", "no_autograd", "checked", "contiguous", "shaper_fields", "stream_ptr", "_req", "_lib", "ops"]

@@ -89,6 +89,13 @@ def td_mlp_forward(x, net):
     ls = [sa._req(n.layer_norm.bias.detach(), "layer_norm.bias") for n in norms]
     eps = float(norms[0].layer_norm.eps) if norms else 1e-5
     slope = float(acts[0].negative_slope) if acts else 0.01
+    # one eps / slope per launch (nws_td_mlp): a stack that mixes them is not what the kernel computes
+    if any(float(n.layer_norm.eps) != eps for n in norms) or any(float(a.negative_slope) != slope for a in acts):
+        raise RuntimeError("TimeDistributedMLP: the stage kernel takes ONE LayerNorm eps and ONE LeakyReLU slope for the whole "
+                           "stack; these layers differ")
+    if len(acts) != len(norms) or any(not n.layer_norm.elementwise_affine for n in norms):
+        raise RuntimeError("TimeDistributedMLP: expected Conv1d -> LayerNorm(affine) -> LeakyReLU blocks")
+    sa.no_autograd(params=[p for c in convs for p in (c.weight, c.bias)])
     depth = len(convs)
     hidden = ws[0].shape[0]
     out_size = ws[-1].shape[0]

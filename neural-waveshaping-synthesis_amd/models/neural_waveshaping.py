@@ -165,6 +165,7 @@ class NeuralWaveshaping(nn.Module):
         if T < 2:
             raise RuntimeError("need at least 2 control frames (reflect padding of the noise STFT, generators.py:31)")
         dev = f0.device
+        sa.no_autograd(inputs=(f0, control))     # inference-only kernels: never hand back a graph-less result for grad inputs
         if phase_u is None:
             phase_u = torch.rand_like(self.osc.rand_phase)          # RNG draw #1 (generators.py:55)
         phase_u = _req(phase_u.reshape(-1), "phase_u", _lib.N_HARMONICS)

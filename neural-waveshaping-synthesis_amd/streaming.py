@@ -142,6 +142,8 @@ class NewtStream:
         self.noise_residue = noise_all[:, cnt:].contiguous()
 
         # 5. linear reverb with carried tail
+        # (fetched per push: cached by the engine per weights version, so an in-place update of reverb.ir is picked up)
+        self._rv_aux = eng.reverb_aux(2 * self.tail_len)
         y, self.tails[self._tail_idx ^ 1] = eng.reverb_linear_chunk(self._rv_aux, pre, self.tails[self._tail_idx])
         self._tail_idx ^= 1
 

@@ -472,7 +472,7 @@ def test_e2e_g7_other_instruments(inst):
     fast.newt = nws.FastNEWT(fast.newt)
     g = load_npz(f"g7_{inst}.npz")
     _e2e((exact, fast), None, g, g, f"g7_{inst}")
-    assert fast._engine.exciter_opts() == 8          # shipped checkpoints: the automatic choice is the hybrid
+    assert fast._engine.exciter_opts() == 0          # shipped checkpoints: the worst-case bound keeps every product two-term
     for opts, tag, tol in ((0, "two_term", 2e-6), (4, "hybrid", 1e-5), (8, "hybrid_w", 1e-5), (2, "one_term", 1e-4), (1, "valu_film", 2e-6)):
         fast.exciter_opts = opts
         fast.invalidate_cache()
@@ -502,6 +502,87 @@ def test_exciter_options_on_golden_vectors(models):
     finally:
         fast.exciter_opts = None
         fast.invalidate_cache()
+
+
+def _fast_model_from(w2):
+    import nws_amd as nws
+
+    m = build_model(False)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in w2.items()})
+    m = m.cuda().eval()
+    m.newt = nws.FastNEWT(m.newt)
+    return m
+
+
+def test_hybrid_w_guard_refuses_checkpoint_the_energy_rule_admitted(weights):
+    """The automatic precision choice (Engine.exciter_opts) is a worst-case bound from the weights
+    (precision.hybrid_w_error_bound), not round 2's share of the mixer's weight ENERGY in harmonics 1..15.  Crafted
+    checkpoint: the vn weights with reverb.ir x 30.  The mixer is untouched, so the energy rule would still have selected the
+    fp16 x fp16 products for harmonics 16..101 (share 61 % >= 55 %) - but every error before the reverb now reaches the
+    output 30 x larger, and on the timing-script inputs (all 101 harmonics live) the hybrid-W arithmetic misses the 1e-4 bar
+    against the oracle run on the SAME weights.  The guard must refuse it by itself; the two-term result stays inside."""
+    from oracle.newt_oracle import OracleNEWT
+
+    w2 = {k: np.array(v, copy=True) for k, v in weights.items()}
+    w2["reverb.ir"] = w2["reverb.ir"] * 30.0
+    e_mix = (w2["harmonic_mixer.weight"].astype(np.float64) ** 2).sum(axis=(0, 2))
+    assert e_mix[:15].sum() / e_mix.sum() >= 0.55                       # what round 2's rule looked at: it admitted this one
+    m = _fast_model_from(w2)
+    b = m._engine.hybrid_w_bound()
+    assert b["bound"] > 1e-5 and m._engine.exciter_opts() == 0          # refused, no monkey-patching
+    assert m._engine.weights()[0].exciter_opts == 0
+    g, d = load_npz("g2_rand.npz"), load_npz("g1_realistic.npz")
+    ref = OracleNEWT(w2, fast=True, lut_python_loop=False)(g["f0"], g["control"], d["phase_u"], d["noise"]).numpy()
+    args = (dev(g["f0"]), dev(g["control"]))
+    kw = dict(phase_u=dev(d["phase_u"]), noise=dev(d["noise"]))
+    y_auto = m(*args, **kw).cpu().numpy()
+    m.exciter_opts = 8
+    m.invalidate_cache()
+    y_forced = m(*args, **kw).cpu().numpy()
+    e_auto, e_forced = rms(y_auto - ref), rms(y_forced - ref)
+    record("hybrid_w_guard_refused", rms_err_auto_two_term=e_auto, rms_err_forced_hybrid_w=e_forced, out_rms=rms(ref),
+           bound=b["bound"], max_abs_forced_vs_auto=maxabs(y_forced, y_auto))
+    assert e_auto <= 2e-5, e_auto                                       # 30 x the two-term error of the plain checkpoint
+    assert e_forced > 3.0 * e_auto, (e_forced, e_auto)                  # what the refusal avoided
+    assert maxabs(y_forced, y_auto) <= b["bound"]                       # the bound is a bound
+
+
+def test_hybrid_w_guard_admits_when_the_bound_allows(weights):
+    """...and the same rule admits EXCITER_HYBRID_W where the bound proves it harmless: (a) harmonics 16..101 with zero mixer
+    weights (bound 0: the dropped terms are exact zeros, output bit-identical to the two-term kernel); (b) small gains all
+    along the chain (bound <= 1e-5), checked against the oracle on the same weights."""
+    from oracle.newt_oracle import OracleNEWT
+
+    g, d = load_npz("g2_rand.npz"), load_npz("g1_realistic.npz")
+    args = (dev(g["f0"]), dev(g["control"]))
+    kw = dict(phase_u=dev(d["phase_u"]), noise=dev(d["noise"]))
+    # (a)
+    w2 = {k: np.array(v, copy=True) for k, v in weights.items()}
+    w2["harmonic_mixer.weight"][:, 15:] = 0.0
+    m = _fast_model_from(w2)
+    assert m._engine.hybrid_w_bound()["bound"] == 0.0 and m._engine.exciter_opts() == 8
+    y8 = m(*args, **kw)
+    m.exciter_opts = 0
+    m.invalidate_cache()
+    assert torch.equal(y8, m(*args, **kw))
+    # (b)
+    w3 = {k: np.array(v, copy=True) for k, v in weights.items()}
+    w3["harmonic_mixer.weight"][:, 15:] *= 1e-4
+    w3["reverb.ir"] = w3["reverb.ir"] * 1e-3
+    for k in ("newt.mlp.net.9.weight", "newt.mlp.net.9.bias"):
+        w3[k] = w3[k] * 0.005
+    m = _fast_model_from(w3)
+    b = m._engine.hybrid_w_bound()
+    assert b["bound"] <= 1e-5 and m._engine.exciter_opts() == 8, b
+    ref = OracleNEWT(w3, fast=True, lut_python_loop=False)(g["f0"], g["control"], d["phase_u"], d["noise"]).numpy()
+    y8 = m(*args, **kw).cpu().numpy()
+    m.exciter_opts = 0
+    m.invalidate_cache()
+    y0 = m(*args, **kw).cpu().numpy()
+    record("hybrid_w_guard_admitted", rms_err_hybrid_w=rms(y8 - ref), rms_err_two_term=rms(y0 - ref), out_rms=rms(ref),
+           bound=b["bound"], max_abs_hybrid_vs_two_term=maxabs(y8, y0))
+    assert maxabs(y8, y0) <= b["bound"] + 1e-7        # + the two kernels' own fp32 summation-order noise
+    assert rms(y8 - ref) <= 1e-5
 
 
 def test_e2e_g3_batch2_extra_control_channels(models, oracle):
