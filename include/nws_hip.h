@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NWS_ABI_VERSION 2
+#define NWS_ABI_VERSION 3
 
 #define NWS_N_HARMONICS 101
 #define NWS_N_SHAPERS 64
@@ -110,7 +110,7 @@ typedef struct NwsWeights {
                                    (one MFMA per product there instead of two) */
 
 int nws_abi_version(void);
-/* sizeof of the C structs above as this library was compiled (0 NwsWeights, 1 NwsReverbPlan, 2 NwsForwardAux): lets a
+/* sizeof of the C structs above as this library was compiled (0 NwsWeights, 1 NwsReverbPlan, 2 NwsForwardAux, 3 NwsShaperDesc, 4 NwsGenericModel): lets a
  * foreign-language binding verify its own struct declarations at load time */
 size_t nws_sizeof(int which);
 const char* nws_error_string(int code);
@@ -327,6 +327,91 @@ int nws_loudness_frames(int N, int hop);
 size_t nws_loudness_workspace_bytes(int B, int N, int n_fft, int hop);
 int nws_loudness(const float* audio, int B, int N, int n_fft, int hop, const float* dft, float amin, float top_db,
                  int normalise, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * ---- Runtime-size path (csrc/generic.hip): every gin-configurable size of the reference ------------------------------
+ * The fused kernels above are compiled for gin/models/newt.gin.  These entry points take the sizes as arguments and run
+ * one plain-fp32 stage kernel each (correct first, stage boundaries materialised); nws_forward_generic chains them into
+ * NeuralWaveshaping.forward (models/neural_waveshaping.py:74-90) for ANY configuration:
+ *   HarmonicOscillator.n_harmonics (generators.py:40-48), NeuralWaveshaping.n_waveshapers / control_hop (:31-62),
+ *   NEWT.shaping_fn_size / out_channels (shaping.py:41-65), TrainableNonlinearity.depth (:15-34),
+ *   ControlModule.hidden_size / embedding_size (neural_waveshaping.py:17-23), the h_generator's depth / hidden_size,
+ *   FIRNoiseSynth.ir_length / hop_length (generators.py:13-19), Reverb.sr * length_in_seconds (shaping.py:156-158),
+ *   FastNEWT table_size / table_min / table_max (shaping.py:83-105).
+ */
+/* TrainableNonlinearity(channels = n_shapers, width, depth) (shaping.py:15-37) or a FastNEWT table (lut != NULL) */
+typedef struct NwsShaperDesc {
+  int32_t n_shapers, width, depth, lut_size;
+  float lut_min, lut_max;
+  const float* in_scale; /* (n_shapers) */
+  const float* w[8];     /* net.{2i}.weight: depth 1: (S); else layer 0: (S*width); hidden: (S*width, width); last: (S, width) */
+  const float* b[8];     /* net.{2i}.bias */
+  const float* lut;      /* (n_shapers, lut_size) or NULL */
+} NwsShaperDesc;
+
+typedef struct NwsGenericModel {
+  int32_t control_size;   /* GRU input channels consumed (the reference's get_embedding always feeds 2, :69-72) */
+  int32_t gru_hidden, embedding, n_harmonics, n_shapers;
+  int32_t hop;            /* control_hop == FIRNoiseSynth.hop_length */
+  int32_t newt_mlp_depth; /* 4 (NEWT hard-codes depth=4, shaping.py:53-55) */
+  int32_t hgen_depth, hgen_hidden;
+  int32_t fir_len;        /* FIRNoiseSynth.ir_length (even); the h_generator emits fir_len/2 + 1 bands */
+  int32_t out_channels;   /* NEWT.out_channels (summed by forward's cat + sum(1)) */
+  int32_t ir_len;         /* len(reverb.ir) = sr * length_in_seconds - 1 */
+  float ln_eps, leaky_slope;
+  const float *gru_w_ih, *gru_w_hh, *gru_b_ih, *gru_b_hh; /* (3H, control_size), (3H, H), (3H), (3H) */
+  const float *proj_w, *proj_b;                           /* (embedding, H), (embedding) */
+  const float *mixer_w, *mixer_b;                         /* (n_shapers, n_harmonics), (n_shapers) */
+  const float* newt_mlp_w[8];
+  const float* newt_mlp_b[8];
+  const float* newt_ln_g[8];
+  const float* newt_ln_b[8];
+  const float* hgen_w[8];
+  const float* hgen_b[8];
+  const float* hgen_ln_g[8];
+  const float* hgen_ln_b[8];
+  const float *newt_out_w, *newt_out_b; /* (out_channels, n_shapers), (out_channels) */
+  const float* noise_window;            /* (fir_len) */
+  const float* ir;                      /* (ir_len) */
+  NwsShaperDesc shaper;
+} NwsGenericModel;
+
+size_t nws_g_gru_workspace_bytes(int hidden);
+/* torch.nn.GRU(C_in -> hidden, batch_first) over control[:, 0:C_in] of (B, C_total, T); out (B, T, hidden); h0 / hT optional */
+int nws_g_gru(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, const float* control, int B,
+              int C_total, int C_in, int hidden, int T, const float* h0, float* out, float* hT, void* workspace,
+              size_t workspace_bytes, void* stream);
+int nws_g_bth_to_bht(const float* x, int B, int T, int H, float* y, void* stream);
+/* F.upsample(f0, T*hop, "linear") (f0 (B,T); or f0_up (B, T) given with hop = 1) + the double-accumulated cumsum and the
+ * fp32 chain of generators.py:59: phase = fl(fl(tau * c) / sr).  f0_up_out optional. */
+int nws_g_phase(const float* f0, const float* f0_up, int B, int T, int hop, float sample_rate, float* f0_up_out,
+                float* phase_out, void* stream);
+/* HarmonicOscillator.forward (generators.py:58-66) for K harmonics: out (B, K, N) */
+int nws_g_oscillator(const float* f0_up, const float* phase, const float* phase_u, const float* rand_phase, int K, int B, int N,
+                     float sample_rate, float* out, void* stream);
+/* nn.Conv1d(Cin, Cout, 1) on (B, Cin, N); bias may be NULL */
+int nws_g_conv1x1(const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int N, float* y, void* stream);
+/* TrainableNonlinearity.forward / FastNEWT.shaping_fn on (rows = B * n_shapers, N) */
+int nws_g_shaper_apply(const NwsShaperDesc* d, const float* x, int64_t rows, int64_t N, float* y, void* stream);
+int nws_g_shaper_table(const NwsShaperDesc* d, int table_size, float table_min, float table_max, float* table_out, void* stream);
+/* NEWT.forward before the mixer (shaping.py:68-76): exciter (B,S,N), film (B,4S,T) channel-major -> (B,S,N) */
+int nws_g_film_shaper(const NwsShaperDesc* d, const float* exciter, const float* film, int B, int T, int hop, float* out,
+                      void* stream);
+/* FIRNoiseSynth (generators.py:21-35) for any even ir_length >= hop: H (B, L/2+1, T) -> taps (B, T, L); then the noise
+ * branch (+ the sum over `add_channels` channels of add_in (B, add_channels, N), NULL = none) -> out (B, N) */
+int nws_g_fir_design(const float* H, const float* window, int fir_len, int B, int T, float* fir_out, void* stream);
+int nws_g_fir_noise(const float* fir, const float* noise, int fir_len, int hop, int B, int T, const float* add_in,
+                    int add_channels, float* out, void* stream);
+/* Reverb.forward in the time domain (any lengths; the four-step FFT of nws_reverb needs L = N1 * 2^k, N1 <= 8192, 32 | L) */
+int nws_g_reverb_direct(const float* x, const float* ir, int ir_len, int B, int N, float* y, void* stream);
+
+size_t nws_forward_generic_workspace_bytes(const NwsGenericModel* m, int B, int T);
+/* plan / reverb_tables / reverb_spectrum / reverb_workspace: from nws_reverb_plan & co when the plan exists for
+ * (T*hop, ir_len+1), else all NULL (time-domain reverb) */
+int nws_forward_generic(const NwsGenericModel* m, const float* f0, const float* control, int B, int C, int T, float sample_rate,
+                        const float* phase_u, const float* rand_phase, const float* noise, const NwsReverbPlan* plan,
+                        const void* reverb_tables, const void* reverb_spectrum, void* reverb_workspace,
+                        size_t reverb_workspace_bytes, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Diagnostics only: ablation variants of the fused kernel for timing (1 no sin, 2 no LUT gather, 3 no shaper tail,
  * 4 no MFMA; 0 = product kernel).  Outputs of variants != 0 are meaningless. */

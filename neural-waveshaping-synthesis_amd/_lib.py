@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnws_hip.so")
 
-ABI_VERSION = 2          # include/nws_hip.h NWS_ABI_VERSION
+ABI_VERSION = 3          # include/nws_hip.h NWS_ABI_VERSION
 EXCITER_VALU_FILM = 1    # NwsWeights.exciter_opts bits (include/nws_hip.h)
 EXCITER_ONE_TERM = 2
 EXCITER_HYBRID = 4
@@ -23,6 +23,7 @@ HOP = 128
 FIR_LEN = 256
 N_BANDS = 129
 FILM_CH = 256
+SHAPER_WIDTH = 8
 SHAPER_TURNS_ROW = 176
 FIR_DESIGN_COLS = 132
 
@@ -54,6 +55,25 @@ class NwsReverbPlan(C.Structure):
 class NwsForwardAux(C.Structure):
     _fields_ = [("fir_design", _fp), ("plan", C.POINTER(NwsReverbPlan)), ("reverb_tables", _fp),
                 ("reverb_spectrum", _fp)]
+
+
+class NwsShaperDesc(C.Structure):
+    _fields_ = [("n_shapers", C.c_int32), ("width", C.c_int32), ("depth", C.c_int32), ("lut_size", C.c_int32),
+                ("lut_min", C.c_float), ("lut_max", C.c_float),
+                ("in_scale", _fp), ("w", _fp * 8), ("b", _fp * 8), ("lut", _fp)]
+
+
+class NwsGenericModel(C.Structure):
+    _fields_ = [("control_size", C.c_int32), ("gru_hidden", C.c_int32), ("embedding", C.c_int32), ("n_harmonics", C.c_int32),
+                ("n_shapers", C.c_int32), ("hop", C.c_int32), ("newt_mlp_depth", C.c_int32), ("hgen_depth", C.c_int32),
+                ("hgen_hidden", C.c_int32), ("fir_len", C.c_int32), ("out_channels", C.c_int32), ("ir_len", C.c_int32),
+                ("ln_eps", C.c_float), ("leaky_slope", C.c_float),
+                ("gru_w_ih", _fp), ("gru_w_hh", _fp), ("gru_b_ih", _fp), ("gru_b_hh", _fp),
+                ("proj_w", _fp), ("proj_b", _fp), ("mixer_w", _fp), ("mixer_b", _fp),
+                ("newt_mlp_w", _fp * 8), ("newt_mlp_b", _fp * 8), ("newt_ln_g", _fp * 8), ("newt_ln_b", _fp * 8),
+                ("hgen_w", _fp * 8), ("hgen_b", _fp * 8), ("hgen_ln_g", _fp * 8), ("hgen_ln_b", _fp * 8),
+                ("newt_out_w", _fp), ("newt_out_b", _fp), ("noise_window", _fp), ("ir", _fp),
+                ("shaper", NwsShaperDesc)]
 
 
 _PROTOTYPES = {
@@ -118,6 +138,22 @@ _PROTOTYPES = {
     "nws_td_layer_norm": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp]),
     "nws_film": (C.c_int, [_fp, _fp, _fp, C.c_int64, _fp, _fp]),
     "nws_fir_from_h": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp, _fp]),
+    "nws_g_gru_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "nws_g_gru": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp,
+                            C.c_size_t, _fp]),
+    "nws_g_bth_to_bht": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "nws_g_phase": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp, _fp]),
+    "nws_g_oscillator": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp]),
+    "nws_g_conv1x1": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "nws_g_shaper_apply": (C.c_int, [C.POINTER(NwsShaperDesc), _fp, C.c_int64, C.c_int64, _fp, _fp]),
+    "nws_g_shaper_table": (C.c_int, [C.POINTER(NwsShaperDesc), C.c_int, C.c_float, C.c_float, _fp, _fp]),
+    "nws_g_film_shaper": (C.c_int, [C.POINTER(NwsShaperDesc), _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "nws_g_fir_design": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "nws_g_fir_noise": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp]),
+    "nws_g_reverb_direct": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "nws_forward_generic_workspace_bytes": (C.c_size_t, [C.POINTER(NwsGenericModel), C.c_int, C.c_int]),
+    "nws_forward_generic": (C.c_int, [C.POINTER(NwsGenericModel), _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp, _fp,
+                                      C.POINTER(NwsReverbPlan), _fp, _fp, _fp, C.c_size_t, _fp, _fp, C.c_size_t, _fp]),
     "nws_profile_begin": (C.c_int, [C.c_int, C.c_uint]),
     "nws_profile_collect": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "nws_profile_end": (C.c_int, []),
@@ -151,7 +187,7 @@ def lib():
         if handle.nws_abi_version() != ABI_VERSION:
             raise NwsError(f"{LIB_PATH} has ABI version {handle.nws_abi_version()}, this package binds version "
                            f"{ABI_VERSION}: rebuild it (python __graft_entry__.py build)")
-        for which, struct in enumerate((NwsWeights, NwsReverbPlan, NwsForwardAux)):
+        for which, struct in enumerate((NwsWeights, NwsReverbPlan, NwsForwardAux, NwsShaperDesc, NwsGenericModel)):
             if handle.nws_sizeof(which) != C.sizeof(struct):
                 raise NwsError(f"struct layout mismatch for {struct.__name__}: library {handle.nws_sizeof(which)} B, "
                                f"binding {C.sizeof(struct)} B")

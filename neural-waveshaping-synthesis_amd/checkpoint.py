@@ -42,6 +42,10 @@ def read_checkpoint(path):
     if str(path).endswith(".npz"):
         z = np.load(path)
         state = {k: z[k] for k in z.files if not k.startswith("__")}
+        if "__hparams__" in z.files:        # fixtures of non-default gin configurations carry their constructor arguments
+            import json
+
+            return state, {k: v for k, v in json.loads(str(z["__hparams__"])).items() if k in _HPARAM_KEYS}
         return state, dict(n_waveshapers=64, control_hop=128, sample_rate=16000)
     with _lightning_standin():
         ck = torch.load(path, map_location="cpu", weights_only=False)

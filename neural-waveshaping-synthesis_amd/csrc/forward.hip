@@ -152,6 +152,8 @@ size_t nws_sizeof(int which) {
     case 0: return sizeof(NwsWeights);
     case 1: return sizeof(NwsReverbPlan);
     case 2: return sizeof(NwsForwardAux);
+    case 3: return sizeof(NwsShaperDesc);
+    case 4: return sizeof(NwsGenericModel);
     default: return 0;
   }
 }

@@ -1,0 +1,696 @@
+// Runtime-size path: NeuralWaveshaping.forward for ANY gin configuration of the reference (models/neural_waveshaping.py:31-62,
+// models/modules/shaping.py:15-65, generators.py:11-48, dynamic.py:20-40): n_harmonics, n_waveshapers, shaping_fn_size,
+// TrainableNonlinearity.depth, GRU / embedding sizes, h_generator depth / width, ir_length, hop_length / control_hop,
+// out_channels, Reverb.sr * length_in_seconds, FastNEWT table size / range.
+//
+// The fused kernels of exciter_newt.hip / frame_mlps.hip / control_gru.hip / fir_noise.hip are compiled for the one
+// architecture the reference ships (gin/models/newt.gin).  Everything else runs here: plain fp32 VALU kernels with runtime
+// sizes, one stage per launch, the reference's own rounding chains where the result depends on them (F0 upsample, fp64
+// prefix sum, fl(fl(tau c)/sr), fl(fl(k phase) + shift), the LUT index chain).  Correct first: stage boundaries are
+// materialised in the caller's workspace (the oscillator bank (B, K, N) included), nothing is tuned.  No kernel here indexes
+// a private array with a runtime value (that would become scratch memory, which the build refuses): per-thread vectors of
+// runtime length live in LDS.
+#include "nws_common.h"
+
+namespace {
+
+constexpr float kTauF = 6.283185307179586f;  // fl32(math.tau)
+constexpr float kPiF = 3.141592653589793f;   // fl32(math.pi)
+
+// F.upsample(x, T*hop, mode="linear") for any hop (align_corners=False), the arithmetic of nws_lerp_coeff with a runtime
+// scale: src = (n + 0.5) * (T / N) - 0.5 with the scale computed like ATen's area_pixel_compute_scale (float(T) / float(N)).
+struct GLerp {
+  int i0, i1;
+  float w0, w1;
+};
+__device__ __forceinline__ GLerp g_lerp_coeff(int n, int T, float scale) {
+  float src = ((float)n + 0.5f) * scale - 0.5f;
+  src = src < 0.0f ? 0.0f : src;
+  const int i0 = (int)src;
+  GLerp c;
+  c.i0 = i0 < T - 1 ? i0 : T - 1;
+  c.i1 = i0 + 1 < T ? i0 + 1 : T - 1;
+  c.w1 = src - (float)i0;
+  c.w0 = 1.0f - c.w1;
+  return c;
+}
+
+// ---- GRU (models/neural_waveshaping.py:21-25, torch.nn.GRU gate order [r; z; n]) ---------------------------------------
+// W_hh transposed once per call (k-major) so that thread j's reads for a fixed k are coalesced over j.
+__global__ void g_transpose_kernel(const float* __restrict__ w, int rows, int cols, float* __restrict__ wt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int r = i / cols, c = i - r * cols;
+  wt[(size_t)c * rows + r] = w[i];
+}
+
+// one workgroup per utterance, thread j = hidden unit j (+ blockDim strides); h ping-pongs in LDS
+__global__ __launch_bounds__(256) void g_gru_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh_t,
+                                                    const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                                    const float* __restrict__ control, int C_total, int C_in, int H, int T,
+                                                    const float* __restrict__ h0, float* __restrict__ out,
+                                                    float* __restrict__ hT) {
+  extern __shared__ float lds[];   // h[2][H] | x[C_in]
+  float* hbuf = lds;
+  float* xs = lds + 2 * (size_t)H;
+  const int b = blockIdx.x;
+  for (int j = threadIdx.x; j < H; j += blockDim.x) hbuf[j] = h0 ? h0[(size_t)b * H + j] : 0.0f;
+  __syncthreads();
+  int cur = 0;
+  const int H3 = 3 * H;
+  for (int t = 0; t < T; ++t) {
+    for (int c = threadIdx.x; c < C_in; c += blockDim.x) xs[c] = control[((size_t)b * C_total + c) * T + t];
+    __syncthreads();
+    const float* hp = hbuf + (size_t)cur * H;
+    float* hn = hbuf + (size_t)(cur ^ 1) * H;
+    for (int j = threadIdx.x; j < H; j += blockDim.x) {
+      float ir = b_ih[j], iz = b_ih[H + j], in = b_ih[2 * H + j];
+      for (int c = 0; c < C_in; ++c) {
+        const float xv = xs[c];
+        ir = fmaf(w_ih[(size_t)j * C_in + c], xv, ir);
+        iz = fmaf(w_ih[(size_t)(H + j) * C_in + c], xv, iz);
+        in = fmaf(w_ih[(size_t)(2 * H + j) * C_in + c], xv, in);
+      }
+      float hr = b_hh[j], hz = b_hh[H + j], hnn = b_hh[2 * H + j];
+      for (int k = 0; k < H; ++k) {
+        const float hv = hp[k];
+        const float* wr = w_hh_t + (size_t)k * H3;
+        hr = fmaf(wr[j], hv, hr);
+        hz = fmaf(wr[H + j], hv, hz);
+        hnn = fmaf(wr[2 * H + j], hv, hnn);
+      }
+      const float r = 1.0f / (1.0f + expf(-(ir + hr)));
+      const float z = 1.0f / (1.0f + expf(-(iz + hz)));
+      const float nn = tanhf(in + r * hnn);
+      const float hv = (1.0f - z) * nn + z * hp[j];
+      hn[j] = hv;
+      out[((size_t)b * T + t) * H + j] = hv;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (hT)
+    for (int j = threadIdx.x; j < H; j += blockDim.x) hT[(size_t)b * H + j] = hbuf[(size_t)cur * H + j];
+}
+
+// (B, T, H) -> (B, H, T) (the GRU writes frame-major, the Conv1d stacks read channel-major)
+__global__ void g_bth_to_bht_kernel(const float* __restrict__ x, int T, int H, float* __restrict__ y) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T * H) return;
+  const int h = i / T, t = i - h * T;
+  y[(size_t)b * H * T + i] = x[((size_t)b * T + t) * H + h];
+}
+
+// ---- phase: upsample + double-accumulated prefix sum + the reference's fp32 chain (generators.py:59) -------------------
+// one workgroup (1024 threads) per utterance; thread = contiguous chunk; exact fp64 sums, so the chunking is immaterial
+__global__ __launch_bounds__(1024) void g_phase_kernel(const float* __restrict__ f0, const float* __restrict__ f0_up_in, int T,
+                                                       int N, float scale, float sample_rate, float* __restrict__ f0_up_out,
+                                                       float* __restrict__ phase_out) {
+  __shared__ double tot[1024];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int per = (N + 1023) / 1024;
+  const int n0 = tid * per, n1 = n0 + per < N ? n0 + per : N;
+  const float* x = f0 ? f0 + (size_t)b * T : nullptr;
+  auto value = [&](int n) {
+    if (f0_up_in) return f0_up_in[(size_t)b * N + n];
+    const GLerp L = g_lerp_coeff(n, T, scale);
+    return fmaf(L.w0, x[L.i0], L.w1 * x[L.i1]);
+  };
+  double s = 0.0;
+  for (int n = n0; n < n1; ++n) s += (double)value(n);
+  tot[tid] = s;
+  __syncthreads();
+  // exclusive prefix over the 1024 chunk sums (Hillis-Steele on doubles in LDS)
+  for (int off = 1; off < 1024; off <<= 1) {
+    const double v = tid >= off ? tot[tid - off] : 0.0;
+    __syncthreads();
+    tot[tid] += v;
+    __syncthreads();
+  }
+  double run = tid > 0 ? tot[tid - 1] : 0.0;
+  for (int n = n0; n < n1; ++n) {
+    const float v = value(n);
+    run += (double)v;
+    const float c = (float)run;                         // torch's CPU cumsum: accumulate in double, round per element
+    const float tc = kTauF * c;                         // math.tau * cumsum      (one rounding)
+    phase_out[(size_t)b * N + n] = __fdiv_rn(tc, sample_rate);   // ... / sample_rate (true division)
+    if (f0_up_out) f0_up_out[(size_t)b * N + n] = v;
+  }
+}
+
+// ---- oscillator bank (generators.py:58-66): out[b][k-1][n] = sin(fl(fl(k phase) + shift_k)) * [fl(f0 k) < sr/2] --------
+__global__ __launch_bounds__(256) void g_oscillator_kernel(const float* __restrict__ f0_up, const float* __restrict__ phase,
+                                                           const float* __restrict__ phase_u, const float* __restrict__ rand_phase,
+                                                           int K, int N, float sample_rate, float* __restrict__ out) {
+  const int b = blockIdx.z;
+  const int k = blockIdx.y + 1;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const float shift = phase_u[k - 1] * rand_phase[k - 1] - kPiF;     // generators.py:54-56, two roundings
+  const float kf = (float)k;
+  const float f0n = f0_up[(size_t)b * N + n];
+  const float arg = kf * phase[(size_t)b * N + n] + shift;            // two roundings (-ffp-contract=off)
+  const float v = nws_sinf(arg);
+  out[((size_t)b * K + (k - 1)) * N + n] = (f0n * kf) < sample_rate * 0.5f ? v : 0.0f;
+}
+
+// ---- Conv1d(Cin, Cout, 1) on (B, Cin, N): harmonic_mixer (neural_waveshaping.py:54), newt.mixer (shaping.py:63-65) ------
+// thread = sample, blockIdx.y = output-channel tile of 8 (weights are wave-uniform: scalar loads), blockIdx.z = utterance
+__global__ __launch_bounds__(256) void g_conv1x1_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, int Cin, int Cout, int N,
+                                                        float* __restrict__ y) {
+  const int b = blockIdx.z;
+  const int o0 = blockIdx.y * 8;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+  const float* xp = x + (size_t)b * Cin * N + n;
+  auto wrow = [&](int o) { return w + (size_t)(o < Cout ? o : Cout - 1) * Cin; };
+  const float *w0 = wrow(o0), *w1 = wrow(o0 + 1), *w2 = wrow(o0 + 2), *w3 = wrow(o0 + 3), *w4 = wrow(o0 + 4),
+              *w5 = wrow(o0 + 5), *w6 = wrow(o0 + 6), *w7 = wrow(o0 + 7);
+  for (int c = 0; c < Cin; ++c) {
+    const float xv = xp[(size_t)c * N];
+    a0 = fmaf(w0[c], xv, a0);
+    a1 = fmaf(w1[c], xv, a1);
+    a2 = fmaf(w2[c], xv, a2);
+    a3 = fmaf(w3[c], xv, a3);
+    a4 = fmaf(w4[c], xv, a4);
+    a5 = fmaf(w5[c], xv, a5);
+    a6 = fmaf(w6[c], xv, a6);
+    a7 = fmaf(w7[c], xv, a7);
+  }
+  float* yp = y + (size_t)b * Cout * N + n;
+  auto put = [&](int o, float v) {
+    if (o < Cout) yp[(size_t)o * N] = v + (bias ? bias[o] : 0.0f);
+  };
+  put(o0, a0);
+  put(o0 + 1, a1);
+  put(o0 + 2, a2);
+  put(o0 + 3, a3);
+  put(o0 + 4, a4);
+  put(o0 + 5, a5);
+  put(o0 + 6, a6);
+  put(o0 + 7, a7);
+}
+
+// ---- shapers ------------------------------------------------------------------------------------------------------------
+struct GShaper {
+  int S, width, depth;          // TrainableNonlinearity(channels = S, width, depth)
+  const float* in_scale;        // (S)
+  const float* w[8];            // layer i: depth 1: (S); else i = 0: (S*width), 0 < i < depth-1: (S*width, width), last: (S, width)
+  const float* b[8];
+  const float* lut;             // (S, lut_size) or NULL
+  int lut_size;
+  float lut_min, lut_max;
+};
+
+// exact sin-MLP of one (sample, shaper): hidden activations in LDS columns hb[2][width][blockDim] (runtime width).
+// Rounding chain of the reference (shaping.py:36-37): grouped Conv1d = bias + sum (sequential FMAs are within an ulp of
+// ATen's order), torch.sin -> nws_sinf.
+__device__ __forceinline__ float g_exact_shaper(const GShaper& P, int s, float x, float* hb, int tid, int nthreads) {
+  float a = P.in_scale[s] * x;
+  if (P.depth == 1) return nws_sinf(fmaf(P.w[0][s], a, P.b[0][s]));
+  const int W = P.width;
+  float* cur = hb;
+  float* nxt = hb + (size_t)W * nthreads;
+  for (int j = 0; j < W; ++j) cur[(size_t)j * nthreads + tid] = nws_sinf(fmaf(P.w[0][s * W + j], a, P.b[0][s * W + j]));
+  for (int layer = 1; layer < P.depth - 1; ++layer) {
+    const float* wl = P.w[layer] + (size_t)s * W * W;
+    const float* bl = P.b[layer] + (size_t)s * W;
+    for (int i = 0; i < W; ++i) {
+      float acc = bl[i];
+      for (int j = 0; j < W; ++j) acc = fmaf(wl[i * W + j], cur[(size_t)j * nthreads + tid], acc);
+      nxt[(size_t)i * nthreads + tid] = nws_sinf(acc);
+    }
+    float* t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+  const float* wl = P.w[P.depth - 1] + (size_t)s * W;
+  float acc = P.b[P.depth - 1][s];
+  for (int j = 0; j < W; ++j) acc = fmaf(wl[j], cur[(size_t)j * nthreads + tid], acc);
+  return nws_sinf(acc);
+}
+
+// FastNEWT.shaping_fn (shaping.py:136-151), the reference's chain rounding for rounding (index scale `size`, clamped floor,
+// fraction against the CLAMPED floor: linear extrapolation below the table, flat above)
+__device__ __forceinline__ float g_lut_shaper(const GShaper& P, int s, float x) {
+  const float t = (float)P.lut_size * (x - P.lut_min);
+  const float idx = __fdiv_rn(t, P.lut_max - P.lut_min);
+  float fl = floorf(idx);
+  fl = fmaxf(fl, 0.0f);
+  fl = fminf(fl, (float)(P.lut_size - 1));
+  const int lo = (int)fl;
+  const int up = lo + 1 < P.lut_size ? lo + 1 : P.lut_size - 1;
+  const float fract = idx - fl;
+  const float lv = P.lut[(size_t)s * P.lut_size + lo], uv = P.lut[(size_t)s * P.lut_size + up];
+  return (uv - lv) * fract + lv;
+}
+
+// TrainableNonlinearity.forward / FastNEWT.shaping_fn on (B, S, N): y = shaper_s(x)
+__global__ __launch_bounds__(128) void g_shaper_apply_kernel(GShaper P, const float* __restrict__ x, int64_t N,
+                                                             float* __restrict__ y) {
+  extern __shared__ float hb[];
+  const int s = blockIdx.y % P.S;
+  const size_t row = blockIdx.y;
+  for (int64_t n = (int64_t)blockIdx.x * 128 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 128) {
+    const float v = x[row * N + n];
+    y[row * N + n] = P.lut ? g_lut_shaper(P, s, v) : g_exact_shaper(P, s, v, hb, threadIdx.x, 128);
+  }
+}
+
+// FastNEWT._init_lookup_table (shaping.py:107-119): table[s][i] = shaper_s(linspace(min, max, size)[i]); torch.linspace's
+// fp32 kernel: start + step * i for the first half, end - step * (size - 1 - i) for the second
+__global__ __launch_bounds__(128) void g_shaper_table_kernel(GShaper P, int size, float tmin, float tmax,
+                                                             float* __restrict__ table) {
+  extern __shared__ float hb[];
+  const int s = blockIdx.y;
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  const float step = (tmax - tmin) / (float)(size - 1);
+  const int half = size / 2;
+  const float xv = i < half ? tmin + step * (float)i : tmax - step * (float)(size - 1 - i);
+  const float v = g_exact_shaper(P, s, xv, hb, threadIdx.x, 128);     // every thread takes part (LDS columns), stores guarded
+  if (i < size) table[(size_t)s * size + i] = v;
+}
+
+// NEWT.forward up to the mixer (shaping.py:68-76): film (B, 4S, T) channel-major, upsampled xhop on the fly;
+// v[b][s][n] = g_norm * shaper_s(g_idx * e + b_idx) + b_norm   (FiLM: multiply then add, two roundings, dynamic.py:8)
+__global__ __launch_bounds__(128) void g_film_shaper_kernel(GShaper P, const float* __restrict__ exciter,
+                                                            const float* __restrict__ film, int T, int N, float scale,
+                                                            float* __restrict__ out) {
+  extern __shared__ float hb[];
+  const int b = blockIdx.z, s = blockIdx.y;
+  const int S = P.S;
+  const float* fb = film + (size_t)b * 4 * S * T;
+  for (int n = blockIdx.x * 128 + threadIdx.x; n < N; n += gridDim.x * 128) {
+    const GLerp lc = g_lerp_coeff(n, T, scale);
+    auto lerp = [&](int ch) { return fmaf(lc.w0, fb[(size_t)ch * T + lc.i0], lc.w1 * fb[(size_t)ch * T + lc.i1]); };
+    const float g_i = lerp(s), b_i = lerp(S + s), g_n = lerp(2 * S + s), b_n = lerp(3 * S + s);
+    const float x = g_i * exciter[((size_t)b * S + s) * N + n] + b_i;
+    const float sh = P.lut ? g_lut_shaper(P, s, x) : g_exact_shaper(P, s, x, hb, threadIdx.x, 128);
+    out[((size_t)b * S + s) * N + n] = g_n * sh + b_n;
+  }
+}
+
+// ---- FIR noise (generators.py:21-35) for any ir_length L / hop --------------------------------------------------------
+// zero-phase FIR design: fir[b][t][n] = window[n] * roll(irfft(H[b, :, t]), L/2)[n]; irfft of a real half-spectrum as a
+// cosine sum (cos table of L entries in LDS, built in double)
+__global__ __launch_bounds__(256) void g_fir_design_kernel(const float* __restrict__ H, const float* __restrict__ window, int L,
+                                                           int T, float* __restrict__ fir) {
+  extern __shared__ float lds[];   // cos[L] | Hs[L/2 + 1]
+  float* ct = lds;
+  float* hs = lds + L;
+  const int b = blockIdx.y, t = blockIdx.x;
+  const int nb = L / 2 + 1;
+  for (int i = threadIdx.x; i < L; i += 256) ct[i] = (float)cospi(2.0 * (double)i / (double)L);
+  for (int k = threadIdx.x; k < nb; k += 256) hs[k] = H[((size_t)b * nb + k) * T + t];
+  __syncthreads();
+  const float inv = 1.0f / (float)L;
+  for (int n = threadIdx.x; n < L; n += 256) {
+    const int m = (n + L - L / 2) % L;                       // roll(h, L/2): h_rolled[n] = h[(n - L/2) mod L]
+    float acc = 0.0f;
+    int idx = m % L;                                         // (k m) mod L, advanced incrementally
+    for (int k = 1; k < L / 2; ++k) {
+      acc = fmaf(hs[k], ct[idx], acc);
+      idx += m;
+      if (idx >= L) idx -= L;
+    }
+    float v = hs[0] + 2.0f * acc;
+    v += (m & 1) ? -hs[L / 2] : hs[L / 2];
+    fir[((size_t)b * T + t) * L + n] = window[n] * (v * inv);
+  }
+}
+
+// rectangular-window STFT of the shared noise (reflect-padded by L/2), per-frame L-point CIRCULAR convolution with the
+// frame's taps, overlap-add divided by the number of covering frames (torch.istft with window = ones), first hop*T samples;
+// out = noise branch + sum over channels of add_in (B, O, N) (the cat + sum(1) of neural_waveshaping.py:85-86)
+__global__ __launch_bounds__(256) void g_fir_noise_kernel(const float* __restrict__ fir, const float* __restrict__ noise, int M,
+                                                          int L, int hop, int T, const float* __restrict__ add_in, int O,
+                                                          int N, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  int t_hi = n / hop;
+  if (t_hi > T - 1) t_hi = T - 1;
+  float acc = 0.0f;
+  int count = 0;
+  for (int t = t_hi; t >= 0 && hop * t + L > n; --t) {
+    const int j = n - hop * t;                    // position inside frame t
+    const float* h = fir + ((size_t)b * T + t) * L;
+    const int base = hop * t - L / 2;             // frame_t[i] = noise[reflect(base + i)]
+    float y = 0.0f;
+    for (int k = 0; k < L; ++k) {
+      int i = j - k;
+      if (i < 0) i += L;
+      int p = base + i;
+      if (p < 0) p = -p;
+      if (p >= M) p = 2 * (M - 1) - p;
+      y = fmaf(h[k], noise[p], y);
+    }
+    acc += y;
+    ++count;
+  }
+  float v = acc / (float)count;
+  if (add_in)
+    for (int o = 0; o < O; ++o) v += add_in[((size_t)b * O + o) * N + n];
+  out[(size_t)b * N + n] = v;
+}
+
+// ---- reverb, time-domain form for lengths the four-step FFT plan does not factor (shaping.py:161-173) -------------------
+// y[n] = x[n] + sum_{m=1..ir_len} ir[m-1] * xz[(n - m) mod Lc], xz = x zero-padded to Lc = max(N, ir_len + 1)
+__global__ __launch_bounds__(256) void g_reverb_direct_kernel(const float* __restrict__ x, const float* __restrict__ ir,
+                                                              int ir_len, int N, int Lc, float* __restrict__ y) {
+  extern __shared__ float tile[];     // 256 + 1024 x-samples | 1024 taps
+  float* xs = tile;
+  float* hs = tile + 1280;
+  const int b = blockIdx.y;
+  const int n0 = blockIdx.x * 256;
+  const int n = n0 + threadIdx.x;
+  const float* xb = x + (size_t)b * N;
+  float acc = 0.0f;
+  for (int m0 = 1; m0 <= ir_len; m0 += 1024) {
+    // taps m0 .. m0+1023; x indices (n0 - m0 - 1023) .. (n0 + 255 - m0), circular over Lc
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1024; i += 256) hs[i] = m0 + i <= ir_len ? ir[m0 + i - 1] : 0.0f;
+    const int lo = n0 - m0 - 1023;
+    for (int i = threadIdx.x; i < 1280; i += 256) {
+      int p = (lo + i) % Lc;
+      if (p < 0) p += Lc;
+      xs[i] = p < N ? xb[p] : 0.0f;
+    }
+    __syncthreads();
+    // tap m0 + i pairs with x index n - m0 - i = lo + (threadIdx.x + 1023 - i)
+    for (int i = 0; i < 1024; ++i) acc = fmaf(hs[i], xs[threadIdx.x + 1023 - i], acc);
+  }
+  if (n < N) y[(size_t)b * N + n] = xb[n] + acc;
+}
+
+bool shaper_ok(const NwsShaperDesc* d) {
+  if (!d || d->n_shapers <= 0) return false;
+  if (d->lut) return d->lut_size >= 2 && d->lut_max > d->lut_min;
+  if (d->depth < 1 || d->depth > 8 || d->width < 1 || !d->in_scale) return false;
+  for (int i = 0; i < d->depth; ++i)
+    if (!d->w[i] || !d->b[i]) return false;
+  return true;
+}
+
+GShaper to_dev(const NwsShaperDesc* d) {
+  GShaper g{};
+  g.S = d->n_shapers;
+  g.width = d->width;
+  g.depth = d->depth;
+  g.in_scale = d->in_scale;
+  for (int i = 0; i < 8; ++i) {
+    g.w[i] = d->w[i];
+    g.b[i] = d->b[i];
+  }
+  g.lut = d->lut;
+  g.lut_size = d->lut_size;
+  g.lut_min = d->lut_min;
+  g.lut_max = d->lut_max;
+  return g;
+}
+
+// LDS of the exact shapers: hb[2][width][128 threads]
+size_t shaper_lds(const NwsShaperDesc* d) { return d->lut ? 16 : (size_t)2 * d->width * 128 * sizeof(float); }
+
+int ensure_lds(const void* fn, unsigned long long& mask) {
+  if (nws_first_use_on_device(mask)) {
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+  }
+  return NWS_OK;
+}
+
+size_t al(size_t b) { return (b + 255) & ~size_t(255); }
+
+}  // namespace
+
+extern "C" {
+
+size_t nws_g_gru_workspace_bytes(int hidden) { return hidden > 0 ? al((size_t)3 * hidden * hidden * sizeof(float)) : 0; }
+
+int nws_g_gru(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, const float* control, int B,
+              int C_total, int C_in, int hidden, int T, const float* h0, float* out, float* hT, void* workspace,
+              size_t workspace_bytes, void* stream) {
+  if (!w_ih || !w_hh || !b_ih || !b_hh || !control || !out || !workspace) return NWS_ERR_BAD_ARG;
+  if (B <= 0 || T <= 0 || hidden <= 0 || C_in <= 0 || C_total < C_in) return NWS_ERR_BAD_ARG;
+  if (workspace_bytes < nws_g_gru_workspace_bytes(hidden)) return NWS_ERR_WORKSPACE;
+  const size_t lds = ((size_t)2 * hidden + C_in) * sizeof(float);
+  if (lds > 160 * 1024) return NWS_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  float* wt = static_cast<float*>(workspace);
+  const int cells = 3 * hidden * hidden;
+  g_transpose_kernel<<<(cells + 255) / 256, 256, 0, st>>>(w_hh, 3 * hidden, hidden, wt);
+  NWS_CHECK_LAUNCH();
+  static unsigned long long attr = 0;
+  if (int rc = ensure_lds(reinterpret_cast<const void*>(g_gru_kernel), attr)) return rc;
+  g_gru_kernel<<<B, 256, lds, st>>>(w_ih, wt, b_ih, b_hh, control, C_total, C_in, hidden, T, h0, out, hT);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+int nws_g_bth_to_bht(const float* x, int B, int T, int H, float* y, void* stream) {
+  if (!x || !y || B <= 0 || T <= 0 || H <= 0) return NWS_ERR_BAD_ARG;
+  if (B > 65535) return NWS_ERR_UNSUPPORTED;
+  g_bth_to_bht_kernel<<<dim3((T * H + 255) / 256, B), 256, 0, (hipStream_t)stream>>>(x, T, H, y);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+int nws_g_phase(const float* f0, const float* f0_up, int B, int T, int hop, float sample_rate, float* f0_up_out,
+                float* phase_out, void* stream) {
+  if ((!f0) == (!f0_up) || !phase_out || B <= 0 || T <= 0 || hop <= 0 || !(sample_rate > 0.0f)) return NWS_ERR_BAD_ARG;
+  const long long N = (long long)T * hop;     // f0_up given: T = N, hop = 1
+  if (N > (1ll << 30)) return NWS_ERR_UNSUPPORTED;
+  const float scale = (float)T / (float)N;
+  g_phase_kernel<<<B, 1024, 0, (hipStream_t)stream>>>(f0, f0_up, T, (int)N, scale, sample_rate, f0_up_out, phase_out);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+int nws_g_oscillator(const float* f0_up, const float* phase, const float* phase_u, const float* rand_phase, int K, int B, int N,
+                     float sample_rate, float* out, void* stream) {
+  if (!f0_up || !phase || !phase_u || !rand_phase || !out || K <= 0 || B <= 0 || N <= 0) return NWS_ERR_BAD_ARG;
+  if (K > 65535 || B > 65535) return NWS_ERR_UNSUPPORTED;
+  g_oscillator_kernel<<<dim3((N + 255) / 256, K, B), 256, 0, (hipStream_t)stream>>>(f0_up, phase, phase_u, rand_phase, K, N,
+                                                                                     sample_rate, out);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+int nws_g_conv1x1(const float* x, const float* w, const float* bias, int B, int Cin, int Cout, int N, float* y, void* stream) {
+  if (!x || !w || !y || B <= 0 || Cin <= 0 || Cout <= 0 || N <= 0) return NWS_ERR_BAD_ARG;
+  if (B > 65535 || (Cout + 7) / 8 > 65535) return NWS_ERR_UNSUPPORTED;
+  g_conv1x1_kernel<<<dim3((N + 255) / 256, (Cout + 7) / 8, B), 256, 0, (hipStream_t)stream>>>(x, w, bias, Cin, Cout, N, y);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+int nws_g_shaper_apply(const NwsShaperDesc* d, const float* x, int64_t rows, int64_t N, float* y, void* stream) {
+  if (!shaper_ok(d) || !x || !y || rows <= 0 || N <= 0) return NWS_ERR_BAD_ARG;
+  if (rows > 65535 || rows % d->n_shapers) return NWS_ERR_UNSUPPORTED;
+  const size_t lds = shaper_lds(d);
+  if (lds > 160 * 1024) return NWS_ERR_UNSUPPORTED;
+  static unsigned long long attr = 0;
+  if (int rc = ensure_lds(reinterpret_cast<const void*>(g_shaper_apply_kernel), attr)) return rc;
+  const int gx = (int)((N + 127) / 128 < 4096 ? (N + 127) / 128 : 4096);
+  g_shaper_apply_kernel<<<dim3(gx, (unsigned)rows), 128, lds, (hipStream_t)stream>>>(to_dev(d), x, N, y);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+int nws_g_shaper_table(const NwsShaperDesc* d, int table_size, float table_min, float table_max, float* table_out, void* stream) {
+  if (!shaper_ok(d) || d->lut || !table_out || table_size < 2 || !(table_max > table_min)) return NWS_ERR_BAD_ARG;
+  if (d->n_shapers > 65535) return NWS_ERR_UNSUPPORTED;
+  const size_t lds = shaper_lds(d);
+  if (lds > 160 * 1024) return NWS_ERR_UNSUPPORTED;
+  static unsigned long long attr = 0;
+  if (int rc = ensure_lds(reinterpret_cast<const void*>(g_shaper_table_kernel), attr)) return rc;
+  g_shaper_table_kernel<<<dim3((table_size + 127) / 128, d->n_shapers), 128, lds, (hipStream_t)stream>>>(
+      to_dev(d), table_size, table_min, table_max, table_out);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+int nws_g_film_shaper(const NwsShaperDesc* d, const float* exciter, const float* film, int B, int T, int hop, float* out,
+                      void* stream) {
+  if (!shaper_ok(d) || !exciter || !film || !out || B <= 0 || T <= 0 || hop <= 0) return NWS_ERR_BAD_ARG;
+  if (B > 65535 || d->n_shapers > 65535) return NWS_ERR_UNSUPPORTED;
+  const size_t lds = shaper_lds(d);
+  if (lds > 160 * 1024) return NWS_ERR_UNSUPPORTED;
+  static unsigned long long attr = 0;
+  if (int rc = ensure_lds(reinterpret_cast<const void*>(g_film_shaper_kernel), attr)) return rc;
+  const int N = T * hop;
+  const int gx = (N + 127) / 128 < 2048 ? (N + 127) / 128 : 2048;
+  g_film_shaper_kernel<<<dim3(gx, d->n_shapers, B), 128, lds, (hipStream_t)stream>>>(to_dev(d), exciter, film, T, N,
+                                                                                     (float)T / (float)N, out);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+int nws_g_fir_design(const float* H, const float* window, int fir_len, int B, int T, float* fir_out, void* stream) {
+  if (!H || !window || !fir_out || B <= 0 || T <= 0 || fir_len < 2 || (fir_len & 1)) return NWS_ERR_BAD_ARG;
+  if (B > 65535) return NWS_ERR_UNSUPPORTED;
+  const size_t lds = ((size_t)fir_len + fir_len / 2 + 1) * sizeof(float);
+  if (lds > 160 * 1024) return NWS_ERR_UNSUPPORTED;
+  static unsigned long long attr = 0;
+  if (int rc = ensure_lds(reinterpret_cast<const void*>(g_fir_design_kernel), attr)) return rc;
+  g_fir_design_kernel<<<dim3(T, B), 256, lds, (hipStream_t)stream>>>(H, window, fir_len, T, fir_out);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+int nws_g_fir_noise(const float* fir, const float* noise, int fir_len, int hop, int B, int T, const float* add_in,
+                    int add_channels, float* out, void* stream) {
+  if (!fir || !noise || !out || B <= 0 || T <= 0 || hop <= 0 || fir_len < 2 || (fir_len & 1)) return NWS_ERR_BAD_ARG;
+  if (add_in && add_channels <= 0) return NWS_ERR_BAD_ARG;
+  // torch.istft needs every sample of the first hop*T covered (fir_len >= hop) and torch.stft's reflect padding needs
+  // fir_len / 2 < hop*T - 1
+  const long long N = (long long)T * hop;
+  if (fir_len < hop || fir_len / 2 >= N - 1 || B > 65535) return NWS_ERR_UNSUPPORTED;
+  g_fir_noise_kernel<<<dim3((unsigned)((N + 255) / 256), B), 256, 0, (hipStream_t)stream>>>(fir, noise, (int)N - 1, fir_len, hop,
+                                                                                            T, add_in, add_channels, (int)N, out);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+int nws_g_reverb_direct(const float* x, const float* ir, int ir_len, int B, int N, float* y, void* stream) {
+  if (!x || !ir || !y || ir_len <= 0 || B <= 0 || N <= 0) return NWS_ERR_BAD_ARG;
+  if (B > 65535 || x == y) return NWS_ERR_UNSUPPORTED;
+  const int Lc = N > ir_len + 1 ? N : ir_len + 1;
+  g_reverb_direct_kernel<<<dim3((N + 255) / 256, B), 256, (1280 + 1024) * sizeof(float), (hipStream_t)stream>>>(x, ir, ir_len, N,
+                                                                                                               Lc, y);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+// ---- whole forward for any configuration -----------------------------------------------------------------------------
+static bool model_ok(const NwsGenericModel* m) {
+  if (!m) return false;
+  if (m->control_size < 1 || m->gru_hidden < 1 || m->embedding < 1 || m->n_harmonics < 1 || m->n_shapers < 1 || m->hop < 1)
+    return false;
+  if (m->newt_mlp_depth < 1 || m->newt_mlp_depth > 8 || m->hgen_depth < 1 || m->hgen_depth > 8 || m->hgen_hidden < 1) return false;
+  if (m->fir_len < 2 || (m->fir_len & 1) || m->out_channels < 1 || m->ir_len < 1) return false;
+  if (!m->gru_w_ih || !m->gru_w_hh || !m->gru_b_ih || !m->gru_b_hh || !m->proj_w || !m->proj_b || !m->mixer_w || !m->mixer_b ||
+      !m->newt_out_w || !m->newt_out_b || !m->noise_window || !m->ir)
+    return false;
+  for (int i = 0; i < m->newt_mlp_depth; ++i)
+    if (!m->newt_mlp_w[i] || !m->newt_mlp_b[i] || (i < m->newt_mlp_depth - 1 && (!m->newt_ln_g[i] || !m->newt_ln_b[i]))) return false;
+  for (int i = 0; i < m->hgen_depth; ++i)
+    if (!m->hgen_w[i] || !m->hgen_b[i] || (i < m->hgen_depth - 1 && (!m->hgen_ln_g[i] || !m->hgen_ln_b[i]))) return false;
+  return shaper_ok(&m->shaper) && m->shaper.n_shapers == m->n_shapers;
+}
+
+struct GArena {
+  float *gru_bth, *gru_bht, *emb, *film, *H, *fir, *f0_up, *phase, *osc, *exciter, *shaped, *newt, *pre;
+  void* gru_ws;
+  size_t gru_ws_bytes;
+  bool ok;
+};
+
+static GArena g_carve(const NwsGenericModel* m, int B, int T, void* ws, size_t bytes) {
+  const size_t N = (size_t)T * m->hop;
+  char* p = static_cast<char*>(ws);
+  size_t left = bytes;
+  bool ok = true;
+  auto take = [&](size_t b) -> void* {
+    b = al(b);
+    if (b > left) {
+      ok = false;
+      return nullptr;
+    }
+    void* r = p;
+    p += b;
+    left -= b;
+    return r;
+  };
+  auto fl = [&](size_t n) { return static_cast<float*>(take(n * sizeof(float))); };
+  GArena a{};
+  a.gru_ws_bytes = nws_g_gru_workspace_bytes(m->gru_hidden);
+  a.gru_ws = take(a.gru_ws_bytes);
+  a.gru_bth = fl((size_t)B * T * m->gru_hidden);
+  a.gru_bht = fl((size_t)B * T * m->gru_hidden);
+  a.emb = fl((size_t)B * T * m->embedding);
+  a.film = fl((size_t)B * T * 4 * m->n_shapers);
+  a.H = fl((size_t)B * T * (m->fir_len / 2 + 1));
+  a.fir = fl((size_t)B * T * m->fir_len);
+  a.f0_up = fl((size_t)B * N);
+  a.phase = fl((size_t)B * N);
+  a.osc = fl((size_t)B * m->n_harmonics * N);
+  a.exciter = fl((size_t)B * m->n_shapers * N);
+  a.shaped = a.osc;                                  // the oscillator bank is dead once the exciter exists
+  if (m->n_shapers > m->n_harmonics) a.shaped = fl((size_t)B * m->n_shapers * N);
+  a.newt = fl((size_t)B * m->out_channels * N);
+  a.pre = fl((size_t)B * N);
+  a.ok = ok;
+  return a;
+}
+
+size_t nws_forward_generic_workspace_bytes(const NwsGenericModel* m, int B, int T) {
+  if (!m || B <= 0 || T <= 0 || m->hop <= 0) return 0;
+  const size_t N = (size_t)T * m->hop;
+  auto fb = [](size_t n) { return al(n * sizeof(float)); };
+  size_t t = nws_g_gru_workspace_bytes(m->gru_hidden);
+  t += 2 * fb((size_t)B * T * m->gru_hidden) + fb((size_t)B * T * m->embedding) + fb((size_t)B * T * 4 * m->n_shapers);
+  t += fb((size_t)B * T * (m->fir_len / 2 + 1)) + fb((size_t)B * T * m->fir_len) + 2 * fb((size_t)B * N);
+  t += fb((size_t)B * m->n_harmonics * N) + fb((size_t)B * m->n_shapers * N);
+  if (m->n_shapers > m->n_harmonics) t += fb((size_t)B * m->n_shapers * N);
+  t += fb((size_t)B * m->out_channels * N) + fb((size_t)B * N);
+  return t;
+}
+
+int nws_forward_generic(const NwsGenericModel* m, const float* f0, const float* control, int B, int C, int T, float sample_rate,
+                        const float* phase_u, const float* rand_phase, const float* noise, const NwsReverbPlan* plan,
+                        const void* reverb_tables, const void* reverb_spectrum, void* reverb_workspace,
+                        size_t reverb_workspace_bytes, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!model_ok(m) || !f0 || !control || !phase_u || !rand_phase || !noise || !out || !workspace) return NWS_ERR_BAD_ARG;
+  if (B <= 0 || T < 2 || C < m->control_size) return NWS_ERR_BAD_ARG;
+  const GArena a = g_carve(m, B, T, workspace, workspace_bytes);
+  if (!a.ok) return NWS_ERR_WORKSPACE;
+  const int N = T * m->hop;
+  const int S = m->n_shapers, K = m->n_harmonics, nb = m->fir_len / 2 + 1;
+  int rc;
+#define G(call)                  \
+  do {                           \
+    rc = (call);                 \
+    if (rc != NWS_OK) return rc; \
+  } while (0)
+  // control encoder (neural_waveshaping.py:69-72, :24-26)
+  G(nws_g_gru(m->gru_w_ih, m->gru_w_hh, m->gru_b_ih, m->gru_b_hh, control, B, C, m->control_size, m->gru_hidden, T, nullptr,
+              a.gru_bth, nullptr, a.gru_ws, a.gru_ws_bytes, stream));
+  G(nws_g_bth_to_bht(a.gru_bth, B, T, m->gru_hidden, a.gru_bht, stream));
+  {
+    const float* w1[1] = {m->proj_w};
+    const float* b1[1] = {m->proj_b};
+    const float* none[1] = {nullptr};
+    G(nws_td_mlp(a.gru_bht, B, m->gru_hidden, m->embedding, m->embedding, 1, T, w1, b1, none, none, m->ln_eps, m->leaky_slope,
+                 a.emb, stream));
+  }
+  // frame-rate MLPs (shaping.py:68, neural_waveshaping.py:82)
+  G(nws_td_mlp(a.emb, B, m->embedding, m->embedding, 4 * S, m->newt_mlp_depth, T, m->newt_mlp_w, m->newt_mlp_b, m->newt_ln_g,
+               m->newt_ln_b, m->ln_eps, m->leaky_slope, a.film, stream));
+  G(nws_td_mlp(a.emb, B, m->embedding, m->hgen_hidden, nb, m->hgen_depth, T, m->hgen_w, m->hgen_b, m->hgen_ln_g, m->hgen_ln_b,
+               m->ln_eps, m->leaky_slope, a.H, stream));
+  // exciter (neural_waveshaping.py:75-76, :64-67)
+  G(nws_g_phase(f0, nullptr, B, T, m->hop, sample_rate, a.f0_up, a.phase, stream));
+  G(nws_g_oscillator(a.f0_up, a.phase, phase_u, rand_phase, K, B, N, sample_rate, a.osc, stream));
+  G(nws_g_conv1x1(a.osc, m->mixer_w, m->mixer_b, B, K, S, N, a.exciter, stream));
+  // NEWT (shaping.py:67-79)
+  G(nws_g_film_shaper(&m->shaper, a.exciter, a.film, B, T, m->hop, a.shaped, stream));
+  G(nws_g_conv1x1(a.shaped, m->newt_out_w, m->newt_out_b, B, S, m->out_channels, N, a.newt, stream));
+  // noise branch + branch sum (generators.py:21-35, neural_waveshaping.py:82-86)
+  G(nws_g_fir_design(a.H, m->noise_window, m->fir_len, B, T, a.fir, stream));
+  G(nws_g_fir_noise(a.fir, noise, m->fir_len, m->hop, B, T, a.newt, m->out_channels, a.pre, stream));
+  // reverb (shaping.py:161-173): four-step FFT when the circular length factors, time-domain form otherwise
+  if (plan && reverb_tables && reverb_spectrum && reverb_workspace) {
+    G(nws_reverb(plan, reverb_tables, reverb_spectrum, a.pre, B, N, out, reverb_workspace, reverb_workspace_bytes, stream));
+  } else {
+    G(nws_g_reverb_direct(a.pre, m->ir, m->ir_len, B, N, out, stream));
+  }
+#undef G
+  return NWS_OK;
+}
+
+}  // extern "C"

@@ -527,6 +527,202 @@ Tensor loudness(const Tensor& audio, const Tensor& dft, int64_t n_fft, int64_t h
   return out;
 }
 
+// ---- runtime-size path (csrc/generic.hip): any gin configuration of the reference --------------------------------------
+template <class T>
+const T* struct_of(const Tensor& desc, const char* name) {
+  TORCH_CHECK(desc.device().is_cpu() && desc.scalar_type() == at::kByte && desc.is_contiguous() && (size_t)desc.numel() == sizeof(T),
+              name, ": expected a contiguous CPU uint8 tensor of ", sizeof(T), " bytes, got ", desc.sizes());
+  return reinterpret_cast<const T*>(desc.data_ptr());
+}
+
+Tensor forward_generic(const Tensor& gdesc, const Tensor& f0, const Tensor& control, const Tensor& phase_u, const Tensor& rand_phase,
+                       const Tensor& noise, const OptTensor& plan_t, const OptTensor& tables, const OptTensor& spectrum,
+                       Tensor& reverb_workspace, Tensor& workspace, double sample_rate) {
+  const NwsGenericModel* m = struct_of<NwsGenericModel>(gdesc, "gdesc");
+  int64_t B, C, T;
+  check_inputs(f0, control, B, C, T);
+  check_dev(phase_u, "phase_u");
+  check_dev(rand_phase, "rand_phase");
+  check_dev(noise, "noise");
+  check_same_device(f0, "f0", phase_u, "phase_u");
+  check_same_device(f0, "f0", noise, "noise");
+  check_same_device(f0, "f0", rand_phase, "osc.rand_phase");
+  check_dev(workspace, "workspace", at::kByte);
+  check_dev(reverb_workspace, "reverb_workspace", at::kByte);
+  check_same_device(f0, "f0", workspace, "workspace");
+  TORCH_CHECK(m->hop > 0 && m->n_harmonics > 0, "gdesc: not a NwsGenericModel");
+  TORCH_CHECK(phase_u.numel() == m->n_harmonics && rand_phase.numel() == m->n_harmonics, "phase_u / rand_phase: expected ",
+              m->n_harmonics, " elements");
+  const int64_t N = T * m->hop;
+  TORCH_CHECK(noise.numel() == N - 1, "noise: expected ", N - 1, " elements, got ", noise.sizes());
+  TORCH_CHECK((size_t)workspace.numel() >= nws_forward_generic_workspace_bytes(m, (int)B, (int)T), "workspace too small");
+  NwsReverbPlan plan{};
+  const bool fft = plan_t.has_value();
+  if (fft) {
+    TORCH_CHECK(tables.has_value() && spectrum.has_value(), "forward_generic: plan without tables / spectrum");
+    plan = plan_of(*plan_t);
+    check_dev(*tables, "reverb_tables");
+    check_dev(*spectrum, "reverb_spectrum");
+    check_reverb_buffers(plan, *tables, *spectrum);
+    TORCH_CHECK(N <= plan.L, "forward_generic: ", N, " samples do not fit the plan's circular length ", plan.L);
+    TORCH_CHECK((size_t)reverb_workspace.numel() >= nws_reverb_workspace_bytes(&plan, (int)B), "reverb workspace too small");
+  }
+  Launch L(f0);
+  Tensor out = at::empty({B, N}, f0.options());
+  nws_check(nws_forward_generic(m, f0.data_ptr<float>(), control.data_ptr<float>(), (int)B, (int)C, (int)T, (float)sample_rate,
+                                phase_u.data_ptr<float>(), rand_phase.data_ptr<float>(), noise.data_ptr<float>(),
+                                fft ? &plan : nullptr, fft ? tables->data_ptr() : nullptr, fft ? spectrum->data_ptr() : nullptr,
+                                fft ? reverb_workspace.data_ptr() : nullptr, fft ? (size_t)reverb_workspace.numel() : 0,
+                                out.data_ptr<float>(), workspace.data_ptr(), (size_t)workspace.numel(), L.stream),
+            "nws_forward_generic");
+  return out;
+}
+
+// nn.GRU(C_in -> H, batch_first) over control[:, 0:C_in] of (B, C_total, T): -> (out (B, T, H), hT (B, H))
+std::tuple<Tensor, Tensor> g_gru(const Tensor& w_ih, const Tensor& w_hh, const Tensor& b_ih, const Tensor& b_hh, const Tensor& control,
+                                 const OptTensor& h0) {
+  check_dev(control, "control");
+  for (const Tensor* t : {&w_ih, &w_hh, &b_ih, &b_hh}) {
+    check_dev(*t, "gru parameter");
+    check_same_device(control, "control", *t, "the GRU's parameters");
+  }
+  TORCH_CHECK(control.dim() == 3 && w_hh.dim() == 2 && w_ih.dim() == 2, "g_gru: control (B, C, T), weight_ih (3H, C_in), weight_hh (3H, H)");
+  const int64_t B = control.size(0), Ct = control.size(1), T = control.size(2), H = w_hh.size(1), Cin = w_ih.size(1);
+  TORCH_CHECK(w_hh.size(0) == 3 * H && w_ih.size(0) == 3 * H && b_ih.numel() == 3 * H && b_hh.numel() == 3 * H, "g_gru: inconsistent GRU parameter shapes");
+  TORCH_CHECK(Ct >= Cin && T >= 1, "g_gru: control has ", Ct, " channels, the GRU takes ", Cin);
+  if (h0.has_value()) {
+    check_dev(*h0, "h0");
+    TORCH_CHECK(h0->numel() == B * H, "h0: expected (", B, ", ", H, ")");
+  }
+  Launch L(control);
+  Tensor out = at::empty({B, T, H}, control.options());
+  Tensor hT = at::empty({B, H}, control.options());
+  const size_t nb = nws_g_gru_workspace_bytes((int)H);
+  Tensor ws = at::empty({(int64_t)nb}, control.options().dtype(at::kByte));
+  nws_check(nws_g_gru(w_ih.data_ptr<float>(), w_hh.data_ptr<float>(), b_ih.data_ptr<float>(), b_hh.data_ptr<float>(),
+                      control.data_ptr<float>(), (int)B, (int)Ct, (int)Cin, (int)H, (int)T, fptr(h0), out.data_ptr<float>(),
+                      hT.data_ptr<float>(), ws.data_ptr(), nb, L.stream), "nws_g_gru");
+  return {out, hT};
+}
+
+// HarmonicOscillator.forward for any n_harmonics / length: f0_up (B, N) -> (B, K, N)
+Tensor g_oscillator(const Tensor& f0_up, const Tensor& phase_u, const Tensor& rand_phase, double sample_rate) {
+  check_dev(f0_up, "f0");
+  check_dev(phase_u, "phase_u");
+  check_dev(rand_phase, "rand_phase");
+  check_same_device(f0_up, "f0", phase_u, "phase_u");
+  check_same_device(f0_up, "f0", rand_phase, "rand_phase");
+  TORCH_CHECK(f0_up.dim() == 2 && f0_up.size(1) > 0, "HarmonicOscillator: expected f0 of shape (B, N), got ", f0_up.sizes());
+  const int64_t B = f0_up.size(0), N = f0_up.size(1), K = phase_u.numel();
+  TORCH_CHECK(rand_phase.numel() == K && K > 0, "phase_u / rand_phase disagree");
+  Launch L(f0_up);
+  Tensor phase = at::empty_like(f0_up);
+  nws_check(nws_g_phase(nullptr, f0_up.data_ptr<float>(), (int)B, (int)N, 1, (float)sample_rate, nullptr, phase.data_ptr<float>(),
+                        L.stream), "nws_g_phase");
+  Tensor out = at::empty({B, K, N}, f0_up.options());
+  nws_check(nws_g_oscillator(f0_up.data_ptr<float>(), phase.data_ptr<float>(), phase_u.data_ptr<float>(), rand_phase.data_ptr<float>(),
+                             (int)K, (int)B, (int)N, (float)sample_rate, out.data_ptr<float>(), L.stream), "nws_g_oscillator");
+  return out;
+}
+
+Tensor g_conv1x1(const Tensor& x, const Tensor& w, const OptTensor& bias) {
+  check_dev(x, "x");
+  check_dev(w, "weight");
+  check_same_device(x, "x", w, "weight");
+  TORCH_CHECK(x.dim() == 3 && w.dim() >= 2 && w.size(1) == x.size(1) && w.numel() == w.size(0) * w.size(1),
+              "conv1x1: x (B, Cin, N), weight (Cout, Cin[, 1]); got ", x.sizes(), " / ", w.sizes());
+  if (bias.has_value()) {
+    check_dev(*bias, "bias");
+    TORCH_CHECK(bias->numel() == w.size(0), "conv1x1: bias ", bias->sizes());
+  }
+  Launch L(x);
+  Tensor y = at::empty({x.size(0), w.size(0), x.size(2)}, x.options());
+  nws_check(nws_g_conv1x1(x.data_ptr<float>(), w.data_ptr<float>(), fptr(bias), (int)x.size(0), (int)x.size(1), (int)w.size(0),
+                          (int)x.size(2), y.data_ptr<float>(), L.stream), "nws_g_conv1x1");
+  return y;
+}
+
+Tensor g_shaper_apply(const Tensor& sdesc, const Tensor& x) {
+  const NwsShaperDesc* d = struct_of<NwsShaperDesc>(sdesc, "sdesc");
+  check_dev(x, "x");
+  TORCH_CHECK(x.dim() == 3 && x.size(1) == d->n_shapers, "expected (B, ", d->n_shapers, ", N), got ", x.sizes());
+  Launch L(x);
+  Tensor y = at::empty_like(x);
+  nws_check(nws_g_shaper_apply(d, x.data_ptr<float>(), x.size(0) * x.size(1), x.size(2), y.data_ptr<float>(), L.stream),
+            "nws_g_shaper_apply");
+  return y;
+}
+
+Tensor g_shaper_table(const Tensor& sdesc, const Tensor& like, int64_t size, double tmin, double tmax) {
+  const NwsShaperDesc* d = struct_of<NwsShaperDesc>(sdesc, "sdesc");
+  check_dev(like, "shaping_fn.input_scale");
+  TORCH_CHECK(size >= 2 && tmax > tmin, "FastNEWT: need table_size >= 2 and table_max > table_min");
+  Launch L(like);
+  Tensor table = at::empty({(int64_t)d->n_shapers, size}, like.options());
+  nws_check(nws_g_shaper_table(d, (int)size, (float)tmin, (float)tmax, table.data_ptr<float>(), L.stream), "nws_g_shaper_table");
+  return table;
+}
+
+// NEWT.forward / FastNEWT.forward for any sizes: exciter (B, S, N), film (B, 4S, T) -> (B, O, N)
+Tensor g_newt_apply(const Tensor& sdesc, const Tensor& exciter, const Tensor& film, const Tensor& mix_w, const Tensor& mix_b) {
+  const NwsShaperDesc* d = struct_of<NwsShaperDesc>(sdesc, "sdesc");
+  check_dev(exciter, "exciter");
+  check_dev(film, "film_params");
+  check_dev(mix_w, "mixer weight");
+  check_dev(mix_b, "mixer bias");
+  check_same_device(exciter, "exciter", film, "control embedding");
+  check_same_device(exciter, "exciter", mix_w, "newt.mixer");
+  const int64_t S = d->n_shapers;
+  TORCH_CHECK(exciter.dim() == 3 && exciter.size(1) == S, "NEWT: expected an exciter of shape (B, ", S, ", N), got ", exciter.sizes());
+  TORCH_CHECK(film.dim() == 3 && film.size(1) == 4 * S && film.size(0) == exciter.size(0), "NEWT: expected FiLM parameters of shape (B, ",
+              4 * S, ", T), got ", film.sizes());
+  const int64_t B = exciter.size(0), N = exciter.size(2), T = film.size(2);
+  TORCH_CHECK(T > 0 && N % T == 0, "NEWT: ", N, " samples are not a whole multiple of ", T, " control frames");
+  TORCH_CHECK(mix_w.numel() % S == 0 && mix_b.numel() == mix_w.numel() / S, "NEWT: mixer weight ", mix_w.sizes(), " / bias ", mix_b.sizes());
+  const int64_t O = mix_w.numel() / S;
+  Launch L(exciter);
+  Tensor shaped = at::empty_like(exciter);
+  nws_check(nws_g_film_shaper(d, exciter.data_ptr<float>(), film.data_ptr<float>(), (int)B, (int)T, (int)(N / T),
+                              shaped.data_ptr<float>(), L.stream), "nws_g_film_shaper");
+  Tensor out = at::empty({B, O, N}, exciter.options());
+  nws_check(nws_g_conv1x1(shaped.data_ptr<float>(), mix_w.data_ptr<float>(), mix_b.data_ptr<float>(), (int)B, (int)S, (int)O, (int)N,
+                          out.data_ptr<float>(), L.stream), "nws_g_conv1x1");
+  return out;
+}
+
+// FIRNoiseSynth.forward for any even ir_length >= hop: H (B, L/2+1, T) -> (B, hop * T)
+Tensor g_fir_noise(const Tensor& H, const Tensor& window, const Tensor& noise, int64_t hop) {
+  check_dev(H, "H");
+  check_dev(window, "window");
+  check_dev(noise, "noise");
+  check_same_device(H, "H", window, "noise_synth.window");
+  check_same_device(H, "H", noise, "noise");
+  const int64_t Lf = window.numel();
+  TORCH_CHECK(H.dim() == 3 && H.size(1) == Lf / 2 + 1, "FIRNoiseSynth: expected H of shape (B, ", Lf / 2 + 1, ", T), got ", H.sizes());
+  const int64_t B = H.size(0), T = H.size(2);
+  TORCH_CHECK(noise.numel() == hop * T - 1, "noise: expected ", hop * T - 1, " samples, got ", noise.sizes());
+  Launch L(H);
+  Tensor fir = at::empty({B, T, Lf}, H.options());
+  nws_check(nws_g_fir_design(H.data_ptr<float>(), window.data_ptr<float>(), (int)Lf, (int)B, (int)T, fir.data_ptr<float>(), L.stream),
+            "nws_g_fir_design");
+  Tensor out = at::empty({B, hop * T}, H.options());
+  nws_check(nws_g_fir_noise(fir.data_ptr<float>(), noise.data_ptr<float>(), (int)Lf, (int)hop, (int)B, (int)T, nullptr, 0,
+                            out.data_ptr<float>(), L.stream), "nws_g_fir_noise");
+  return out;
+}
+
+Tensor g_reverb_direct(const Tensor& x, const Tensor& ir) {
+  check_dev(x, "x");
+  check_dev(ir, "reverb.ir");
+  check_same_device(x, "x", ir, "reverb.ir");
+  TORCH_CHECK(x.dim() == 2, "Reverb: expected (B, N), got ", x.sizes());
+  Launch L(x);
+  Tensor y = at::empty_like(x);
+  nws_check(nws_g_reverb_direct(x.data_ptr<float>(), ir.data_ptr<float>(), (int)ir.numel(), (int)x.size(0), (int)x.size(1),
+                                y.data_ptr<float>(), L.stream), "nws_g_reverb_direct");
+  return y;
+}
+
 int64_t abi_version() { return nws_abi_version(); }
 
 }  // namespace
@@ -558,5 +754,16 @@ TORCH_LIBRARY(newt_hip, m) {
   m.def("td_layer_norm(Tensor x, Tensor weight, Tensor bias, float eps) -> Tensor", &td_layer_norm);
   m.def("film(Tensor x, Tensor gamma, Tensor beta) -> Tensor", &film);
   m.def("sine(Tensor x) -> Tensor", &sine);
+  m.def("forward_generic(Tensor gdesc, Tensor f0, Tensor control, Tensor phase_u, Tensor rand_phase, Tensor noise, Tensor? plan, "
+        "Tensor? reverb_tables, Tensor? reverb_spectrum, Tensor(a!) reverb_workspace, Tensor(b!) workspace, float sample_rate) -> Tensor",
+        &forward_generic);
+  m.def("g_gru(Tensor w_ih, Tensor w_hh, Tensor b_ih, Tensor b_hh, Tensor control, Tensor? h0) -> (Tensor, Tensor)", &g_gru);
+  m.def("g_oscillator(Tensor f0_up, Tensor phase_u, Tensor rand_phase, float sample_rate) -> Tensor", &g_oscillator);
+  m.def("g_conv1x1(Tensor x, Tensor weight, Tensor? bias) -> Tensor", &g_conv1x1);
+  m.def("g_shaper_apply(Tensor sdesc, Tensor x) -> Tensor", &g_shaper_apply);
+  m.def("g_shaper_table(Tensor sdesc, Tensor like, int size, float tmin, float tmax) -> Tensor", &g_shaper_table);
+  m.def("g_newt_apply(Tensor sdesc, Tensor exciter, Tensor film, Tensor mix_w, Tensor mix_b) -> Tensor", &g_newt_apply);
+  m.def("g_fir_noise(Tensor H, Tensor window, Tensor noise, int hop) -> Tensor", &g_fir_noise);
+  m.def("g_reverb_direct(Tensor x, Tensor ir) -> Tensor", &g_reverb_direct);
   m.def("loudness(Tensor audio, Tensor dft, int n_fft, int hop, float amin, float top_db, bool normalise) -> Tensor", &loudness);
 }

@@ -138,8 +138,52 @@ class Engine:
     def __reduce__(self):
         return (Engine, (self._model_ref,))
 
+    # ---- which kernels: the fused ones are compiled for gin/models/newt.gin, everything else takes the runtime-size path ----
+    def specialised(self) -> bool:
+        """True when the module tree has the architecture the fused kernels are compiled for (101 harmonics, 64 shapers of
+        width 8 / depth 4, GRU(2 -> 128), 128-d embedding, depth-4 frame MLPs, 256-tap FIR, hop 128, one output channel);
+        any other gin configuration runs through generic.GenericEngine (csrc/generic.hip)."""
+        hit = getattr(self, "_spec", None)
+        if hit is not None and hit[0] == _EPOCH[0]:
+            return hit[1]
+        m = self._model_ref
+
+        def mlp_ok(mlp, out_rows):
+            convs = [c for c in mlp.net if isinstance(c, torch.nn.Conv1d)]
+            return (len(mlp.net) == 10 and len(convs) == 4 and all(c.in_channels == _lib.HIDDEN for c in convs)
+                    and all(c.out_channels == _lib.HIDDEN for c in convs[:3]) and convs[3].out_channels == out_rows)
+
+        try:
+            g = m.embedding.gru
+            sh = m.newt._modules.get("shaping_fn")
+            lut = getattr(m.newt, "lookup_table", None)
+            ok = (m.control_hop == _lib.HOP and m.osc.n_harmonics == _lib.N_HARMONICS
+                  and m.harmonic_mixer.out_channels == _lib.N_SHAPERS and m.harmonic_mixer.in_channels == _lib.N_HARMONICS
+                  and g.input_size == 2 and g.hidden_size == _lib.HIDDEN and g.num_layers == 1 and not g.bidirectional
+                  and m.embedding.proj.out_channels == _lib.HIDDEN and m.embedding.proj.in_channels == _lib.HIDDEN
+                  and mlp_ok(m.newt.mlp, _lib.FILM_CH) and mlp_ok(m.h_generator, _lib.N_BANDS)
+                  and m.noise_synth.ir_length == _lib.FIR_LEN and m.noise_synth.hop_length == _lib.HOP
+                  and m.newt.n_waveshapers == _lib.N_SHAPERS and m.newt.mixer[0].out_channels == 1
+                  and (lut is not None and lut.shape[0] == _lib.N_SHAPERS
+                       or lut is None and sh is not None and sh.channels == _lib.N_SHAPERS and sh.width == 8 and sh.depth == 4))
+        except AttributeError:
+            ok = False
+        self._spec = (_EPOCH[0], bool(ok))
+        return bool(ok)
+
+    @property
+    def generic(self):
+        g = self.__dict__.get("_generic")
+        if g is None:
+            from .generic import GenericEngine
+
+            g = self._generic = GenericEngine(self._model_ref)
+        return g
+
     # ---- cache control -----------------------------------------------------------------------
     def invalidate(self):
+        if self.__dict__.get("_generic") is not None:
+            self._generic.invalidate()
         self._w = None
         self._fp = None
         self._tensors = None
@@ -568,6 +612,8 @@ class Engine:
 
     # ---- the whole forward: ONE op / ONE C-ABI call --------------------------------------------------------
     def forward(self, f0, control, phase_u, noise):
+        if not self.specialised():
+            return self.generic.forward(f0, control, phase_u, noise)
         w, _, dev, wdesc = self._wd()
         same_device(dev, f0=f0, control=control, phase_u=phase_u, noise=noise)
         B, Cc, T = control.shape

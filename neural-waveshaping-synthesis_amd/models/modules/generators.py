@@ -48,7 +48,7 @@ class FIRNoiseSynth(nn.Module):
         """H_re (B, ir_length/2 + 1, T) real filter magnitudes -> (B, 1, hop * T) filtered noise (generators.py:21-35).
         `noise` injects the excitation draw (hop * T - 1 samples) for parity tests."""
         if self.ir_length != sa._lib.FIR_LEN or self.hop_length != sa._lib.HOP:
-            raise RuntimeError("kernels are specialised for ir_length 256, hop_length 128 (gin/models/newt.gin)")
+            return self._forward_generic(H_re, noise)
         H = sa.contiguous(H_re, "H_re")
         if H.dim() != 3 or H.shape[1] != sa._lib.N_BANDS:
             raise RuntimeError(f"FIRNoiseSynth: expected (B, {sa._lib.N_BANDS}, T), got {tuple(H.shape)}")
@@ -74,6 +74,33 @@ class FIRNoiseSynth(nn.Module):
         return out.unsqueeze(1)
 
 
+    def _forward_generic(self, H_re, noise):
+        """any even ir_length >= hop_length: runtime-size stage kernels (csrc/generic.hip: g_fir_design_kernel, g_fir_noise_kernel)"""
+        L, hop = int(self.ir_length), int(self.hop_length)
+        H = sa.contiguous(H_re, "H_re")
+        if H.dim() != 3 or H.shape[1] != L // 2 + 1:
+            raise RuntimeError(f"FIRNoiseSynth: expected (B, {L // 2 + 1}, T), got {tuple(H.shape)}")
+        if L % 2 or L < hop:
+            raise RuntimeError(f"FIRNoiseSynth: ir_length {L} must be even and >= hop_length {hop} (torch.istft, generators.py:34)")
+        B, _, T = H.shape
+        win = sa._req(self.window.detach(), "noise_synth.window", L)
+        if noise is None:
+            noise = torch.rand(hop * T - 1, device=H.device)                      # the reference's draw (generators.py:30)
+        noise = sa._req(noise, "noise", hop * T - 1)
+
+        def c_call(lib):
+            with torch.cuda.device(H.device):
+                fir = torch.empty((B, T, L), dtype=torch.float32, device=H.device)
+                out = torch.empty((B, T * hop), dtype=torch.float32, device=H.device)
+                st = sa.stream_ptr(H.device)
+                sa.checked(lib.nws_g_fir_design(H.data_ptr(), win.data_ptr(), L, B, T, fir.data_ptr(), st), "nws_g_fir_design")
+                sa.checked(lib.nws_g_fir_noise(fir.data_ptr(), noise.data_ptr(), L, hop, B, T, None, 0, out.data_ptr(), st),
+                           "nws_g_fir_noise")
+            return out
+
+        return sa.call("g_fir_noise", "nws_g_fir_noise", (H, win, noise, hop), c_call).unsqueeze(1)
+
+
 @gin.configurable
 class HarmonicOscillator(nn.Module):
     def __init__(self, n_harmonics, sample_rate):
@@ -88,15 +115,28 @@ class HarmonicOscillator(nn.Module):
         """(B, N) upsampled F0 in Hz -> (B, n_harmonics, N): sin(k * tau * cumsum(f0) / sr + shift_k) * [k f0 < sr / 2]
         (generators.py:58-66; the cumulative sum is accumulated in float64 like torch's CPU cumsum).  N must be a multiple
         of 128.  `phase_u` injects the U[0,1) phase draw for parity tests."""
-        if self.n_harmonics != sa._lib.N_HARMONICS:
-            raise RuntimeError("kernels are specialised for 101 harmonics (gin/models/newt.gin)")
         f0 = sa.contiguous(f0, "f0")
-        if f0.dim() != 2 or f0.shape[1] % sa._lib.HOP:
-            raise RuntimeError(f"HarmonicOscillator: expected (B, 128*T), got {tuple(f0.shape)}")
-        rp = sa._req(self.rand_phase.detach().reshape(-1), "osc.rand_phase", sa._lib.N_HARMONICS)
+        if f0.dim() != 2 or f0.shape[1] < 1:
+            raise RuntimeError(f"HarmonicOscillator: expected (B, N), got {tuple(f0.shape)}")
+        K = int(self.n_harmonics)
+        rp = sa._req(self.rand_phase.detach().reshape(-1), "osc.rand_phase", K)
         u = torch.rand_like(self.rand_phase) if phase_u is None else phase_u            # the reference's draw (generators.py:55)
-        u = sa._req(u.reshape(-1), "phase_u", sa._lib.N_HARMONICS)
+        u = sa._req(u.reshape(-1), "phase_u", K)
         B, N = f0.shape
+        if K != sa._lib.N_HARMONICS or N % sa._lib.HOP:
+            # any harmonic count / length: runtime-size stage kernels (csrc/generic.hip: g_phase_kernel, g_oscillator_kernel)
+            def g_call(lib):
+                with torch.cuda.device(f0.device):
+                    phase = torch.empty_like(f0)
+                    out = torch.empty((B, K, N), dtype=torch.float32, device=f0.device)
+                    st = sa.stream_ptr(f0.device)
+                    sa.checked(lib.nws_g_phase(None, f0.data_ptr(), B, N, 1, float(self.sample_rate), None, phase.data_ptr(), st),
+                               "nws_g_phase")
+                    sa.checked(lib.nws_g_oscillator(f0.data_ptr(), phase.data_ptr(), u.data_ptr(), rp.data_ptr(), K, B, N,
+                                                    float(self.sample_rate), out.data_ptr(), st), "nws_g_oscillator")
+                return out
+
+            return sa.call("g_oscillator", "nws_g_oscillator", (f0, u, rp, float(self.sample_rate)), g_call)
 
         def c_call(L):
             with torch.cuda.device(f0.device):

@@ -44,6 +44,39 @@ def _shaper_apply(x, wdesc_tuple):
     return sa.call("shaper_apply", "nws_shaper_apply", (wdesc, x), c_call)
 
 
+class _GShaperCache:
+    """NwsShaperDesc (+ its byte tensor for the op layer) of a TrainableNonlinearity or a FastNEWT table, cached until a
+    tensor changes"""
+
+    def __init__(self):
+        self._key = None
+        self._val = None
+
+    def get(self, sh=None, *, lut=None, lut_min=0.0, lut_max=0.0):
+        from ...generic import desc_bytes, shaper_desc
+
+        ts = [lut] if lut is not None else list(sh.parameters())
+        key = tuple((t.data_ptr(), t._version) for t in ts) + (float(lut_min), float(lut_max))
+        if key != self._key:
+            sa.no_autograd(params=ts)
+            keep = []
+            d = shaper_desc(sh, lut=lut, lut_min=lut_min, lut_max=lut_max, keep=keep)
+            self._val = (d, desc_bytes(d), keep)
+            self._key = key
+        return self._val[0], self._val[1]
+
+
+def _g_shaper_apply(x, d, sdesc):
+    def c_call(lib):
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            sa.checked(lib.nws_g_shaper_apply(C.byref(d), x.data_ptr(), x.shape[0] * x.shape[1], x.shape[2], y.data_ptr(),
+                                              sa.stream_ptr(x.device)), "nws_g_shaper_apply")
+        return y
+
+    return sa.call("g_shaper_apply", "nws_g_shaper_apply", (sdesc, x), c_call)
+
+
 @gin.configurable
 class TrainableNonlinearity(nn.Module):
     """64 independent scalar sin-MLPs stored as grouped 1x1 convs (reference shaping.py:15-37)."""
@@ -60,10 +93,12 @@ class TrainableNonlinearity(nn.Module):
         self.net = nn.Sequential(*stack)
         self.channels, self.width, self.depth = channels, width, depth
         self._desc = sa.Desc()
+        self._gdesc = _GShaperCache()
 
     def __getstate__(self):
         d = self.__dict__.copy()
         d["_desc"] = sa.Desc()
+        d["_gdesc"] = _GShaperCache()
         return d
 
     def forward(self, x):
@@ -73,6 +108,8 @@ class TrainableNonlinearity(nn.Module):
             raise RuntimeError(f"expected (B, {self.channels}, N), got {tuple(x.shape)}")
         if not all(isinstance(m, Sine) for m in list(self.net)[1::2]):
             raise RuntimeError("kernels implement the sine activations NEWT configures (nonlinearity=Sine)")
+        if (self.channels, self.width, self.depth) != (sa._lib.N_SHAPERS, sa._lib.SHAPER_WIDTH, 4):
+            return _g_shaper_apply(x, *self._gdesc.get(self))          # any channels / width / depth (csrc/generic.hip)
         return _shaper_apply(x, self._desc.get(sa.shaper_fields(self)))
 
 
@@ -88,27 +125,60 @@ class NEWT(nn.Module):
         self.normalising_coeff = FiLM()
         self.mixer = nn.Sequential(nn.Conv1d(n_waveshapers, out_channels, 1))
         self._newt_desc = sa.Desc()
+        self._g_newt = _GShaperCache()
 
     def __getstate__(self):
         d = self.__dict__.copy()
         d["_newt_desc"] = sa.Desc()
+        d["_g_newt"] = _GShaperCache()
         return d
 
     def _apply_fields(self):
         return sa.shaper_fields(self._modules["shaping_fn"]), {}
 
+    def _specialised(self, hop):
+        sh = self._modules["shaping_fn"]
+        return (self.n_waveshapers == sa._lib.N_SHAPERS and self.mixer[0].out_channels == 1 and hop == sa._lib.HOP
+                and (sh.channels, sh.width, sh.depth) == (sa._lib.N_SHAPERS, sa._lib.SHAPER_WIDTH, 4))
+
+    def _g_shaper(self):
+        return self._g_newt.get(self._modules["shaping_fn"])
+
+    def _forward_generic(self, exciter, film):
+        """any n_waveshapers / shaping_fn_size / depth / out_channels / hop: FiLM -> shaper -> FiLM (g_film_shaper_kernel) then
+        the Conv1d(S -> out_channels) mixer (g_conv1x1_kernel), csrc/generic.hip"""
+        d, sdesc = self._g_shaper()
+        B, S, N = exciter.shape
+        T = film.shape[2]
+        mw = sa._req(self.mixer[0].weight.detach(), "newt.mixer.0.weight")
+        mb = sa._req(self.mixer[0].bias.detach(), "newt.mixer.0.bias")
+        O = mw.shape[0]
+
+        def c_call(lib):
+            with torch.cuda.device(exciter.device):
+                shaped = torch.empty_like(exciter)
+                out = torch.empty((B, O, N), dtype=torch.float32, device=exciter.device)
+                st = sa.stream_ptr(exciter.device)
+                sa.checked(lib.nws_g_film_shaper(C.byref(d), exciter.data_ptr(), film.data_ptr(), B, T, N // T, shaped.data_ptr(), st),
+                           "nws_g_film_shaper")
+                sa.checked(lib.nws_g_conv1x1(shaped.data_ptr(), mw.data_ptr(), mb.data_ptr(), B, S, O, N, out.data_ptr(), st),
+                           "nws_g_conv1x1")
+            return out
+
+        return sa.call("g_newt_apply", "nws_g_film_shaper", (sdesc, exciter, film, mw, mb), c_call)
+
     def forward(self, exciter, control_embedding):
         """(B, 64, N) exciter, (B, 128, T) control embedding -> (B, 1, N) (reference shaping.py:67-79): the FiLM-parameter
         MLP (one launch) then FiLM -> shaper -> FiLM -> Conv1d(64 -> 1) on the materialised exciter (one launch)."""
         exciter = sa.contiguous(exciter, "exciter")
-        if self.n_waveshapers != sa._lib.N_SHAPERS or self.mixer[0].out_channels != 1:
-            raise RuntimeError("kernels are specialised for 64 waveshapers, one output channel (gin/models/newt.gin)")
         if exciter.dim() != 3 or exciter.shape[1] != self.n_waveshapers:
             raise RuntimeError(f"NEWT: expected an exciter of shape (B, {self.n_waveshapers}, N), got {tuple(exciter.shape)}")
         film = self.mlp(control_embedding)                       # (B, 256, T), channel-major like the reference's Conv1d stack
         T = film.shape[2]
-        if exciter.shape[0] != film.shape[0] or exciter.shape[2] != T * sa._lib.HOP:
-            raise RuntimeError(f"NEWT: exciter {tuple(exciter.shape)} does not match {T} control frames x {sa._lib.HOP}")
+        if exciter.shape[0] != film.shape[0] or exciter.shape[2] % T:
+            raise RuntimeError(f"NEWT: exciter {tuple(exciter.shape)} does not match {T} control frames")
+        if not self._specialised(exciter.shape[2] // T):
+            return self._forward_generic(exciter, film)
         tensors, scalars = self._apply_fields()
         tensors = dict(tensors, newt_out_w=self.mixer[0].weight, newt_out_b=self.mixer[0].bias)
         w, _, wdesc = self._newt_desc.get(tensors, scalars)
@@ -145,11 +215,19 @@ class FastNEWT(NEWT):
         self._modules["shaping_fn"] = newt._modules["shaping_fn"]
         self.lookup_table = self._init_lookup_table(newt, table_size, self.n_waveshapers, table_min, table_max)
         self._lut_desc = sa.Desc()
+        self._g_lut = _GShaperCache()
 
     def __getstate__(self):
         d = super().__getstate__()
         d["_lut_desc"] = sa.Desc()
+        d["_g_lut"] = _GShaperCache()
         return d
+
+    def _specialised(self, hop):
+        return self.n_waveshapers == sa._lib.N_SHAPERS and self.mixer[0].out_channels == 1 and hop == sa._lib.HOP
+
+    def _g_shaper(self):
+        return self._g_lut.get(lut=self.lookup_table, lut_min=self.table_min, lut_max=self.table_max)
 
     @staticmethod
     def _init_lookup_table(newt, table_size, n_waveshapers, table_min, table_max):
@@ -163,8 +241,28 @@ class FastNEWT(NEWT):
             dev = torch.device("cuda", torch.cuda.current_device())
         else:
             raise sa._lib.NwsError("FastNEWT needs an AMD GPU to evaluate its lookup table (no CPU fallback)")
-        if n_waveshapers != 64:
-            raise RuntimeError("kernels are specialised for 64 shapers, width 8, depth 4")
+        if (sh.channels, sh.width, sh.depth) != (sa._lib.N_SHAPERS, sa._lib.SHAPER_WIDTH, 4):
+            # any channels / width / depth: runtime-size table kernel (csrc/generic.hip: g_shaper_table_kernel)
+            import copy
+
+            from ...generic import desc_bytes, shaper_desc
+
+            sh_dev = sh if home == dev else copy.deepcopy(sh).to(dev)
+            keep = []
+            d = shaper_desc(sh_dev, keep=keep)
+
+            def g_call(lib):
+                with torch.cuda.device(dev):
+                    table = torch.empty((n_waveshapers, table_size), dtype=torch.float32, device=dev)
+                    sa.checked(lib.nws_g_shaper_table(C.byref(d), int(table_size), float(table_min), float(table_max), table.data_ptr(),
+                                                      sa.stream_ptr(dev)), "nws_g_shaper_table")
+                return table
+
+            with torch.no_grad():
+                table = sa.call("g_shaper_table", "nws_g_shaper_table",
+                                (desc_bytes(d), keep[0], int(table_size), float(table_min), float(table_max)), g_call)
+            torch.cuda.current_stream(dev).synchronize()
+            return nn.Parameter(table.to(home))
         fields = {k: v.detach().to(dev).contiguous() for k, v in sa.shaper_fields(sh).items()}
         w, keep, wdesc = sa.Desc().get(fields)
         like = keep[0]
@@ -192,8 +290,10 @@ class FastNEWT(NEWT):
         x = sa.contiguous(x, "x")
         if x.dim() != 3 or x.shape[1] != self.n_waveshapers:
             raise RuntimeError(f"expected (B, {self.n_waveshapers}, N), got {tuple(x.shape)}")
-        if self.lookup_table.numel() != 64 * self.table_size:
+        if self.lookup_table.numel() != self.n_waveshapers * self.table_size:
             raise RuntimeError("lookup_table does not match table_size")
+        if self.n_waveshapers != sa._lib.N_SHAPERS:
+            return _g_shaper_apply(x, *self._g_shaper())
         return _shaper_apply(x, self._lut_desc.get(*self._lut_fields()))
 
 
@@ -223,6 +323,19 @@ class Reverb(nn.Module):
         if ir.device != x.device:
             raise RuntimeError(f"x is on {x.device} but reverb.ir is on {ir.device}")
         B, N = x.shape
+        from ..._lib import NwsReverbPlan
+
+        probe = NwsReverbPlan()
+        if sa._lib.lib().nws_reverb_plan(int(N), int(ir.numel()) + 1, C.byref(probe)) != 0:
+            # circular length without a (N1 <= 8192) x 2^k factorisation: time-domain form (csrc/generic.hip)
+            def d_call(lib):
+                y = torch.empty_like(x)
+                with torch.cuda.device(x.device):
+                    sa.checked(lib.nws_g_reverb_direct(x.data_ptr(), ir.data_ptr(), ir.numel(), B, N, y.data_ptr(),
+                                                       sa.stream_ptr(x.device)), "nws_g_reverb_direct")
+                return y
+
+            return sa.call("g_reverb_direct", "nws_g_reverb_direct", (x, ir.reshape(-1)), d_call)
         plan, tables, plan_t = reverb_plan_and_tables(x.device, N, ir.numel() + 1)
         L = sa._lib.lib()
         key = (plan.L, ir.data_ptr(), ir._version)

@@ -53,10 +53,31 @@ class ControlModule(nn.Module):
 
         x = sa.contiguous(x, "x")
         g = self.gru
-        if g.input_size != 2 or g.hidden_size != sa._lib.HIDDEN or g.num_layers != 1 or g.bidirectional:
-            raise RuntimeError("kernels are specialised for GRU(2 -> 128), one layer (gin/models/newt.gin)")
+        if g.num_layers != 1 or g.bidirectional or not g.batch_first:
+            raise RuntimeError("the HIP path implements nn.GRU(control_size, hidden_size, batch_first=True), one layer")
         if x.dim() != 3 or x.shape[1] != g.input_size:
             raise RuntimeError(f"ControlModule: expected (B, {g.input_size}, T), got {tuple(x.shape)}")
+        if g.input_size != 2 or g.hidden_size != sa._lib.HIDDEN:
+            # any control_size / hidden_size: runtime-size recurrence (csrc/generic.hip: g_gru_kernel)
+            ps = [sa._req(p.detach(), "gru parameter") for p in (g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)]
+            sa.no_autograd(params=[g.weight_ih_l0])
+            B, Cin, T = x.shape
+            H = g.hidden_size
+
+            def g_call(lib):
+                with torch.cuda.device(x.device):
+                    out = torch.empty((B, T, H), dtype=torch.float32, device=x.device)
+                    nb = lib.nws_g_gru_workspace_bytes(H)
+                    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+                    sa.checked(lib.nws_g_gru(ps[0].data_ptr(), ps[1].data_ptr(), ps[2].data_ptr(), ps[3].data_ptr(), x.data_ptr(), B,
+                                             Cin, Cin, H, T, None, out.data_ptr(), None, ws.data_ptr(), nb, sa.stream_ptr(x.device)),
+                               "nws_g_gru")
+                return out
+
+            o = sa.ops()
+            sa.no_autograd(inputs=(x,))
+            h = o.g_gru(ps[0], ps[1], ps[2], ps[3], x, None)[0] if o is not None else g_call(sa._lib.lib())
+            return td_mlp_forward(h.transpose(1, 2).contiguous(), self.proj)
         w, _, wdesc = self._desc.get({"gru_w_ih": g.weight_ih_l0, "gru_w_hh": g.weight_hh_l0, "gru_b_ih": g.bias_ih_l0,
                                       "gru_b_hh": g.bias_hh_l0})
 
@@ -96,8 +117,6 @@ class NeuralWaveshaping(nn.Module):
             self.h_generator = TimeDistributedMLP()
             self.noise_synth = FIRNoiseSynth()
         self.reverb = Reverb()
-        if control_hop != _lib.HOP:
-            raise RuntimeError("kernels are specialised for control_hop = 128 (gin/models/newt.gin)")
         object.__setattr__(self, "_engine", Engine(self))
 
     # ---- cache hygiene: any re-homing / re-loading of parameters drops the pointer cache ----------
@@ -135,8 +154,25 @@ class NeuralWaveshaping(nn.Module):
     def render_exciter(self, f0):
         """(B, 1, N) upsampled F0 in Hz -> (B, n_waveshapers, N) exciter (reference :64-67)."""
         f0 = _req(f0 if f0.is_contiguous() else f0.contiguous(), "f0")
-        if f0.dim() != 3 or f0.shape[1] != 1 or f0.shape[-1] % _lib.HOP:
-            raise RuntimeError(f"expected (B, 1, 128*T), got {tuple(f0.shape)}")
+        if f0.dim() != 3 or f0.shape[1] != 1:
+            raise RuntimeError(f"expected (B, 1, N), got {tuple(f0.shape)}")
+        if not self._engine.specialised() or f0.shape[-1] % _lib.HOP:
+            # any n_harmonics / n_waveshapers / length: oscillator bank + Conv1d(k=1), runtime-size kernels (csrc/generic.hip)
+            with torch.no_grad():
+                osc = self.osc(f0[:, 0])
+                mw = _req(self.harmonic_mixer.weight.detach(), "harmonic_mixer.weight")
+                mb = _req(self.harmonic_mixer.bias.detach(), "harmonic_mixer.bias")
+                B, K, N = osc.shape
+                S = mw.shape[0]
+
+                def c_call(lib):
+                    with torch.cuda.device(osc.device):
+                        out = torch.empty((B, S, N), dtype=torch.float32, device=osc.device)
+                        sa.checked(lib.nws_g_conv1x1(osc.data_ptr(), mw.data_ptr(), mb.data_ptr(), B, K, S, N, out.data_ptr(),
+                                                     sa.stream_ptr(osc.device)), "nws_g_conv1x1")
+                    return out
+
+                return sa.call("g_conv1x1", "nws_g_conv1x1", (osc, mw, mb), c_call)
         eng = self._engine
         f0_up = f0[:, 0]
         u = torch.rand_like(self.osc.rand_phase).reshape(-1)
@@ -147,6 +183,8 @@ class NeuralWaveshaping(nn.Module):
     def get_embedding(self, control):
         """(B, C>=2, T) normalised control -> (B, 128, T) embedding (reference :69-72)."""
         control = _req(control if control.is_contiguous() else control.contiguous(), "control")
+        if not self._engine.specialised():
+            return self.embedding(control[:, 0:2].contiguous())       # (reference :70-72: f0 and loudness channels only)
         gru = self._engine.control_gru(control)
         emb, _, _, _ = self._engine.frame_mlps(gru, want_emb=True)
         return emb
@@ -168,7 +206,7 @@ class NeuralWaveshaping(nn.Module):
         sa.no_autograd(inputs=(f0, control))     # inference-only kernels: never hand back a graph-less result for grad inputs
         if phase_u is None:
             phase_u = torch.rand_like(self.osc.rand_phase)          # RNG draw #1 (generators.py:55)
-        phase_u = _req(phase_u.reshape(-1), "phase_u", _lib.N_HARMONICS)
+        phase_u = _req(phase_u.reshape(-1), "phase_u", int(self.osc.n_harmonics))
         if noise is None:
             noise = torch.rand(self.control_hop * T - 1, device=dev)  # RNG draw #2 (generators.py:30)
         noise = _req(noise, "noise", self.control_hop * T - 1)

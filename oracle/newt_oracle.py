@@ -72,8 +72,11 @@ class OracleNEWT:
         self._gru_out = x
         return F.conv1d(x.transpose(1, 2), self.w["embedding.proj.weight"], self.w["embedding.proj.bias"])
 
-    def td_mlp(self, x, prefix, depth=4):
-        """models/modules/dynamic.py:20-40: [Conv1x1 -> LayerNorm(channels) -> LeakyReLU] x (depth-1) -> Conv1x1."""
+    def td_mlp(self, x, prefix, depth=None):
+        """models/modules/dynamic.py:20-40: [Conv1x1 -> LayerNorm(channels) -> LeakyReLU] x (depth-1) -> Conv1x1.
+        depth: from the state dict's own keys (net.0, net.3, ...) unless given."""
+        if depth is None:
+            depth = sum(1 for i in range(64) if f"{prefix}.net.{3 * i}.weight" in self.w)
         for i in range(depth):
             k = f"{prefix}.net.{3 * i}"
             x = F.conv1d(x, self.w[k + ".weight"], self.w[k + ".bias"])
@@ -103,11 +106,12 @@ class OracleNEWT:
 
     # ---- shapers ----------------------------------------------------------
     def exact_shaper(self, x):
-        """models/modules/shaping.py:36-37 (TrainableNonlinearity.forward), depth 4, Sine activations."""
+        """models/modules/shaping.py:36-37 (TrainableNonlinearity.forward), Sine activations; the depth is read off the state
+        dict (net.0, net.2, ...: 4 layers for gin/models/newt.gin)."""
         w = self.w
         x = w["newt.shaping_fn.input_scale"] * x
         C = self.n_waveshapers
-        for i in (0, 2, 4, 6):
+        for i in [2 * j for j in range(32) if f"newt.shaping_fn.net.{2 * j}.weight" in w]:
             x = torch.sin(F.conv1d(x, w[f"newt.shaping_fn.net.{i}.weight"], w[f"newt.shaping_fn.net.{i}.bias"], groups=C))
         return x
 

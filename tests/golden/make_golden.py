@@ -17,7 +17,9 @@ Fixtures written:
   g6_highf0.npz       B=1,T=500, F0 1-2 kHz (cumsum ~1e8, large sine arguments)
   weights_fl.npz / weights_tpt.npz   the other two shipped instruments (checkpoints/nws/{fl,tpt}/last.ckpt), same layout
   g7_fl.npz / g7_tpt.npz             B=1,T=125 (1 s) realistic vector per instrument: y_newt, y_fast, draws
-(`python tests/golden/make_golden.py instruments` regenerates only the last four.)
+  g8_small.npz / g8_odd.npz          two NON-default gin configurations (random init, recorded weights + gin text): inputs, draws,
+                                     stage taps, y_newt, y_fast   (`... make_golden.py generic` regenerates only these)
+(`python tests/golden/make_golden.py instruments` regenerates only the fl / tpt four.)
 The RNG draws made inside forward are recorded by wrapping torch.rand / torch.rand_like.
 """
 import hashlib
@@ -225,9 +227,129 @@ def instruments():
         save(f"g7_{inst}.npz", f0=f0, control=control, phase_u=pu, noise=nz, y_newt=y_newt, y_fast=y_fast)
 
 
+GENERIC_GINS = {
+    # every size the reference's gin surface names, away from gin/models/newt.gin (incl. the code defaults shaping_fn_size 16,
+    # TrainableNonlinearity.depth 3 of shaping.py:17,46), two NEWT output channels, hop 64, 128-tap noise FIR, 1 s reverb
+    "g8_small": """
+Reverb.sr = 16000
+Reverb.length_in_seconds = 1
+noise_synth/FIRNoiseSynth.hop_length = 64
+noise_synth/FIRNoiseSynth.ir_length = 128
+noise_synth/TimeDistributedMLP.depth = 3
+noise_synth/TimeDistributedMLP.out_size = 65
+noise_synth/TimeDistributedMLP.hidden_size = 64
+noise_synth/TimeDistributedMLP.in_size = 80
+NEWT.out_channels = 2
+NEWT.control_embedding_size = 80
+NEWT.n_waveshapers = 32
+HarmonicOscillator.sample_rate = 16000
+HarmonicOscillator.n_harmonics = 60
+ControlModule.embedding_size = 80
+ControlModule.hidden_size = 96
+ControlModule.control_size = 2
+NeuralWaveshaping.sample_rate = 16000
+NeuralWaveshaping.control_hop = 64
+NeuralWaveshaping.n_waveshapers = 32
+""",
+    # odd sizes nothing divides: 7 harmonics, 5 shapers of width 3 / depth 2, GRU 33, embedding 17, hop 10, 30-tap FIR, and a
+    # reverb whose circular length (1000) has no power-of-two factor >= 32 (time-domain reverb), 8 kHz sample rate
+    "g8_odd": """
+Reverb.sr = 1000
+Reverb.length_in_seconds = 1
+noise_synth/FIRNoiseSynth.hop_length = 10
+noise_synth/FIRNoiseSynth.ir_length = 30
+noise_synth/TimeDistributedMLP.depth = 4
+noise_synth/TimeDistributedMLP.out_size = 16
+noise_synth/TimeDistributedMLP.hidden_size = 20
+noise_synth/TimeDistributedMLP.in_size = 17
+TrainableNonlinearity.depth = 2
+NEWT.shaping_fn_size = 3
+NEWT.out_channels = 1
+NEWT.control_embedding_size = 17
+NEWT.n_waveshapers = 5
+HarmonicOscillator.sample_rate = 8000
+HarmonicOscillator.n_harmonics = 7
+ControlModule.embedding_size = 17
+ControlModule.hidden_size = 33
+ControlModule.control_size = 2
+NeuralWaveshaping.sample_rate = 8000
+NeuralWaveshaping.control_hop = 10
+NeuralWaveshaping.n_waveshapers = 5
+""",
+}
+
+
+def generic_configs():
+    """Non-default gin configurations: random-init reference models built from the gin text above, their
+    state dicts, inputs, the two recorded draws, stage taps and outputs for exact NEWT and FastNEWT."""
+    import json
+
+    for name, text in GENERIC_GINS.items():
+        gin.clear_config()
+        gin.parse_config(text)
+        torch.manual_seed(2024)
+        model = NeuralWaveshaping().eval()
+        K, hop = model.osc.n_harmonics, model.control_hop
+        with torch.no_grad():
+            # random initialisation leaves reverb.ir at 1e-6 and the LUT argument partly outside [-3, 3] (where the reference
+            # extrapolates with |fract| ~ 1e3): give the IR audible energy and keep the index FiLM inside the table
+            model.reverb.ir.copy_(torch.randn_like(model.reverb.ir) * 0.05 * torch.exp(-torch.arange(model.reverb.ir.numel()) / 300.0))
+            S = model.newt.n_waveshapers
+            model.newt.mlp.net[9].weight[:2 * S] *= 0.5
+            model.newt.mlp.net[9].bias[:2 * S] *= 0.5
+            model.newt.shaping_fn.input_scale.mul_(0.3)
+        exact_newt = model.newt
+        fast_newt = FastNEWT(exact_newt, table_size=1024 if name == "g8_odd" else 4096, table_min=-4.0 if name == "g8_odd" else -3.0)
+        B, T = (2, 16) if name == "g8_small" else (3, 50)
+        torch.manual_seed(5)
+        f0 = 150.0 + 500.0 * torch.rand(B, 1, 1) + 30.0 * torch.randn(B, 1, T).cumsum(-1) / 4
+        f0[-1, 0, T // 2:] = 0.6 * model.sample_rate                       # above Nyquist: every harmonic masked
+        control = torch.randn(B, 3, T)                                     # one extra channel, ignored (:70-71)
+        taps = {}
+
+        def tap(nm, what="out"):
+            def hook(mod, inp, out):
+                taps[nm] = (inp[0] if what == "in" else out[0] if isinstance(out, tuple) else out).clone()
+            return hook
+
+        hs = [model.osc.register_forward_hook(tap("osc")), model.harmonic_mixer.register_forward_hook(tap("exciter")),
+              model.embedding.register_forward_hook(tap("embedding")), exact_newt.mlp.register_forward_hook(tap("film")),
+              model.h_generator.register_forward_hook(tap("H")), model.noise_synth.register_forward_hook(tap("noise_out")),
+              model.reverb.register_forward_hook(tap("pre_reverb", "in")), exact_newt.register_forward_hook(tap("newt_out"))]
+
+        def run_g(seed):
+            torch.manual_seed(seed)
+            with DrawRecorder() as rec:
+                y = model(f0, control)
+            assert len(rec.draws) == 2 and rec.draws[0].shape == (1, K, 1) and rec.draws[1].shape == (hop * T - 1,)
+            return y, rec.draws[0].reshape(-1).numpy(), rec.draws[1].numpy()
+
+        model.newt = exact_newt
+        y_newt, pu, nz = run_g(31)
+        et = dict(taps)
+        for h in hs:
+            h.remove()
+        model.newt = fast_newt
+        y_fast, pu2, nz2 = run_g(31)
+        assert np.array_equal(pu, pu2) and np.array_equal(nz, nz2)
+        model.newt = exact_newt
+        sd = {k: v for k, v in model.state_dict().items()}
+        hp = dict(n_waveshapers=int(model.newt.n_waveshapers), control_hop=int(hop), sample_rate=float(model.sample_rate))
+        save(f"{name}.npz", **sd, __gin__=np.array(text), __hparams__=np.array(json.dumps(hp)),
+             __table_size__=np.int64(fast_newt.table_size), __table_min__=np.float64(fast_newt.table_min),
+             __table_max__=np.float64(fast_newt.table_max), __lookup_table__=fast_newt.lookup_table.detach(),
+             __f0__=f0, __control__=control, __phase_u__=pu, __noise__=nz, __y_newt__=y_newt, __y_fast__=y_fast,
+             __osc__=et["osc"], __exciter__=et["exciter"], __embedding__=et["embedding"], __film__=et["film"], __H__=et["H"],
+             __noise_out__=et["noise_out"], __pre_reverb__=et["pre_reverb"], __newt_out__=et["newt_out"])
+    gin.clear_config()
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["instruments"]:
         instruments()
+    elif sys.argv[1:] == ["generic"]:
+        generic_configs()
     else:
         main()
         instruments()
+        generic_configs()

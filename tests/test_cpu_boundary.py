@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_strings():
     L = _lib.lib()
-    assert L.nws_abi_version() == _lib.ABI_VERSION == 2
+    assert L.nws_abi_version() == _lib.ABI_VERSION == 3
     assert b"unsupported" in L.nws_error_string(-1)
     assert b"bad argument" in L.nws_error_string(-2)
     assert L.nws_error_string(0) == b"ok"

@@ -1,0 +1,129 @@
+"""-m gpu: the runtime-size path (csrc/generic.hip) - NeuralWaveshaping.forward and the sub-modules for NON-default gin
+configurations, against vectors recorded from the real reference built from the same gin text (tests/golden/make_golden.py
+generic: g8_small.npz, g8_odd.npz).  Bar: BASELINE.json's 1e-4 RMS end to end; stage tolerances next to each check."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_npz, rms
+from gpu_util import dev, maxabs, record
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["g8_small", "g8_odd"])
+def cfg(request):
+    import nws_amd as nws
+
+    z = load_npz(request.param + ".npz")
+    nws.gin.clear_config()
+    nws.gin.parse_config(str(z["__gin__"]))
+    yield request.param, z
+    nws.gin.clear_config()
+    nws.gin.parse_config_file(nws.DEFAULT_GIN)
+
+
+def _build(name, z, fast):
+    import nws_amd as nws
+    from conftest import GOLDEN
+    import os
+
+    m = nws.NeuralWaveshaping.load_from_checkpoint(os.path.join(GOLDEN, name + ".npz")).cuda().eval()
+    if fast:
+        m.newt = nws.FastNEWT(m.newt, table_size=int(z["__table_size__"]), table_min=float(z["__table_min__"]),
+                              table_max=float(z["__table_max__"]))
+    return m
+
+
+def test_generic_forward_matches_the_reference(cfg):
+    name, z = cfg
+    hp = json.loads(str(z["__hparams__"]))
+    f0, control = dev(z["__f0__"]), dev(z["__control__"])
+    pu, nz = dev(z["__phase_u__"]), dev(z["__noise__"])
+    for fast, key in ((False, "__y_newt__"), (True, "__y_fast__")):
+        m = _build(name, z, fast)
+        assert not m._engine.specialised()                       # these sizes are NOT the compiled specialisation
+        assert m.control_hop == hp["control_hop"] and m.osc.n_harmonics == z["harmonic_mixer.weight"].shape[1]
+        with torch.no_grad():
+            y = m(f0, control, phase_u=pu, noise=nz)
+        assert y.shape == z[key].shape
+        e = rms(y.cpu().numpy() - z[key])
+        record(f"generic_{name}_{'fast' if fast else 'exact'}", rms_err=e, out_rms=rms(z[key]))
+        assert e <= 1e-4, (name, fast, e)
+        if fast:
+            assert maxabs(m.newt.lookup_table.detach().cpu().numpy(), z["__lookup_table__"]) <= 2e-6
+        # the forward draws its own RNG vectors when none are injected (shapes of the reference's two draws)
+        with torch.no_grad():
+            y2 = m(f0, control)
+        assert y2.shape == y.shape and torch.isfinite(y2).all()
+
+
+def test_generic_sub_modules_match_the_reference_taps(cfg):
+    """model.osc / render_exciter / embedding / newt.mlp / newt / h_generator / noise_synth / reverb called on their own with
+    the non-default sizes: one runtime-size stage kernel each, against the reference's forward-hook taps."""
+    name, z = cfg
+    m = _build(name, z, False)
+    hop = int(m.control_hop)
+    f0, control = dev(z["__f0__"]), dev(z["__control__"])
+    pu, nz = dev(z["__phase_u__"]), dev(z["__noise__"])
+    T = f0.shape[-1]
+    with torch.no_grad():
+        f0_up = torch.nn.functional.interpolate(f0, size=T * hop, mode="linear")      # torch plumbing, as in the reference
+        osc = m.osc(f0_up[:, 0].contiguous(), phase_u=pu)
+        assert maxabs(osc.cpu().numpy(), z["__osc__"]) <= 2e-6
+        assert np.array_equal(osc.cpu().numpy() == 0.0, z["__osc__"] == 0.0)             # anti-alias mask identical
+        # an odd length (not a multiple of anything): the stand-alone oscillator takes any N
+        osc_odd = m.osc(f0_up[:, 0, :T * hop - 3].contiguous(), phase_u=pu)
+        assert maxabs(osc_odd.cpu().numpy(), z["__osc__"][:, :, :T * hop - 3]) <= 2e-6
+        emb = m.embedding(control[:, :2].contiguous())
+        assert maxabs(emb.cpu().numpy(), z["__embedding__"]) <= 1e-5
+        assert maxabs(m.get_embedding(control).cpu().numpy(), z["__embedding__"]) <= 1e-5
+        film = m.newt.mlp(dev(z["__embedding__"]))
+        assert maxabs(film.cpu().numpy(), z["__film__"]) <= 5e-5
+        H = m.h_generator(dev(z["__embedding__"]))
+        assert maxabs(H.cpu().numpy(), z["__H__"]) <= 5e-5
+        newt_out = m.newt(dev(z["__exciter__"]), dev(z["__embedding__"]))
+        assert newt_out.shape == z["__newt_out__"].shape
+        e_newt = maxabs(newt_out.cpu().numpy(), z["__newt_out__"])
+        noise_out = m.noise_synth(dev(z["__H__"]), noise=nz)
+        e_noise = maxabs(noise_out.cpu().numpy(), z["__noise_out__"])
+        pre = dev(z["__pre_reverb__"])
+        y_rv = m.reverb(pre)
+        w = {k: v for k, v in z.items() if not k.startswith("__")}
+        from oracle.newt_oracle import OracleNEWT
+        ref_rv = OracleNEWT(w, sample_rate=m.sample_rate, control_hop=hop).reverb(torch.from_numpy(z["__pre_reverb__"])).numpy()
+        e_rv = rms(y_rv.cpu().numpy() - ref_rv)
+        record(f"generic_{name}_modules", newt_max_abs=e_newt, noise_max_abs=e_noise, reverb_rms=e_rv, newt_out_abs_max=float(np.abs(z["__newt_out__"]).max()))
+        assert e_newt <= 2e-5 * max(1.0, float(np.abs(z["__newt_out__"]).max()))
+        assert e_noise <= 1e-5
+        assert e_rv <= 1e-5 * max(1.0, rms(ref_rv))
+    # render_exciter draws its own phase offsets: compare with the oracle through the module chain instead
+    torch.manual_seed(3)
+    with torch.no_grad():
+        exc = m.render_exciter(f0_up)
+    assert exc.shape == z["__exciter__"].shape and torch.isfinite(exc).all()
+    # the shapers on their own: TrainableNonlinearity / FastNEWT.shaping_fn with these sizes
+    S = m.newt.n_waveshapers
+    x = torch.randn(2, S, 333)
+    from oracle.newt_oracle import OracleNEWT
+    kw = dict(sample_rate=m.sample_rate, control_hop=hop, table_size=int(z["__table_size__"]), table_min=float(z["__table_min__"]),
+              table_max=float(z["__table_max__"]))
+    o_exact, o_fast = OracleNEWT(w, **kw), OracleNEWT(w, fast=True, lut_python_loop=False, **kw)
+    with torch.no_grad():
+        ye = m.newt.shaping_fn(x.cuda())
+    assert maxabs(ye.cpu().numpy(), o_exact.exact_shaper(x).numpy()) <= 2e-5
+    mf = _build(name, z, True)
+    with torch.no_grad():
+        mf.newt.lookup_table.copy_(torch.from_numpy(z["__lookup_table__"]).cuda())      # the reference's own table: bit-exact lookup
+        yl = mf.newt.shaping_fn(x.cuda())
+    o_fast._table = torch.from_numpy(z["__lookup_table__"])
+    assert np.array_equal(yl.cpu().numpy(), o_fast.lut_shaper(x).numpy())
+
+
+def test_default_configuration_still_takes_the_fused_kernels():
+    from gpu_util import build_model
+
+    m = build_model(True)
+    assert m._engine.specialised()

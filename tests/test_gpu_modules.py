@@ -32,7 +32,7 @@ def test_backend_is_the_op_layer_unless_ctypes_was_asked_for():
     if os.environ.get("NWS_BACKEND") == "ctypes":
         assert o is None
     else:
-        assert o is torch.ops.newt_hip and int(o.abi_version()) == 2
+        assert o is torch.ops.newt_hip and int(o.abi_version()) == 3
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             o.sine(torch.zeros(4))
         with pytest.raises(RuntimeError, match="multiple of 128"):
@@ -126,9 +126,14 @@ def test_forward_rebuilt_from_the_sub_modules(models, g):
         osc = model.osc(f0_up[:, 0].contiguous(), phase_u=pu)
         exciter = torch.nn.functional.conv1d(osc, model.harmonic_mixer.weight, model.harmonic_mixer.bias)   # stock nn.Conv1d
         emb = model.embedding(control[:, :2])
-        newt_out = model.newt(exciter.contiguous(), emb)
-        noise_out = model.noise_synth(model.h_generator(emb), noise=nz)
-        y = model.reverb((newt_out + noise_out)[:, 0].contiguous())
+        # the stock Conv1d's output carries a graph; the HIP stage kernels are inference-only and say so instead of silently
+        # returning a graph-less tensor
+        with pytest.raises(RuntimeError, match="inference-only"):
+            model.newt(exciter.contiguous(), emb)
+        with torch.no_grad():
+            newt_out = model.newt(exciter.contiguous(), emb)
+            noise_out = model.noise_synth(model.h_generator(emb), noise=nz)
+            y = model.reverb((newt_out + noise_out)[:, 0].contiguous())
         e = rms(y.cpu().numpy() - g[key])
         fused = model(f0, control, phase_u=pu, noise=nz)
         record("module_chain_" + key, rms_err=e, rms_vs_fused=rms((y - fused).cpu().numpy()))

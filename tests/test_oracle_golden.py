@@ -98,6 +98,33 @@ def test_g5_lut_bit_exact(oracles):
     assert np.array_equal(g["probe_out"][:, -1], g["probe_out"][:, -2])
 
 
+@pytest.mark.parametrize("name", ["g8_small", "g8_odd"])
+def test_g8_non_default_gin_configurations(name):
+    """The oracle is generic in every gin-configurable size; pinned on two non-default configurations recorded from the
+    real reference (random init; 60 harmonics / 32 shapers of width 16, depth 3 / GRU 96 / embedding 80 / hop 64 / 128-tap
+    FIR / two NEWT output channels / 1 s reverb, and an odd one: 7 / 5 / width 3, depth 2 / 33 / 17 / hop 10 / 30 taps / 8 kHz)."""
+    import json
+
+    z = load_npz(name + ".npz")
+    w = {k: v for k, v in z.items() if not k.startswith("__")}
+    hp = json.loads(str(z["__hparams__"]))
+    kw = dict(sample_rate=hp["sample_rate"], control_hop=hp["control_hop"], table_size=int(z["__table_size__"]),
+              table_min=float(z["__table_min__"]), table_max=float(z["__table_max__"]))
+    exact, fast = OracleNEWT(w, fast=False, **kw), OracleNEWT(w, fast=True, lut_python_loop=False, **kw)
+    st = {}
+    y = exact(z["__f0__"], z["__control__"], z["__phase_u__"], z["__noise__"], stages=st).numpy()
+    yf = fast(z["__f0__"], z["__control__"], z["__phase_u__"], z["__noise__"]).numpy()
+    assert np.array_equal(st["osc"].numpy(), z["__osc__"])                   # bit-exact oscillator bank
+    assert np.array_equal(fast.lookup_table().numpy(), z["__lookup_table__"])
+    for k, tol in dict(exciter=1e-6, embedding=1e-6, film=2e-6, H=2e-6).items():
+        assert np.max(np.abs(st[k].numpy() - z[f"__{k}__"])) <= tol, k
+    assert np.max(np.abs(st["noise_out"].numpy() - z["__noise_out__"][:, 0])) <= 1e-6
+    assert np.max(np.abs(st["pre_reverb"].numpy() - z["__pre_reverb__"])) <= 1e-5
+    assert y.shape == z["__y_newt__"].shape
+    assert rms(y - z["__y_newt__"]) <= 2e-6, rms(y - z["__y_newt__"])
+    assert rms(yf - z["__y_fast__"]) <= 2e-6, rms(yf - z["__y_fast__"])
+
+
 def test_rng_draw_order_matches_reference(oracles, g1):
     """Drawing inside the oracle consumes torch's CPU generator in the reference's order and sizes."""
     exact, _ = oracles
