@@ -53,8 +53,11 @@ def test_harmonic_oscillator_forward(models, g):
     torch.manual_seed(3)
     b = exact.osc(dev(g["f0_up"]))
     assert torch.equal(a, b) and not torch.equal(a, osc)
+    # a length that is not a multiple of 128 takes the runtime-size kernels (csrc/generic.hip): same values
+    c = exact.osc(dev(g["f0_up"])[:, :100].contiguous(), phase_u=dev(g["phase_u"]))
+    assert c.shape == (2, 101, 100) and maxabs(c.cpu().numpy(), g["osc"][:, :, :100]) <= 2e-6
     with pytest.raises(RuntimeError):
-        exact.osc(torch.zeros(1, 100, device="cuda"))          # not a multiple of 128 on the HIP path
+        exact.osc(torch.zeros(1, 2, 100, device="cuda"))       # (B, N) expected
 
 
 def test_control_module_and_time_distributed_mlps(models, g):
