@@ -45,7 +45,7 @@ def exciter_mfma_flop_per_sample(terms, film_mfma):
     return terms * 2 * 64 * 112 + (6 * 2 * 32 * 32 * 16 / 32.0 if film_mfma else 0.0)
 
 
-FLOP_PER_FRAME_MLPS = 2 * (128 * 128 + 3 * 128 * 128 + 256 * 128 + 3 * 128 * 128 + 129 * 128 + 256 * 132)   # proj, 2 MLPs, FIR design
+FLOP_PER_FRAME_MLPS = 2 * (128 * 128 + 3 * 128 * 128 + 256 * 128 + 3 * 128 * 128 + 129 * 128 + 128 * 132)   # proj, 2 MLPs, FIR design (upper half-taps)
 FLOP_PER_STEP_GRU = 2 * (384 * 128 + 384 * 2)           # per utterance and control frame
 FLOP_PER_FRAME_NOISE = 2 * 256 * 512                    # two overlapping 256-tap circular convolutions per output hop
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
@@ -53,7 +53,7 @@ PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector peak
 PEAK_HBM_TBS = 8.0              # MI355X_MICROARCH.md: HBM3E spec peak (6.3 achievable)
 MAX_CLOCK_GHZ = 2.4
 N_SIMD = 1024
-FIR_ROW_FLOATS = 256     # floats per (utterance, frame) handed from the frame MLPs to the noise kernel (time-domain taps)
+FIR_ROW_FLOATS = 128     # floats per (utterance, frame) handed from the frame MLPs to the noise kernel (upper half of the mirror-symmetric taps)
 
 
 def parse():
@@ -292,7 +292,7 @@ def hbm_algorithmic_bytes(B, T):
         # f0 frames + FiLM rows (B,T,256) in, carries (B, N/32) f64 in, fragment + pair tables (28 KB + 2 MB, shared), out (B,N)
         "exciter_newt_kernel": 4 * B * T + 1024 * B * T + 8 * B * N // 32 + 28672 + 2 * 64 * 4096 * 4 + 4 * B * N,
         "control_gru_kernel": 8 * B * T + 512 * B * T + 384 * 131 * 4,                 # control in, gru_out (B,T,128) out, weights
-        "frame_mlps16_kernel": 512 * B * T + 819200 + 1024 * B * T + 4 * B * T * FIR_ROW_FLOATS,   # gru_out in, frags, film + noise-filter rows out
+        "frame_mlps16_kernel": 512 * B * T + 745472 + 1024 * B * T + 4 * B * T * FIR_ROW_FLOATS,   # gru_out in, frags, film + noise-filter rows out
         "fir_noise_mfma_kernel": 4 * B * T * FIR_ROW_FLOATS + 4 * N + 2 * 4 * B * N,  # filter rows in, noise, add_in in + out
         "reverb": 2 * 4 * B * N + 3 * 2 * 2 * 4 * B * N,                             # x in, y out, + 3 passes over complex planes (r+w) / 2 utt. per transform
     }

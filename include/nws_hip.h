@@ -35,6 +35,7 @@ extern "C" {
 #define NWS_HOP 128
 #define NWS_FIR_LEN 256
 #define NWS_N_BANDS 129      /* FIR_LEN/2 + 1 */
+#define NWS_FIR_HALF 128     /* taps handed from the frame MLPs to the noise kernel per frame: h[128 .. 255] (see nws_frame_mlps) */
 #define NWS_SHAPER_WIDTH 8
 #define NWS_FILM_CH 256      /* 4 * N_SHAPERS */
 
@@ -69,7 +70,7 @@ typedef struct NwsWeights {
   const float* hgen_b[4];
   const float* hgen_ln_g[3];
   const float* hgen_ln_b[3];
-  /* optional 819200 B from nws_mlp_frags(): proj / newt.mlp / h_generator / FIR-design weights as two fp16 terms in MFMA
+  /* optional NWS_MLP_FRAGS_BYTES from nws_mlp_frags(): proj / newt.mlp / h_generator / FIR-design weights as two fp16 terms in MFMA
    * fragment order -> frame MLPs on the fp16 matrix pipe; NULL -> exact-fp32 MFMA kernel */
   const void* mlp_frags;
   /* newt.shaping_fn = TrainableNonlinearity(64, 8, depth=4) (models/modules/shaping.py:15-37) */
@@ -173,15 +174,20 @@ int nws_control_gru_batched(const NwsWeights* w, const float* control, int B, in
  *   film = newt.mlp(emb)                         models/modules/shaping.py:68, dynamic.py:20-40
  *   H    = h_generator(emb)                      models/neural_waveshaping.py:82
  *   fir  = window * roll(irfft(H), 128)          models/modules/generators.py:22-27 (zero-phase FIR design)
- * emb_out (B,128,T) [optional], film_out (B,T,256), H_out (B,T,129) [optional], fir_out (B,T,256).
+ * emb_out (B,128,T) [optional], film_out (B,T,256), H_out (B,T,129) [optional], fir_out (B,T,128).
  * fir_design: (256, 132) constant matrix from nws_fir_design_matrix().
+ * fir_out holds the UPPER HALF of every frame's taps, u[d] = h[128 + d], d = 0..127: H is real, so irfft(H) is even and with
+ * a window symmetric about tap 128 whose tap 0 is zero (the reference's periodic Hann, generators.py:20) the rolled,
+ * windowed response satisfies h[128 - d] = h[128 + d], h[0] = 0.  Half the bytes between the two kernels; the noise
+ * kernels mirror the row while staging it.  The caller checks the window (engine.py: any other window takes the
+ * runtime-size path, whose nws_g_fir_design emits full rows).
  */
 int nws_frame_mlps(const NwsWeights* w, const float* gru_out, const float* fir_design, int B, int T,
                    float* emb_out, float* film_out, float* H_out, float* fir_out, void* stream);
 
 /* pre-split weight fragments for the fp16 two-term frame-MLP kernel (valid while |layer inputs| stay inside fp16 range:
  * the caller checks the weight-norm bounds, see engine.py) */
-#define NWS_MLP_FRAGS_BYTES 819200
+#define NWS_MLP_FRAGS_BYTES 745472
 int nws_mlp_frags(const NwsWeights* w, const float* fir_design /* (256,132) */, void* frags_out, void* stream);
 
 /* D[n][k]: fir[n] = sum_k D[n][k] H[k]  (irfft + roll(128) + window folded), (256, 132) fp32, cols 129..131 = 0. */
@@ -193,7 +199,7 @@ int nws_fir_design_matrix(const float* window /* (256) */, float* D_out, void* s
  * convolution with fir[b][t], overlap-add / overlap count.   out = add_in + noise_branch
  * (the cat+sum of models/neural_waveshaping.py:85-86); add_in may be NULL.
  */
-int nws_fir_noise(const float* fir /* (B,T,256) */, const float* noise /* (N-1) */, const float* add_in /* (B,N) */,
+int nws_fir_noise(const float* fir /* (B,T,128): upper half-taps, see nws_frame_mlps */, const float* noise /* (N-1) */, const float* add_in /* (B,N) */,
                   int B, int T, float* out /* (B,N) */, void* stream);
 /* general form: STFT frame t covers noise[128 t - origin, 128 t - origin + 256), reflected about 0 and noise_len-1 like
  * torch.stft's reflect padding (nws_fir_noise == origin 128, noise_len N-1); streaming windows use origin 0 */
@@ -252,8 +258,8 @@ int nws_td_layer_norm(const float* x, const float* gain, const float* bias, int 
                       void* stream);
 /* FiLM.forward (dynamic.py:6-8): y = gamma * x + beta on n equally laid out elements */
 int nws_film(const float* x, const float* gamma, const float* beta, int64_t n, float* y, void* stream);
-/* zero-phase FIR design of FIRNoiseSynth.forward (generators.py:22-28): H (B, 129, T) -> fir (B, T, 256) taps
- * (window * roll(irfft(H), 128)); feed nws_fir_noise with them */
+/* zero-phase FIR design of FIRNoiseSynth.forward (generators.py:22-28): H (B, 129, T) -> fir (B, T, 128) upper half-taps
+ * (window * roll(irfft(H), 128))[128:256]; feed nws_fir_noise with them */
 int nws_fir_from_h(const float* H, const float* fir_design /* (256,132) */, int B, int T, float* fir_out, void* stream);
 
 /* ---- FastNEWT table (models/modules/shaping.py:107-119): table[s][i] = shaper_s(linspace(min,max,size)[i]) ---- */

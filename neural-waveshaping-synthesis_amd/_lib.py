@@ -21,6 +21,8 @@ N_SHAPERS = 64
 HIDDEN = 128
 HOP = 128
 FIR_LEN = 256
+FIR_HALF = 128           # taps per row handed from the frame MLPs to the noise kernels: h[128 .. 255] (include/nws_hip.h)
+MLP_FRAGS_BYTES = 745472
 N_BANDS = 129
 FILM_CH = 256
 SHAPER_WIDTH = 8

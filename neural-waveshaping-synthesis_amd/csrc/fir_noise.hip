@@ -20,6 +20,7 @@ namespace {
 
 constexpr int kL = NWS_FIR_LEN;  // 256
 constexpr int kHop = NWS_HOP;    // 128
+constexpr int kHalf = NWS_FIR_HALF;  // taps per stored row: h[128 .. 255]
 constexpr int kHopsPerBlock = 4;
 
 struct NoiseLds {
@@ -48,10 +49,12 @@ __global__ __launch_bounds__(256) void fir_noise_kernel(const float* __restrict_
   const int t0 = blockIdx.x * kHopsPerBlock;
   const int N = T * kHop;
 
+  // fir holds the upper half-taps u[d] = h[128 + d]; the row is symmetric about tap 128 and h[0] = 0 (include/nws_hip.h)
   for (int e = tid; e < (kHopsPerBlock + 1) * kL; e += 256) {
     const int fr = e >> 8, k = e & 255;
     const int t = t0 - 1 + fr;
-    const float v = (t >= 0 && t < T) ? fir[((size_t)b * T + t) * kL + k] : 0.0f;
+    const int d = k >= kHalf ? k - kHalf : kHalf - k;      // k = 0 -> d = 128: the zero tap
+    const float v = (t >= 0 && t < T && d < kHalf) ? fir[((size_t)b * T + t) * kHalf + d] : 0.0f;
     L.taps[fr][k] = v;
     L.taps1[fr][(k + 1) & 255] = v;
   }
@@ -127,7 +130,8 @@ __global__ __launch_bounds__(256) void fir_noise_kernel(const float* __restrict_
 // frame t-1's, i.e. ONE accumulation over K = 512: D[b][j] = sum_k h_t[b][k] f_t[(j-k)&255] + sum_k h_{t-1}[b][k] f_{t-1}[(128+j-k)&255].
 // fp32 accuracy from fp16 MFMAs by the two-term split (x = hi + lo, three products); taps are pre-scaled by a per-utterance
 // power of two and the noise by 2^10 so that the lo parts stay out of the fp16 subnormal range.
-//  * A operand (utterance rows): taps as fp16 hi/lo rows in LDS, row stride 528 B (bank-conflict-free b128 reads).
+//  * A operand (utterance rows): taps as fp16 hi/lo half rows in LDS, row stride 272 B (bank-conflict-free b128 reads);
+//    HBM holds the upper 128 taps of every frame only (mirror-symmetric rows, include/nws_hip.h).
 //  * B operand (sample columns): lane (j, khalf) needs 8 CONSECUTIVE entries of the reversed noise frame starting at
 //    (k0 + 8 khalf - j) & 255 -- an arbitrary offset, but its low three bits are (-j) & 7, fixed per lane: eight copies of
 //    the reversed frame, copy c shifted by c, make every read an aligned ds_read_b128 (copy stride 544 B: conflict-free).
@@ -188,14 +192,21 @@ __global__ __launch_bounds__(256, 4) void fir_noise_mfma_kernel(const float* __r
   // idle in every one of the 416 staging instructions), and the per-row scale search runs on two rows at once.
   const int p32 = lane & 31;
   const int my_row = wave + 4 * kh;   // this lane's row of it = 0; row(it) = wave + 4 (2 it + kh) = my_row + 8 it
+  // The stored row is the upper half u[d] = h[128 + d] (include/nws_hip.h); the lower half is its mirror image:
+  // h[4p + i] = u[128 - 4p - i] with u[128] := 0 (h[0] = 0).  Lane p fetches the aligned quad A = u[124 - 4p .. 127 - 4p] and takes
+  // u[128 - 4p] = the first element of lane p-1's quad (one DPP lane shift): both halves
+  // of a row come out of the SAME 512 B of HBM.
   auto load_rows = [&](int frame, float4 (&v)[8]) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int b = b0 + my_row + 8 * it;
       const bool ok = frame >= 0 && frame < T && b < B;
-      const float* src = &fir[((size_t)b * T + frame) * kL + 4 * p32];
-      v[it] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      v[it + 4] = ok ? *reinterpret_cast<const float4*>(src + kL / 2) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      // (two index expressions off the same row start: written as `src + 124 - 4 p` hipcc put a temporary on the stack)
+      const float* src = &fir[((size_t)b * T + frame) * kHalf + 4 * p32];
+      const float* src_lo = &fir[((size_t)b * T + frame) * kHalf + 4 * (31 - p32)];
+      const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      v[it + 4] = ok ? *reinterpret_cast<const float4*>(src) : zero;
+      v[it] = ok ? *reinterpret_cast<const float4*>(src_lo) : zero;     // the raw quad A; mirrored when staged
     }
   };
   float4 cur[8], prv[8];
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(256, 4) void fir_noise_mfma_kernel(const float* __r
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     auto amax4 = [](const float4& a) { return fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))); };
-    float mx = fmaxf(fmaxf(amax4(cur[it]), amax4(cur[it + 4])), fmaxf(amax4(prv[it]), amax4(prv[it + 4])));
+    float mx = fmaxf(amax4(cur[it + 4]), amax4(prv[it + 4]));     // the upper halves hold every distinct tap of the two rows
     mx = half_max(mx);   // over the 32 lanes that hold this row
     int ex = (int)((__float_as_uint(mx) >> 23) & 0xff);  // biased exponent of the row maximum
     ex = ex < 16 ? 16 : (ex > 250 ? 250 : ex);
@@ -225,9 +236,12 @@ __global__ __launch_bounds__(256, 4) void fir_noise_mfma_kernel(const float* __r
 
   // reversed noise frames, eight shifted copies each: frame 0: R[u] = f_t[(-u) & 255] = win[128 + ((-u) & 255)];
   // frame 1: R[u] = f_{t-1}[(128 - u) & 255] = win[(128 - u) & 255].  One thread fills 8 consecutive v (one 16-byte chunk).
+  // (lane -> chunk with the shift c fastest: the 8 lanes of one v0 read 15 CONSECUTIVE win entries between them and the next
+  // group continues 8 further on, so a half-wave's ds_read_b32 touch 32 distinct banks; with v0 fastest the lanes were 8
+  // dwords apart - 4 banks, 8-way conflicts - which is where the 0.37 LDS bank-conflict rate of round 2 came from)
   for (int ch = tid; ch < 2 * 8 * (kCopyHalfs / 8); ch += 256) {
     const int fr = ch / (8 * (kCopyHalfs / 8)), rem = ch - fr * (8 * (kCopyHalfs / 8));
-    const int c = rem / (kCopyHalfs / 8), v0 = 8 * (rem - c * (kCopyHalfs / 8));
+    const int c = rem & 7, v0 = 8 * (rem >> 3);
     f16x8 h8, l8;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -248,7 +262,12 @@ __global__ __launch_bounds__(256, 4) void fir_noise_mfma_kernel(const float* __r
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int r = my_row + 8 * it;
-      const float4 t4 = v[it + 4 * khalf];
+      float4 t4 = v[it + 4 * khalf];
+      if (khalf == 0) {   // lower half: h[4p + i] = u[128 - 4p - i] from the quad A = u[124 - 4p .. 127 - 4p] (see load_rows)
+        float up = dpp_f32<0x138, 0xf>(t4.x);      // wave_shr:1: lane l <- lane l-1 (lane 0 keeps the 0 of `old`)
+        up = p32 == 0 ? 0.0f : up;                 // u[128] := 0 (h[0] = 0); also cuts the shift across the two rows of a wave
+        t4 = make_float4(up, t4.w, t4.z, t4.y);
+      }
       f16x2 h01, l01, h23, l23;
       split16x2(t4.x * scale[it], t4.y * scale[it], h01, l01);
       split16x2(t4.z * scale[it], t4.w * scale[it], h23, l23);

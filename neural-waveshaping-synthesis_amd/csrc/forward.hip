@@ -52,7 +52,7 @@ size_t nws_forward_workspace_bytes(const NwsReverbPlan* plan, int B, int T) {
   total += aligned((size_t)B * (N / 32) * sizeof(double));          // carries
   total += aligned((size_t)B * T * NWS_HIDDEN * sizeof(float));     // gru_out
   total += aligned((size_t)B * T * NWS_FILM_CH * sizeof(float));    // film
-  total += aligned((size_t)B * T * NWS_FIR_LEN * sizeof(float));    // fir
+  total += aligned((size_t)B * T * NWS_FIR_HALF * sizeof(float));   // fir (upper half-taps)
   total += aligned((size_t)B * N * sizeof(float));                  // newt_out
   total += aligned((size_t)B * N * sizeof(float));                  // pre-reverb
   total += aligned(nws_reverb_workspace_bytes(plan, B));
@@ -81,7 +81,7 @@ Arena carve_arena(const NwsReverbPlan* plan, void* workspace, size_t bytes, int 
   a.gru_out = static_cast<float*>(cv.take((size_t)B * T * NWS_HIDDEN * sizeof(float)));
   if (!head_only) {
     a.film = static_cast<float*>(cv.take((size_t)B * T * NWS_FILM_CH * sizeof(float)));
-    a.fir = static_cast<float*>(cv.take((size_t)B * T * NWS_FIR_LEN * sizeof(float)));
+    a.fir = static_cast<float*>(cv.take((size_t)B * T * NWS_FIR_HALF * sizeof(float)));
     a.newt_out = static_cast<float*>(cv.take((size_t)B * N * sizeof(float)));
     a.pre = static_cast<float*>(cv.take((size_t)B * N * sizeof(float)));
     a.rv_bytes = nws_reverb_workspace_bytes(plan, B);

@@ -210,16 +210,15 @@ __global__ __launch_bounds__(256) void frame_mlps_kernel(NwsWeights w, const flo
   }
   __syncthreads();
 
-  // ---- fir = D * H  (256 taps) ----
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    const int c0 = 32 * (wave + 4 * pass);
+  // ---- fir = D[128 .. 255] * H  (the upper 128 taps: the lower half is their mirror image, include/nws_hip.h) ----
+  {
+    const int c0 = 32 * wave;
     f32x16 acc;
-    gemm_tile<kDK / 2>(fir_design, kDK, c0, NWS_FIR_LEN, L.p1, lane, acc);
+    gemm_tile<kDK / 2>(fir_design + (size_t)NWS_FIR_HALF * kDK, kDK, c0, NWS_FIR_HALF, L.p1, lane, acc);
     float v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = acc[r];
-    store_tile_frame_major(L.stage[wave], v, lane, fir_out + ((size_t)b * T + t0) * NWS_FIR_LEN + c0, NWS_FIR_LEN,
+    store_tile_frame_major(L.stage[wave], v, lane, fir_out + ((size_t)b * T + t0) * NWS_FIR_HALF + c0, NWS_FIR_HALF,
                            frames_valid);
   }
 }
@@ -245,15 +244,16 @@ struct FragMap {
   int base, mt, ks;
 };
 __host__ __device__ constexpr FragMap frag_map(int id) {
-  // 0 proj | 1-3 newt hidden | 4 newt out (256) | 5-7 hgen hidden | 8 hgen out (129 -> 160) | 9 FIR design (K 132 -> 144)
+  // 0 proj | 1-3 newt hidden | 4 newt out (256) | 5-7 hgen hidden | 8 hgen out (129 -> 160) | 9 FIR design rows 128..255 (K 132 -> 144)
   return id == 0 ? FragMap{0, 4, 8}
        : id <= 3 ? FragMap{4096 * id, 4, 8}
        : id == 4 ? FragMap{16384, 8, 8}
        : id <= 7 ? FragMap{24576 + 4096 * (id - 5), 4, 8}
        : id == 8 ? FragMap{36864, 5, 8}
-                 : FragMap{41984, 8, 9};
+                 : FragMap{41984, 4, 9};   // rows 128..255 of D only (upper half-taps)
 }
-constexpr int kFragTotal = 51200;  // x 16 B = 819200 B
+constexpr int kFragTotal = 46592;  // x 16 B = 745472 B
+static_assert(kFragTotal * 16 == NWS_MLP_FRAGS_BYTES, "fragment table size");
 
 struct MlpLds16 {
   char xt[4][2][kXtBytes];     // four activation buffers E, X, Y, Z, each [hi|lo]; dead ones double as store patches
@@ -549,19 +549,20 @@ __global__ __launch_bounds__(512, 4) void frame_mlps16_kernel(NwsWeights w, cons
         split4_store(Z, Z + kXtBytes, col, 128 + 8 * g + 4 * half, vh[4 * g], vh[4 * g + 1], vh[4 * g + 2], vh[4 * g + 3]);
     }
   }
+  // ---- fir = D[128 .. 255] * H  (upper half-taps = 4 M-tiles, K = 144 padded): waves 0-3; their fragments are requested
+  // before the barrier (nothing else to wait for).  Waves 4-7 have produced H and are done. ----
   AFrag<9> A9;
-  __builtin_amdgcn_sched_barrier(0);   // the fragments reuse registers the MFMAs above have just released
-  load_frags<9>(A9, F + frag_map(9).base, wave, lane);   // FIR design, M-tile `wave`
+  if (path == 0) {
+    __builtin_amdgcn_sched_barrier(0);   // the fragments reuse registers the MFMAs above have just released
+    load_frags<9>(A9, F + frag_map(9).base, mt, lane);
+  }
   __syncthreads();
-
-  // ---- fir = D * H  (256 taps = 8 M-tiles, K = 144 padded); X is dead too: patches of waves 4-7 ----
-  {
-    float* patch9 = path ? reinterpret_cast<float*>(X) + mt * (kFT * kPS) : patch;
+  if (path == 0) {
     float v[16];
     mma_tile1<9>(A9, Z, lane, acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = acc[r];
-    store_tile_frame_major(patch9, v, lane, fir_out + ((size_t)b * T + t0) * NWS_FIR_LEN + 32 * wave, NWS_FIR_LEN, frames_valid);
+    store_tile_frame_major(patch, v, lane, fir_out + ((size_t)b * T + t0) * NWS_FIR_HALF + 32 * mt, NWS_FIR_HALF, frames_valid);
   }
 }
 
@@ -583,7 +584,7 @@ __global__ void mlp_frags_kernel(NwsWeights w, const float* __restrict__ fir_des
   if (id == 0) { W = w.proj_w; rows = 128; ld = 128; kmax = 128; }
   else if (id <= 4) { W = w.newt_mlp_w[id - 1]; rows = id == 4 ? 256 : 128; ld = 128; kmax = 128; }
   else if (id <= 8) { W = w.hgen_w[id - 5]; rows = id == 8 ? NWS_N_BANDS : 128; ld = 128; kmax = 128; }
-  else { W = fir_design; rows = NWS_FIR_LEN; ld = kDK; kmax = NWS_N_BANDS; }
+  else { W = fir_design + (size_t)NWS_FIR_HALF * kDK; rows = NWS_FIR_HALF; ld = kDK; kmax = NWS_N_BANDS; }   // D rows 128..255
   f16x8 hi, lo;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {

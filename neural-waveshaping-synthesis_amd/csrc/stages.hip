@@ -109,18 +109,18 @@ __global__ void film_kernel(const float* __restrict__ x, const float* __restrict
     y[i] = gamma[i] * x[i] + beta[i];
 }
 
-// FIR design of FIRNoiseSynth.forward (generators.py:22-28) from H (B, 129, T): fir[b][t][n] = sum_k D[n][k] H[b][k][t]
+// FIR design of FIRNoiseSynth.forward (generators.py:22-28) from H (B, 129, T): fir[b][t][d] = sum_k D[128 + d][k] H[b][k][t], d < 128
 // with D = window * roll(irfft(.), 128) folded into one (256, 132) matrix (nws_fir_design_matrix).
-__global__ __launch_bounds__(256) void fir_from_h_kernel(const float* __restrict__ H, const float* __restrict__ D, int T,
+__global__ __launch_bounds__(128) void fir_from_h_kernel(const float* __restrict__ H, const float* __restrict__ D, int T,
                                                          float* __restrict__ fir) {
   __shared__ float hs[NWS_N_BANDS][kFT + 1];
   const int b = blockIdx.y, t0 = blockIdx.x * kFT;
-  for (int i = threadIdx.x; i < NWS_N_BANDS * kFT; i += 256) {
+  for (int i = threadIdx.x; i < NWS_N_BANDS * kFT; i += 128) {
     const int k = i / kFT, f = i - k * kFT;
     hs[k][f] = t0 + f < T ? H[((size_t)b * NWS_N_BANDS + k) * T + t0 + f] : 0.0f;
   }
   __syncthreads();
-  const int n = threadIdx.x;                 // tap
+  const int n = NWS_FIR_HALF + threadIdx.x;  // tap 128 .. 255 (the lower half is the mirror image, include/nws_hip.h)
   float acc[kFT];
 #pragma unroll
   for (int f = 0; f < kFT; ++f) acc[f] = 0.0f;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void fir_from_h_kernel(const float* __restrict
   }
 #pragma unroll
   for (int f = 0; f < kFT; ++f)
-    if (t0 + f < T) fir[((size_t)b * T + t0 + f) * NWS_FIR_LEN + n] = acc[f];
+    if (t0 + f < T) fir[((size_t)b * T + t0 + f) * NWS_FIR_HALF + threadIdx.x] = acc[f];
 }
 
 }  // namespace
@@ -191,7 +191,7 @@ int nws_film(const float* x, const float* gamma, const float* beta, int64_t n, f
 int nws_fir_from_h(const float* H, const float* fir_design, int B, int T, float* fir_out, void* stream) {
   if (!H || !fir_design || !fir_out || B <= 0 || T <= 0) return NWS_ERR_BAD_ARG;
   if (B > 65535) return NWS_ERR_UNSUPPORTED;
-  fir_from_h_kernel<<<dim3((T + kFT - 1) / kFT, B), 256, 0, (hipStream_t)stream>>>(H, fir_design, T, fir_out);
+  fir_from_h_kernel<<<dim3((T + kFT - 1) / kFT, B), 128, 0, (hipStream_t)stream>>>(H, fir_design, T, fir_out);
   NWS_CHECK_LAUNCH();
   return NWS_OK;
 }

@@ -281,7 +281,7 @@ std::tuple<Tensor, Tensor> control_gru(const Tensor& wdesc, const Tensor& contro
   return {out, hT};
 }
 
-// proj + newt.mlp + h_generator + FIR design in one kernel: -> (emb (B,128,T), film (B,T,256), H (B,T,129), fir (B,T,256))
+// proj + newt.mlp + h_generator + FIR design in one kernel: -> (emb (B,128,T), film (B,T,256), H (B,T,129), fir (B,T,128) upper half-taps)
 std::tuple<Tensor, Tensor, Tensor, Tensor> frame_mlps(const Tensor& wdesc, const Tensor& gru_out, const Tensor& fir_design,
                                                        bool want_emb, bool want_H) {
   const NwsWeights* w = weights_of(wdesc);
@@ -296,7 +296,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> frame_mlps(const Tensor& wdesc, const
   Tensor emb = want_emb ? at::empty({B, NWS_HIDDEN, T}, o) : at::empty({0}, o);
   Tensor film = at::empty({B, T, NWS_FILM_CH}, o);
   Tensor H = want_H ? at::empty({B, T, NWS_N_BANDS}, o) : at::empty({0}, o);
-  Tensor fir = at::empty({B, T, NWS_FIR_LEN}, o);
+  Tensor fir = at::empty({B, T, NWS_FIR_HALF}, o);
   nws_check(nws_frame_mlps(w, gru_out.data_ptr<float>(), fir_design.data_ptr<float>(), (int)B, (int)T,
                            want_emb ? emb.data_ptr<float>() : nullptr, film.data_ptr<float>(),
                            want_H ? H.data_ptr<float>() : nullptr, fir.data_ptr<float>(), L.stream), "nws_frame_mlps");
@@ -308,7 +308,7 @@ Tensor fir_noise(const Tensor& fir, const Tensor& noise, const OptTensor& add_in
   check_dev(fir, "fir");
   check_dev(noise, "noise");
   check_same_device(fir, "fir", noise, "noise");
-  TORCH_CHECK(fir.dim() == 3 && fir.size(2) == NWS_FIR_LEN, "fir: expected (B, T, 256), got ", fir.sizes());
+  TORCH_CHECK(fir.dim() == 3 && fir.size(2) == NWS_FIR_HALF, "fir: expected (B, T, 128) upper half-taps (nws_frame_mlps), got ", fir.sizes());
   const int64_t B = fir.size(0), T = fir.size(1);
   if (add_in.has_value()) {
     check_dev(*add_in, "add_in");
@@ -328,7 +328,7 @@ Tensor fir_noise(const Tensor& fir, const Tensor& noise, const OptTensor& add_in
   return out;
 }
 
-// FIRNoiseSynth's zero-phase FIR design from H (B, 129, T) (generators.py:22-28) -> taps (B, T, 256)
+// FIRNoiseSynth's zero-phase FIR design from H (B, 129, T) (generators.py:22-28) -> upper half-taps (B, T, 128)
 Tensor fir_from_h(const Tensor& H, const Tensor& fir_design) {
   check_dev(H, "H");
   check_dev(fir_design, "fir_design");
@@ -336,7 +336,7 @@ Tensor fir_from_h(const Tensor& H, const Tensor& fir_design) {
   TORCH_CHECK(H.dim() == 3 && H.size(1) == NWS_N_BANDS, "FIRNoiseSynth: expected H of shape (B, 129, T), got ", H.sizes());
   TORCH_CHECK(fir_design.numel() == NWS_FIR_LEN * 132, "fir_design: expected (256, 132)");
   Launch L(H);
-  Tensor fir = at::empty({H.size(0), H.size(2), NWS_FIR_LEN}, H.options());
+  Tensor fir = at::empty({H.size(0), H.size(2), NWS_FIR_HALF}, H.options());
   nws_check(nws_fir_from_h(H.data_ptr<float>(), fir_design.data_ptr<float>(), (int)H.size(0), (int)H.size(2), fir.data_ptr<float>(),
                            L.stream), "nws_fir_from_h");
   return fir;

@@ -169,7 +169,22 @@ class Engine:
         except AttributeError:
             ok = False
         self._spec = (_EPOCH[0], bool(ok))
-        return bool(ok)
+        return bool(ok) and self._window_symmetric()
+
+    def _window_symmetric(self) -> bool:
+        """The fused kernels hand HALF of every frame's FIR taps from the frame MLPs to the noise kernel (include/nws_hip.h,
+        nws_frame_mlps): valid when noise_synth.window is symmetric about tap L/2 with window[0] == 0 - the reference's
+        periodic Hann (generators.py:20).  Any other window_fn takes the runtime-size path (full rows).  One 1 KB read per
+        window version."""
+        win = self._model_ref.noise_synth.window
+        key = (win.data_ptr(), win._version)
+        hit = self.__dict__.get("_win_ok")
+        if hit is None or hit[0] != key:
+            w = win.detach().float().cpu()
+            L = w.numel()
+            ok = bool(L == _lib.FIR_LEN and float(w[0]) == 0.0 and torch.equal(w[1:L // 2], w[L // 2 + 1:].flip(0)))
+            hit = self._win_ok = (key, ok)
+        return hit[1]
 
     @property
     def generic(self):
@@ -307,7 +322,7 @@ class Engine:
             keep.append(fd)
             w.mlp_frags = None
             if self.fp16_mlp_safe():
-                frags = torch.empty(819200, dtype=torch.uint8, device=dev)
+                frags = torch.empty(_lib.MLP_FRAGS_BYTES, dtype=torch.uint8, device=dev)
                 check(L.nws_mlp_frags(C.byref(w), ptr(fd), ptr(frags), st), "nws_mlp_frags")
                 keep.append(frags)
                 w.mlp_frags = frags.data_ptr()
@@ -466,7 +481,7 @@ class Engine:
             emb = torch.empty((B, _lib.HIDDEN, T), dtype=torch.float32, device=dev) if want_emb else None
             film = torch.empty((B, T, _lib.FILM_CH), dtype=torch.float32, device=dev)
             H = torch.empty((B, T, _lib.N_BANDS), dtype=torch.float32, device=dev) if want_H else None
-            fir = torch.empty((B, T, _lib.FIR_LEN), dtype=torch.float32, device=dev)
+            fir = torch.empty((B, T, _lib.FIR_HALF), dtype=torch.float32, device=dev)
             check(_lib.lib().nws_frame_mlps(C.byref(w), ptr(gru_out), ptr(self._fir_design), B, T, ptr(emb), ptr(film),
                                             ptr(H), ptr(fir), stream_ptr(dev)), "nws_frame_mlps")
         return emb, film, H, fir

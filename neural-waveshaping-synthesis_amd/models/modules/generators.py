@@ -47,7 +47,7 @@ class FIRNoiseSynth(nn.Module):
     def forward(self, H_re, *, noise=None):
         """H_re (B, ir_length/2 + 1, T) real filter magnitudes -> (B, 1, hop * T) filtered noise (generators.py:21-35).
         `noise` injects the excitation draw (hop * T - 1 samples) for parity tests."""
-        if self.ir_length != sa._lib.FIR_LEN or self.hop_length != sa._lib.HOP:
+        if self.ir_length != sa._lib.FIR_LEN or self.hop_length != sa._lib.HOP or not self._window_symmetric():
             return self._forward_generic(H_re, noise)
         H = sa.contiguous(H_re, "H_re")
         if H.dim() != 3 or H.shape[1] != sa._lib.N_BANDS:
@@ -62,7 +62,7 @@ class FIRNoiseSynth(nn.Module):
 
         def c_call(L):
             with torch.cuda.device(H.device):
-                fir = torch.empty((B, T, sa._lib.FIR_LEN), dtype=torch.float32, device=H.device)
+                fir = torch.empty((B, T, sa._lib.FIR_HALF), dtype=torch.float32, device=H.device)
                 out = torch.empty((B, T * sa._lib.HOP), dtype=torch.float32, device=H.device)
                 sa.checked(L.nws_fir_from_h(H.data_ptr(), D.data_ptr(), B, T, fir.data_ptr(), sa.stream_ptr(H.device)), "nws_fir_from_h")
                 sa.checked(L.nws_fir_noise(fir.data_ptr(), noise.data_ptr(), None, B, T, out.data_ptr(), sa.stream_ptr(H.device)),
@@ -73,6 +73,19 @@ class FIRNoiseSynth(nn.Module):
         out = o.fir_noise(o.fir_from_h(H, D), noise, None, -1) if o is not None else c_call(sa._lib.lib())
         return out.unsqueeze(1)
 
+
+    def _window_symmetric(self):
+        """the specialised kernels pass half rows of taps (include/nws_hip.h, nws_frame_mlps): needs a window that is symmetric
+        about tap L/2 with window[0] == 0, like the reference's periodic Hann"""
+        win = self.window
+        key = (win.data_ptr(), win._version)
+        hit = self.__dict__.get("_win_ok")
+        if hit is None or hit[0] != key:
+            w = win.detach().float().cpu()
+            L = w.numel()
+            hit = (key, bool(float(w[0]) == 0.0 and torch.equal(w[1:L // 2], w[L // 2 + 1:].flip(0))))
+            self.__dict__["_win_ok"] = hit
+        return hit[1]
 
     def _forward_generic(self, H_re, noise):
         """any even ir_length >= hop_length: runtime-size stage kernels (csrc/generic.hip: g_fir_design_kernel, g_fir_noise_kernel)"""

@@ -127,3 +127,32 @@ def test_default_configuration_still_takes_the_fused_kernels():
 
     m = build_model(True)
     assert m._engine.specialised()
+
+
+def test_asymmetric_window_leaves_the_fused_path(weights):
+    """The fused kernels hand over half of every frame's mirror-symmetric FIR taps; a window that is NOT symmetric about tap 128
+    (FIRNoiseSynth.window_fn is gin-configurable, generators.py:13-20) must take the runtime-size path by itself - and match
+    the oracle run on the same window."""
+    from gpu_util import build_model
+    from oracle.newt_oracle import OracleNEWT
+
+    w2 = {k: np.array(v, copy=True) for k, v in weights.items()}
+    w2["noise_synth.window"] = (np.hanning(257)[:256] * np.linspace(0.2, 1.0, 256)).astype(np.float32)    # tilted Hann
+    m = build_model(False)
+    assert m._engine.specialised()
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in w2.items()})
+    m = m.cuda()
+    assert not m._engine.specialised()
+    g = load_npz("g4_stream.npz")
+    f0, control, pu, nz = g["f0_T32"], g["control_T32"], g["phase_u_T32"], g["noise_T32"]
+    ref = OracleNEWT(w2, fast=False)(f0, control, pu, nz).numpy()
+    with torch.no_grad():
+        y = m(dev(f0), dev(control), phase_u=dev(pu), noise=dev(nz)).cpu().numpy()
+        H = torch.rand(2, 129, 5).cuda() * 0.01
+        nzs = torch.rand(128 * 5 - 1)
+        out = m.noise_synth(H, noise=nzs.cuda())                  # the stand-alone module takes the same decision
+    e = rms(y - ref)
+    record("generic_asymmetric_window", rms_err=e, out_rms=rms(ref))
+    assert e <= 1e-4, e
+    ref_n = OracleNEWT(w2, fast=False).fir_noise(H.cpu(), nzs).numpy()
+    assert maxabs(out.cpu().numpy(), ref_n) <= 1e-6

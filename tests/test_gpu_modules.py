@@ -176,6 +176,7 @@ def test_same_suite_through_the_ctypes_binding():
     """The torch-free binding of the same C-ABI (what INTEGRATION.md shows a foreign host): module tests + end-to-end parity."""
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_modules.py"),
                         os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_streaming.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_generic.py"),
                         "-k", "not offline_render and not soak and not full_size"],
                        env=dict(os.environ, NWS_BACKEND="ctypes"), capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
