@@ -669,6 +669,33 @@ def main():
             extra["streaming_hop256_hipgraph"] = {"p50_us": round(float(np.percentile(lat, 50)), 2),
                                                   "p99_us": round(float(np.percentile(lat, 99)), 2),
                                                   "buffer_period_us": 16000.0}
+            # config "streaming 256-sample hop", STATEFUL (GRU / phase / noise / reverb state carried across hops, linear reverb;
+            # streaming.NewtStream over csrc/stream.hip): push() = input copies + one graph launch + output copy; hop() = the
+            # captured hop on its own static buffers
+            st_model = model
+            strm = st_model.stream(1)
+            fh, ch = 220 + 20 * torch.rand(1, 1, 2, device=dev), torch.randn(1, 2, 2, device=dev)
+            for _ in range(20):
+                strm.push(fh, ch)
+            torch.cuda.synchronize()
+
+            def hop_lat(fn, n):
+                v = []
+                for _ in range(n):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    fn()
+                    e1.record()
+                    e1.synchronize()
+                    v.append(e0.elapsed_time(e1) * 1e3)
+                return {"p50_us": round(float(np.percentile(v, 50)), 2), "p99_us": round(float(np.percentile(v, 99)), 2)}
+
+            push_lat = hop_lat(lambda: strm.push(fh, ch), 500)
+            strm.static_io(2)
+            extra["streaming_hop256_stateful"] = dict(push_lat, static_io=hop_lat(lambda: strm.hop(2), 500), buffer_period_us=16000.0,
+                                                      note="NewtStream: state carried across hops, reverb as a linear convolution of "
+                                                           "the stream; steady-state hops replay a hipGraph")
+            del strm
             # the same B=1 clip as `batch1`, the forward (its two RNG draws included) captured once into a hipGraph: what a
             # serving loop with fixed shapes pays per clip without the seven launch gaps of the eager call
             f1, c1 = f0[:1].contiguous(), control[:1].contiguous()

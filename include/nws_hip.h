@@ -234,6 +234,30 @@ int nws_reverb_linear_chunk(const NwsReverbPlan* plan, const void* tables, const
                             size_t workspace_bytes, void* stream);
 
 /*
+ * ---- Stateful streaming (csrc/stream.hip): the reference's buffer benchmark (scripts/time_buffer_sizes.py:50-72)
+ * restarts the GRU, the oscillator phase and the reverb with every buffer; here B parallel streams carry them across chunks.
+ * The concatenated output equals the one-shot forward up to the reverb input for ANY chunking, and the learned reverb
+ * (models/modules/shaping.py:161-173) is applied as a linear convolution of the stream.  All state lives in one caller-owned
+ * device blob behind fixed pointers: a steady-state hop is eight launches that can be captured into a hipGraph.
+ * `plan` (the L = 64 000 plan of nws_reverb_plan(64000, ir_len + 1)) is only needed for chunks beyond 2048 samples and for
+ * nws_stream_reverb_tail; pass NULL to nws_stream_state_bytes when the stream never takes more than 16 frames at a time.
+ */
+size_t nws_stream_state_bytes(int B, int max_frames, int ir_len, const NwsReverbPlan* plan);
+int nws_stream_reset(void* state, size_t state_bytes, void* stream);
+int nws_stream_out_samples(int K, int first, int final);   /* 128 K (-64 for the first chunk, +64 for the final one) */
+long long nws_stream_noise_start(int first, long long frames_seen);
+int nws_stream_noise_draws(int K, int first, long long frames_seen);
+int nws_stream_step(const NwsWeights* w, const float* fir_design, const NwsReverbPlan* plan, const void* reverb_tables,
+                    const void* reverb_spectrum, void* state, size_t state_bytes, int B, int max_frames, const float* f0 /* (B,K) */,
+                    const float* control /* (B,C,K) */, int C, int K, int first, int final, long long frames_seen,
+                    long long nz_prev_start, float sample_rate, const float* phase_u, const float* rand_phase,
+                    const float* noise_new, const float* noise_all, int noise_all_len, const float* ir, int ir_len,
+                    float* out /* (B, M) */, float* pre_out /* optional (B, M) */, void* stream);
+int nws_stream_reverb_tail(const NwsReverbPlan* plan, const void* reverb_tables, const void* reverb_spectrum, void* state,
+                           size_t state_bytes, int B, int max_frames, int ir_len, float* tail_out /* (B, ir_len + 1) */,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Stand-alone forms of the reference's sub-modules ("the seven module classes" are public interface).  Inside
  * nws_forward the same arithmetic is fused; these entry points serve callers that invoke a sub-module on its own
  * (model.osc(f0), model.newt(exciter, emb), model.h_generator(emb), model.noise_synth(H), ...).

@@ -156,6 +156,16 @@ _PROTOTYPES = {
     "nws_forward_generic_workspace_bytes": (C.c_size_t, [C.POINTER(NwsGenericModel), C.c_int, C.c_int]),
     "nws_forward_generic": (C.c_int, [C.POINTER(NwsGenericModel), _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp, _fp,
                                       C.POINTER(NwsReverbPlan), _fp, _fp, _fp, C.c_size_t, _fp, _fp, C.c_size_t, _fp]),
+    "nws_stream_state_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.POINTER(NwsReverbPlan)]),
+    "nws_stream_reset": (C.c_int, [_fp, C.c_size_t, _fp]),
+    "nws_stream_out_samples": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "nws_stream_noise_start": (C.c_longlong, [C.c_int, C.c_longlong]),
+    "nws_stream_noise_draws": (C.c_int, [C.c_int, C.c_int, C.c_longlong]),
+    "nws_stream_step": (C.c_int, [C.POINTER(NwsWeights), _fp, C.POINTER(NwsReverbPlan), _fp, _fp, _fp, C.c_size_t, C.c_int, C.c_int,
+                                  _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_float, _fp, _fp,
+                                  _fp, _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp]),
+    "nws_stream_reverb_tail": (C.c_int, [C.POINTER(NwsReverbPlan), _fp, _fp, _fp, C.c_size_t, C.c_int, C.c_int, C.c_int, _fp, _fp,
+                                         C.c_size_t, _fp]),
     "nws_profile_begin": (C.c_int, [C.c_int, C.c_uint]),
     "nws_profile_collect": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "nws_profile_end": (C.c_int, []),

@@ -14,7 +14,7 @@ OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libnws_hip.so")
 OPS_LIB = os.path.join(HERE, "libnws_torch_ops.so")     # torch.ops.newt_hip.* over the C-ABI (csrc/torch_ops.cpp)
 SOURCES = ["exciter_newt.hip", "control_gru.hip", "frame_mlps.hip", "fir_noise.hip", "reverb_fft.hip", "forward.hip",
-           "loudness.hip", "stages.hip", "generic.hip", "coexec_probe.hip"]
+           "loudness.hip", "stages.hip", "generic.hip", "stream.hip", "coexec_probe.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=default",
          "-Wall", "-Wno-unused-function", "-Wno-pass-failed", "-Rpass-analysis=kernel-resource-usage"]
 # -fno-slp-vectorize: the SLP vectoriser turns scalar fp32 code into packed instructions with operand swizzles of its own

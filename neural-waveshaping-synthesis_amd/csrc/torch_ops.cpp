@@ -723,6 +723,66 @@ Tensor g_reverb_direct(const Tensor& x, const Tensor& ir) {
   return y;
 }
 
+// ---- stateful streaming step (csrc/stream.hip): K new frames of B streams -> out (B, M); all state in `state` ----------
+void stream_step(const Tensor& wdesc, const Tensor& fir_design, const OptTensor& plan_t, const OptTensor& tables,
+                 const OptTensor& spectrum, Tensor& state, int64_t max_frames, const Tensor& f0, const Tensor& control, bool first,
+                 bool final, int64_t frames_seen, int64_t nz_prev_start, double sample_rate, const Tensor& phase_u,
+                 const Tensor& rand_phase, const OptTensor& noise_new, const OptTensor& noise_all, const Tensor& ir, Tensor& out,
+                 const OptTensor& pre_out) {
+  const NwsWeights* w = weights_of(wdesc);
+  check_dev(f0, "f0");
+  check_dev(control, "control");
+  check_dev(fir_design, "fir_design");
+  check_dev(state, "state", at::kByte);
+  check_dev(phase_u, "phase_u");
+  check_dev(rand_phase, "rand_phase");
+  check_dev(ir, "reverb.ir");
+  check_dev(out, "out");
+  check_same_device(f0, "f0", control, "control");
+  check_same_device(f0, "f0", state, "state");
+  check_same_device(f0, "f0", out, "out");
+  check_same_device(f0, "f0", ir, "reverb.ir");
+  TORCH_CHECK(f0.dim() == 2 && control.dim() == 3 && control.size(0) == f0.size(0) && control.size(2) == f0.size(1) && control.size(1) >= 2,
+              "stream_step: f0 (B, K), control (B, C>=2, K); got ", f0.sizes(), " / ", control.sizes());
+  const int64_t B = f0.size(0), K = f0.size(1), C = control.size(1);
+  TORCH_CHECK(K >= 1 && K <= max_frames, "stream_step: chunk of ", K, " frames, the stream was sized for ", max_frames);
+  TORCH_CHECK(phase_u.numel() == NWS_N_HARMONICS && rand_phase.numel() == NWS_N_HARMONICS, "phase_u / rand_phase: 101 elements each");
+  TORCH_CHECK(noise_new.has_value() != noise_all.has_value(), "stream_step: give exactly one of noise_new and noise_all");
+  const int M = nws_stream_out_samples((int)K, first, final);
+  TORCH_CHECK(out.numel() == B * M, "out: expected (", B, ", ", M, "), got ", out.sizes());
+  if (pre_out.has_value()) {
+    check_dev(*pre_out, "pre_out");
+    TORCH_CHECK(pre_out->numel() == B * M, "pre_out: expected (", B, ", ", M, ")");
+  }
+  if (noise_new.has_value()) {
+    check_dev(*noise_new, "noise_new");
+    TORCH_CHECK(noise_new->numel() >= nws_stream_noise_draws((int)K, first, frames_seen), "noise_new: expected ",
+                nws_stream_noise_draws((int)K, first, frames_seen), " fresh samples");
+  } else {
+    check_dev(*noise_all, "noise_all");
+  }
+  NwsReverbPlan plan{};
+  const bool fft = plan_t.has_value();
+  if (fft) {
+    TORCH_CHECK(tables.has_value() && spectrum.has_value(), "stream_step: plan without tables / spectrum");
+    plan = plan_of(*plan_t);
+    check_dev(*tables, "reverb_tables");
+    check_dev(*spectrum, "reverb_spectrum");
+    check_reverb_buffers(plan, *tables, *spectrum);
+  }
+  TORCH_CHECK((size_t)state.numel() >= nws_stream_state_bytes((int)B, (int)max_frames, (int)ir.numel(), fft ? &plan : nullptr),
+              "stream_step: state blob too small");
+  Launch L(f0);
+  nws_check(nws_stream_step(w, fir_design.data_ptr<float>(), fft ? &plan : nullptr, fft ? tables->data_ptr() : nullptr,
+                            fft ? spectrum->data_ptr() : nullptr, state.data_ptr(), (size_t)state.numel(), (int)B, (int)max_frames,
+                            f0.data_ptr<float>(), control.data_ptr<float>(), (int)C, (int)K, first ? 1 : 0, final ? 1 : 0,
+                            (long long)frames_seen, (long long)nz_prev_start, (float)sample_rate, phase_u.data_ptr<float>(),
+                            rand_phase.data_ptr<float>(), fptr(noise_new), fptr(noise_all),
+                            noise_all.has_value() ? (int)noise_all->numel() : 0, ir.data_ptr<float>(), (int)ir.numel(),
+                            out.data_ptr<float>(), pre_out.has_value() ? pre_out->data_ptr<float>() : nullptr, L.stream),
+            "nws_stream_step");
+}
+
 int64_t abi_version() { return nws_abi_version(); }
 
 }  // namespace
@@ -765,5 +825,9 @@ TORCH_LIBRARY(newt_hip, m) {
   m.def("g_newt_apply(Tensor sdesc, Tensor exciter, Tensor film, Tensor mix_w, Tensor mix_b) -> Tensor", &g_newt_apply);
   m.def("g_fir_noise(Tensor H, Tensor window, Tensor noise, int hop) -> Tensor", &g_fir_noise);
   m.def("g_reverb_direct(Tensor x, Tensor ir) -> Tensor", &g_reverb_direct);
+  m.def("stream_step(Tensor wdesc, Tensor fir_design, Tensor? plan, Tensor? reverb_tables, Tensor? reverb_spectrum, Tensor(a!) state, "
+        "int max_frames, Tensor f0, Tensor control, bool first, bool final, int frames_seen, int nz_prev_start, float sample_rate, "
+        "Tensor phase_u, Tensor rand_phase, Tensor? noise_new, Tensor? noise_all, Tensor ir, Tensor(b!) out, Tensor(c!)? pre_out) -> ()",
+        &stream_step);
   m.def("loudness(Tensor audio, Tensor dft, int n_fft, int hop, float amin, float top_db, bool normalise) -> Tensor", &loudness);
 }

@@ -235,11 +235,11 @@ def ensure_default_config():
         gin.parse_config_file(_DEFAULT_GIN)
 
 
-def _stream(self, batch_size: int = 1, *, phase_u=None, noise=None):
-    """Stateful streaming synthesiser bound to this model (see streaming.NewtStream)."""
+def _stream(self, batch_size: int = 1, *, phase_u=None, noise=None, **kw):
+    """Stateful streaming synthesiser bound to this model (see streaming.NewtStream; kw: max_chunk_frames, graph)."""
     from ..streaming import NewtStream
 
-    return NewtStream(self, batch_size, phase_u=phase_u, noise=noise)
+    return NewtStream(self, batch_size, phase_u=phase_u, noise=noise, **kw)
 
 
 NeuralWaveshaping.stream = _stream

@@ -1,74 +1,113 @@
-"""Stateful streaming synthesis on top of the one-shot HIP kernels.
+"""Stateful streaming synthesis: host side of csrc/stream.hip.
 
 The reference's buffer benchmark (scripts/time_buffer_sizes.py) is stateless: every buffer restarts the GRU, the
 oscillator phase and the reverb.  `NewtStream` carries that state so that the concatenation of the chunks it emits
 equals the reference's ONE-SHOT forward over the whole signal up to the reverb input (`pre_reverb`), and applies the
-learned reverb as a linear (overlap-add) convolution instead of the one-shot path's wrap-around.
+learned reverb as a linear convolution of the stream instead of the one-shot path's wrap-around.
 
-How the one-shot kernels are reused (no streaming-specific sample-rate kernels):
-  * control frames arrive in chunks of K frames; every kernel runs on a WINDOW = [last frame of the previous chunk] +
-    [K new frames].  The linear upsampling of F0 / FiLM parameters only looks one frame back and one ahead, so all
-    window samples except the first and last 64 are exactly the one-shot values; the stream therefore emits audio
-    64 samples (4 ms) behind the control frames it has seen (`push(..., final=True)` releases the remainder).
-  * GRU hidden state: carried (nws_control_gru_state).
-  * oscillator phase: the float64 prefix sum of the upsampled F0 is carried as one double per utterance and spliced
-    into the per-window carries, so `fl32(cumsum)` is bit-identical to the one-shot forward's.
-  * noise branch: frames are cut from one absolute noise stream (nws_fir_noise_window with origin 0); the branch runs
-    64 samples ahead of the NEWT branch, the surplus is kept as a residue for the next chunk.
-  * reverb: nws_reverb_linear_chunk with a 32000-sample tail per utterance.
-The phase offsets are drawn once per stream and the noise is drawn chunk by chunk from the device generator (or both
-are injected for parity testing), mirroring the reference's two hidden draws.
+One `push` = ONE C-ABI call (`nws_stream_step` / `torch.ops.newt_hip.stream_step`): eight launches of the one-shot kernels
+plus four small streaming kernels on a window = [last frame of the previous chunk] + [K new frames]; every piece of state
+(GRU h, previous frame, float64 phase sum, noise residue and window, reverb-input ring, position counters) lives in one
+device blob behind fixed pointers.  Nothing is computed by torch.  Because the pointers and launch arguments of a
+steady-state hop (same K as the previous push, not first, not final) never change, such hops are captured ONCE into a
+hipGraph and replayed (`graph=True`, the default): a 256-sample hop is then one graph launch.
+
+  * the stream emits audio 64 samples (4 ms) behind the control frames it has seen (linear upsampling looks one frame
+    ahead); `push(..., final=True)` releases the remainder exactly like the one-shot forward's right edge;
+  * the phase offsets are drawn once per stream and the noise chunk by chunk from the device generator (or both are
+    injected for parity testing), mirroring the reference's two hidden draws.
 """
 from __future__ import annotations
+
+import ctypes as C
 
 import torch
 
 from . import _lib
-from .engine import _req
+from .engine import _req, ops, stream_ptr
 
 HOP = _lib.HOP
-_MAX_CHUNK_FRAMES = 249   # (K+1) * 128 + 31999 <= 64000: one linear-reverb chunk
+_MAX_CHUNK_FRAMES = 249   # (K+1) * 128 + 31999 <= 64000: the FFT reverb of a long chunk fits the L = 64000 plan
+_GRAPH_AFTER = 2          # steady-state pushes of one K before that hop is captured
 
 
 class NewtStream:
-    def __init__(self, model, batch_size: int, phase_u: torch.Tensor | None = None, noise: torch.Tensor | None = None):
+    def __init__(self, model, batch_size: int, phase_u: torch.Tensor | None = None, noise: torch.Tensor | None = None,
+                 max_chunk_frames: int = _MAX_CHUNK_FRAMES, graph: bool = True):
+        if not model._engine.specialised():
+            raise RuntimeError("stateful streaming runs on the fused kernels: the model must have the architecture of "
+                               "gin/models/newt.gin")
         self.model = model
         self.eng = model._engine
         w, _, dev = self.eng.weights()
         self.dev = dev
         self.B = int(batch_size)
+        self.max_frames = int(min(max(1, max_chunk_frames), _MAX_CHUNK_FRAMES))
         self.phase_u = _req((phase_u if phase_u is not None else torch.rand_like(model.osc.rand_phase)).reshape(-1),
                             "phase_u", _lib.N_HARMONICS)
-        self._noise_fixed = noise is not None          # parity mode: the reference's whole draw is supplied up front
-        self._noise = _req(noise, "noise") if noise is not None else torch.empty(0, dtype=torch.float32, device=dev)
-        self._noise_base = 0                            # absolute index of self._noise[0]
-        self.h = torch.zeros((self.B, _lib.HIDDEN), dtype=torch.float32, device=dev)
-        self.prev = None                                # (f0 (B,1), film (B,1,256), fir (B,1,256)) of the last frame seen
-        self.S = torch.zeros((self.B, 1), dtype=torch.float64, device=dev)   # fp64 phase sum through the last emitted sample
-        self.noise_residue = torch.zeros((self.B, 0), dtype=torch.float32, device=dev)
+        self._noise_all = _req(noise, "noise") if noise is not None else None    # parity mode: the reference's whole draw
         self.frames_seen = 0
         self.samples_emitted = 0
         self.finished = False
-        ir = self.eng.ir()
-        self.tail_len = ir.numel() + 1
-        self._rv_aux = self.eng.reverb_aux(2 * self.tail_len)   # L = 64000 >= chunk + 32000 - 1
-        self.plan = self._rv_aux[0]
-        self.tails = [torch.zeros((self.B, self.tail_len), dtype=torch.float32, device=dev) for _ in range(2)]
-        self._tail_idx = 0
+        self._nz_prev_start = 0
+        self._ir_len = int(self.eng.ir().numel())
+        self.tail_len = self._ir_len + 1
+        self._need_fft = HOP * (self.max_frames + 1) > 2048
+        L = _lib.lib()
+        plan = self.eng.reverb_aux(2 * self.tail_len)[0] if self._need_fft else None
+        nbytes = L.nws_stream_state_bytes(self.B, self.max_frames, self._ir_len, C.byref(plan) if plan is not None else None)
+        with torch.cuda.device(dev):
+            self._state = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(L.nws_stream_reset(self._state.data_ptr(), nbytes, stream_ptr(dev)), "nws_stream_reset")
+        self._use_graph = bool(graph)
+        self._graphs = {}          # K -> (graph, f0_in, control_in, noise_new, out, pre)
+        self._steady_runs = {}     # K -> consecutive steady-state pushes seen
+        self._last_K = None
+        self._last_pre = None
 
-    # ---- noise stream ---------------------------------------------------------------------------------------------
-    def _noise_view(self, start: int, upto: int):
-        """View of the absolute noise stream beginning at `start`, guaranteed to hold indices < upto (unless fixed)."""
-        if not self._noise_fixed:
-            have = self._noise_base + self._noise.numel()
-            if upto > have:
-                extra = torch.rand(max(upto - have, 4096), device=self.dev)
-                self._noise = torch.cat((self._noise, extra))
-            drop = start - self._noise_base - 1024                      # forget what no future window can reach
-            if drop > 65536:
-                self._noise = self._noise[drop:].contiguous()
-                self._noise_base += drop
-        return self._noise[start - self._noise_base:]
+    # ---- one C-ABI call ---------------------------------------------------------------------------------------------
+    def _step(self, f0_2d, control, first, final, noise_new, out, pre):
+        eng = self.eng
+        w, keep, dev, wdesc = eng._wd()
+        B, K = f0_2d.shape
+        fft = self._need_fft
+        plan, tables, spec, plan_t = eng._reverb_aux(2 * self.tail_len) if fft else (None, None, None, None)
+        sr = float(self.model.sample_rate)
+        rp, ir = keep[-2], keep[-1]
+        o = ops()
+        if o is not None:
+            o.stream_step(wdesc, eng._fir_design, plan_t, tables, spec, self._state, self.max_frames, f0_2d, control, bool(first),
+                          bool(final), int(self.frames_seen), int(self._nz_prev_start), sr, self.phase_u, rp, noise_new,
+                          self._noise_all, ir.reshape(-1), out, pre)
+            return
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().nws_stream_step(
+                C.byref(w), eng._fir_design.data_ptr(), C.byref(plan) if fft else None, tables.data_ptr() if fft else None,
+                spec.data_ptr() if fft else None, self._state.data_ptr(), self._state.numel(), B, self.max_frames,
+                f0_2d.data_ptr(), control.data_ptr(), control.shape[1], K, int(first), int(final), int(self.frames_seen),
+                int(self._nz_prev_start), sr, self.phase_u.data_ptr(), rp.data_ptr(),
+                noise_new.data_ptr() if noise_new is not None else None,
+                self._noise_all.data_ptr() if self._noise_all is not None else None,
+                self._noise_all.numel() if self._noise_all is not None else 0, ir.data_ptr(), ir.numel(), out.data_ptr(),
+                pre.data_ptr() if pre is not None else None, stream_ptr(dev)), "nws_stream_step")
+
+    def _capture(self, K, C_in):
+        """hipGraph of one steady-state hop of K frames: static input / output buffers, the fresh noise draws inside."""
+        dev = self.dev
+        with torch.cuda.device(dev):
+            f0_in = torch.zeros((self.B, K), dtype=torch.float32, device=dev)
+            c_in = torch.zeros((self.B, C_in, K), dtype=torch.float32, device=dev)
+            nz = torch.empty(HOP * K, dtype=torch.float32, device=dev) if self._noise_all is None else None
+            out = torch.empty((self.B, HOP * K), dtype=torch.float32, device=dev)
+            pre = torch.empty((self.B, HOP * K), dtype=torch.float32, device=dev)
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize(dev)
+            with torch.cuda.graph(g):
+                if nz is not None:
+                    nz.uniform_()                                  # the reference's torch.rand draw, chunk by chunk
+                self._step(f0_in, c_in, False, False, nz, out, pre)
+        # capture records, it does not run: the state has not advanced
+        return g, f0_in, c_in, nz, out, pre
 
     # ---- one chunk ----------------------------------------------------------------------------------------------------
     def push(self, f0: torch.Tensor, control: torch.Tensor, final: bool = False) -> torch.Tensor:
@@ -83,80 +122,89 @@ class NewtStream:
             raise RuntimeError(f"expected f0 ({self.B},1,K) and control ({self.B},C>=2,K)")
         if K < 1:
             raise RuntimeError("empty chunk")
-        if K > _MAX_CHUNK_FRAMES:                       # long chunks: process in pieces (state makes that exact)
+        if K > self.max_frames:                          # long chunks: process in pieces (state makes that exact)
             outs = []
-            for k0 in range(0, K, _MAX_CHUNK_FRAMES):
-                k1 = min(K, k0 + _MAX_CHUNK_FRAMES)
+            for k0 in range(0, K, self.max_frames):
+                k1 = min(K, k0 + self.max_frames)
                 outs.append(self.push(f0[:, :, k0:k1], control[:, :, k0:k1], final and k1 == K))
             return torch.cat(outs, dim=1)
-        eng = self.eng
-        first = self.prev is None
-
-        # 1. control path on the K new frames (GRU state carried)
-        gru, self.h = eng.control_gru(control, h0=self.h, return_state=True)
-        _, film, _, fir = eng.frame_mlps(gru)
-
-        # 2. window = [previous frame] + new frames
-        f0_new = f0[:, 0, :]
-        if first:
-            f0_w, film_w, fir_w = f0_new.contiguous(), film, fir
-        else:
-            f0_w = torch.cat((self.prev[0], f0_new), dim=1).contiguous()
-            film_w = torch.cat((self.prev[1], film), dim=1).contiguous()
-            fir_w = torch.cat((self.prev[2], fir), dim=1).contiguous()
-        Tw = f0_w.shape[1]
-        lo = 0 if first else 64
-        hi = HOP * Tw if final else HOP * Tw - 64
-
-        # 3. exciter + waveshapers on the window, with the carried fp64 phase sum spliced into the chunk carries
-        carry = eng.phase_carry(f0=f0_w)                               # (B, 4 Tw) exclusive prefix sums, float64
-        if not first:
-            carry = self.S + (carry - carry[:, 2:3])                   # exact: sums of fp32 values in fp64
-        # the kernel's lerp clamps to the window edges; those samples are only kept at the true stream edges
-        _, newt = eng.exciter_newt(f0_w, None, carry.contiguous(), self.phase_u, film_w)
-        new_S = None if final else carry[:, (hi // 32):(hi // 32) + 1].clone()
-        newt_emit = newt[:, lo:hi]
-
-        # 4. noise branch on the same window, from the absolute noise stream
-        A0 = self.frames_seen - (0 if first else 1)                   # absolute index of the window's first frame
-        if A0 == 0:
-            start, origin = 0, HOP            # frame 0 reaches 128 samples before the stream: reflect like torch.stft
-        else:
-            start, origin = HOP * A0 - HOP, 0
-        need_upto = HOP * (A0 + Tw - 1) + HOP + 1
-        nview = self._noise_view(start, need_upto)
-        if final and self._noise_fixed:
-            n_len = (HOP * (A0 + Tw) - 1) - start                    # the one-shot draw has N-1 samples: reflect at its end
-        elif final:
-            n_len = (HOP * (A0 + Tw) - 1) - start
-            nview = self._noise_view(start, start + n_len)
-        else:
-            n_len = nview.numel()
-        if n_len > nview.numel():
-            raise RuntimeError("injected noise vector is shorter than the stream (needs 128*frames - 1 samples)")
-        noise_w = eng.fir_noise(fir_w, nview, origin=origin, noise_len=int(n_len))
-        noise_new = noise_w if first else noise_w[:, HOP:]             # local hop 0 of a non-first window is not ours
-        noise_all = torch.cat((self.noise_residue, noise_new), dim=1)
-        cnt = hi - lo
-        pre = (newt_emit + noise_all[:, :cnt]).contiguous()
-        self.noise_residue = noise_all[:, cnt:].contiguous()
-
-        # 5. linear reverb with carried tail
-        # (fetched per push: cached by the engine per weights version, so an in-place update of reverb.ir is picked up)
-        self._rv_aux = eng.reverb_aux(2 * self.tail_len)
-        y, self.tails[self._tail_idx ^ 1] = eng.reverb_linear_chunk(self._rv_aux, pre, self.tails[self._tail_idx])
-        self._tail_idx ^= 1
-
-        # 6. state for the next chunk
-        self.prev = (f0_new[:, -1:].contiguous(), film[:, -1:, :].contiguous(), fir[:, -1:, :].contiguous())
-        if new_S is not None:
-            self.S = new_S
-        self.frames_seen += K
-        self.samples_emitted += cnt
-        self.finished = final
+        first = self.frames_seen == 0
+        L = _lib.lib()
+        M = L.nws_stream_out_samples(K, int(first), int(final))
+        if M <= 0:
+            raise RuntimeError("a first chunk of one frame that is also not final emits 64 samples; nothing smaller exists")
+        steady = (not first) and (not final) and self._last_K == K and self.frames_seen >= K + 2
+        f0_2d = f0[:, 0, :]
+        if steady and self._use_graph:
+            hit = self._graphs.get((K, control.shape[1]))
+            runs = self._steady_runs.get(K, 0) + 1
+            self._steady_runs[K] = runs
+            if hit is None and runs > _GRAPH_AFTER and not torch.cuda.is_current_stream_capturing():
+                try:
+                    hit = self._graphs[(K, control.shape[1])] = self._capture(K, control.shape[1])
+                except Exception:          # capture not possible here (e.g. foreign capture in progress): stay eager
+                    self._use_graph = False
+                    hit = None
+            if hit is not None:
+                g, f0_in, c_in, _, out, pre = hit
+                f0_in.copy_(f0_2d)
+                c_in.copy_(control)
+                g.replay()
+                self._advance(K, M, first, final)
+                self._last_pre = pre
+                return out.clone()
+        with torch.cuda.device(self.dev):
+            out = torch.empty((B, M), dtype=torch.float32, device=self.dev)
+            pre = torch.empty((B, M), dtype=torch.float32, device=self.dev)
+            nz = None
+            if self._noise_all is None:
+                nz = torch.rand(L.nws_stream_noise_draws(K, int(first), self.frames_seen), device=self.dev)   # RNG draw #2, chunk-wise
+            self._step(f0_2d.contiguous(), control, first, final, nz, out, pre)
+        self._advance(K, M, first, final)
         self._last_pre = pre
-        return y
+        return out
+
+    # ---- zero-copy hops: the caller writes into the captured hop's own input buffers and reads its output buffer ----------
+    def static_io(self, K: int, channels: int = 2):
+        """(f0_in (B, K), control_in (B, channels, K), out (B, 128 K)) of the captured steady-state hop of K frames - the
+        buffers `hop()` consumes and fills, for callers that produce control frames in place (an audio callback): no input
+        copies, no output copy.  Needs the stream in steady state for this K (two pushes of K frames behind it)."""
+        if not (self.frames_seen >= K + 2 and self._last_K == K and not self.finished):
+            raise RuntimeError(f"static_io({K}): push at least two chunks of {K} frames first (the captured hop is the steady-state one)")
+        hit = self._graphs.get((K, channels))
+        if hit is None:
+            hit = self._graphs[(K, channels)] = self._capture(K, channels)
+        return hit[1], hit[2], hit[4]
+
+    def hop(self, K: int, channels: int = 2) -> torch.Tensor:
+        """Replay the captured hop on whatever the caller left in static_io(K)'s input buffers; returns the static output
+        buffer (overwritten by the next hop)."""
+        hit = self._graphs.get((K, channels))
+        if hit is None or self._last_K != K or self.finished:
+            raise RuntimeError("hop(): call static_io(K) first, and do not interleave other chunk sizes")
+        hit[0].replay()
+        self._advance(K, HOP * K, False, False)
+        self._last_pre = hit[5]
+        return hit[4]
+
+    def _advance(self, K, M, first, final):
+        self._nz_prev_start = int(_lib.lib().nws_stream_noise_start(int(first), self.frames_seen))
+        self.frames_seen += K
+        self.samples_emitted += M
+        self._last_K = K
+        self.finished = bool(final)
 
     def reverb_tail(self) -> torch.Tensor:
         """The remaining (B, 32000) reverb tail after the last chunk (what a linear reverb still rings out)."""
-        return self.tails[self._tail_idx].clone()
+        eng = self.eng
+        eng._wd()
+        plan, tables, spec, _ = eng._reverb_aux(2 * self.tail_len)
+        L = _lib.lib()
+        with torch.cuda.device(self.dev):
+            tail = torch.empty((self.B, self.tail_len), dtype=torch.float32, device=self.dev)
+            nb = 2 * ((self.B * (2 * self._ir_len + 1) * 4 + 255) // 256 * 256) + L.nws_reverb_workspace_bytes(C.byref(plan), self.B)
+            ws = torch.empty(nb, dtype=torch.uint8, device=self.dev)
+            _lib.check(L.nws_stream_reverb_tail(C.byref(plan), tables.data_ptr(), spec.data_ptr(), self._state.data_ptr(),
+                                                self._state.numel(), self.B, self.max_frames, self._ir_len, tail.data_ptr(),
+                                                ws.data_ptr(), nb, stream_ptr(self.dev)), "nws_stream_reverb_tail")
+        return tail

@@ -72,3 +72,38 @@ def test_stream_self_drawn_noise_and_long_chunks(setup):
     assert abs(float(a.std()) - float(b.std())) <= 0.05 * float(a.std())
     with pytest.raises(RuntimeError):
         s1.push(f0[:, :, :4], control[:, :, :4])
+
+
+def test_captured_hop_with_static_io_equals_push(setup):
+    """Steady-state hops replay a hipGraph; `static_io` / `hop` expose the captured hop's own buffers (no copies).  Same
+    stream contents as eager pushes, bit for bit (same kernels, same launch arguments), for injected and for drawn noise."""
+    model, _, _ = setup
+    B, K, n = 2, 2, 12
+    g = torch.Generator().manual_seed(9)
+    f0 = (150 + 300 * torch.rand(B, 1, 1, generator=g)) * (1 + 0.02 * torch.randn(B, 1, K * n, generator=g))
+    control = torch.randn(B, 2, K * n, generator=g)
+    pu, nz = torch.rand(101, generator=g), torch.rand(128 * K * n - 1, generator=g)
+    chunks = [(f0[:, :, i * K:(i + 1) * K].cuda(), control[:, :, i * K:(i + 1) * K].cuda()) for i in range(n)]
+    eager = model.stream(B, phase_u=pu.cuda(), noise=nz.cuda(), graph=False)
+    ref = [eager.push(a, c, final=(i == n - 1)) for i, (a, c) in enumerate(chunks)]
+    s = model.stream(B, phase_u=pu.cuda(), noise=nz.cuda())
+    got = []
+    for i, (a, c) in enumerate(chunks):
+        if 4 <= i < n - 1:
+            f0_in, c_in, out = s.static_io(K)
+            f0_in.copy_(a[:, 0])
+            c_in.copy_(c)
+            got.append(s.hop(K).clone())
+        else:
+            got.append(s.push(a, c, final=(i == n - 1)))
+    assert s._graphs, "the steady-state hop was never captured"
+    for i, (x, y) in enumerate(zip(got, ref)):
+        assert torch.equal(x, y), i
+    assert s.samples_emitted == eager.samples_emitted == 128 * K * n
+    # drawn noise: the graph carries the draws; same seed -> same stream as eager pushes drawing chunk by chunk
+    outs = []
+    for use_graph in (False, True):
+        torch.manual_seed(11)
+        st = model.stream(B, graph=use_graph)
+        outs.append(torch.cat([st.push(a, c) for a, c in chunks[:8]], dim=1))
+    assert torch.isfinite(outs[1]).all() and abs(float(outs[0].std()) - float(outs[1].std())) <= 0.05 * float(outs[0].std())
