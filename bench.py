@@ -76,6 +76,9 @@ def parse():
                     help="N > 1: how the rendered waveforms are all-gathered: rccl = all_gather_into_tensor (RCCL kernels on the "
                          "CUs); copy = every rank pushes its shard into every peer's buffer with device-to-device copies on "
                          "peer-mapped memory (copy engines over xGMI, no collective kernels; parallel.PeerCopyAllGather)")
+    ap.add_argument("--gather-chunks", type=int, default=1,
+                    help="N > 1: push the rendered waveforms in this many sub-batches (4 = 4 x 16 utterances), each as soon as ITS "
+                         "reverb has been enqueued, instead of one all-gather after the whole batch (SURVEY 8(e))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="time budget of the cpu_baseline leg")
     ap.add_argument("--batch1-iters", type=int, default=200)
@@ -455,8 +458,28 @@ def main():
     elif distributed:
         full = [torch.empty((B * world, N), dtype=torch.float32, device=dev) for _ in range(nbuf)]
 
+    class _Works:      # several collectives of one step behind the single handle the loop carries
+        def __init__(self, works):
+            self.works = [w for w in works if w is not None]
+
+        def wait(self):
+            for w in self.works:
+                w.wait()
+
+    blocks = pmod.ForwardPipeline.row_blocks(B, a.gather_chunks) if (distributed and use_pipe) else None
+
+    def gather_rows(i, y, row0, n):
+        """rows [row0, row0 + n) of this step's waveforms to every rank, on the CURRENT stream"""
+        if peer is not None:
+            peer.push_rows(y, i % nbuf, row0, n)
+            return None
+        return dist.all_gather([full[i % nbuf][r * B + row0:r * B + row0 + n] for r in range(world)], y[row0:row0 + n], async_op=True)
+
     def gather(i, y):
         """all-gather of this step's waveforms on the CURRENT stream; returns a work handle (or None)"""
+        if blocks is not None:      # (compute skipped: the same sub-batch messages, back to back)
+            works = [gather_rows(i, y, r0, n) for r0, n in blocks]
+            return peer.finish(i % nbuf)[1] if peer is not None else _Works(works)
         if peer is not None:
             return peer.gather(y, i % nbuf)[1]
         return dist.all_gather_into_tensor(full[i % nbuf], y, async_op=True)
@@ -472,6 +495,19 @@ def main():
             if do_compute:
                 with torch.cuda.stream(au):             # draws where they are consumed: nothing ever runs on the null stream
                     pu, nz = par.shared_draws(101, N - 1, dev, generator=shared_gen)   # identical on all ranks
+                if blocks is not None and do_gather:
+                    # sub-batch exchange: block q leaves for the peers as soon as ITS reverb is enqueued (on the audio stream,
+                    # inside submit), under the reverb of block q + 1; the previous step's exchange is waited for first
+                    works = []
+
+                    def on_block(row0, n, out, _i=i, _works=works, _pending=pending):
+                        if row0 == blocks[0][0] and _pending is not None:
+                            _pending.wait()
+                        _works.append(gather_rows(_i, out, row0, n))
+
+                    pipe.submit(f0, control, phase_u=pu, noise=nz, row_blocks=blocks, on_block=on_block)
+                    with torch.cuda.stream(au):
+                        return peer.finish(i % nbuf)[1] if peer is not None else _Works(works)
                 y = pipe.submit(f0, control, phase_u=pu, noise=nz)
             with torch.cuda.stream(au):                 # ordered after this batch's reverb
                 if pending is not None:
@@ -560,7 +596,10 @@ def main():
             k2 = max(10, min(a.steps, 100))
             g_el, g_ranks = timed(k2, do_compute=False)
             c_el, c_ranks = timed(k2, do_gather=False)
-            extra["exchange"] = {"kind": gather_kind, "gather_ms": g_el / k2 * 1e3, "compute_only_ms": c_el / k2 * 1e3,
+            extra["exchange"] = {"kind": gather_kind, "chunks": len(blocks) if blocks else 1,
+                                 # 1.0 = the exchange is completely hidden under the compute of the neighbouring steps
+                                 "overlap_efficiency": (c_el / k2) / (elapsed / a.steps),
+                                 "gather_ms": g_el / k2 * 1e3, "compute_only_ms": c_el / k2 * 1e3,
                                  "steps": k2, "bytes_gathered_per_rank_per_step": B * world * N * 4,
                                  "gather_ms_per_rank": [round(t / k2 * 1e3, 4) for t in g_ranks],
                                  "compute_only_ms_per_rank": [round(t / k2 * 1e3, 4) for t in c_ranks]}
@@ -575,6 +614,19 @@ def main():
             ys, pend = [], None
             for i, (pu_c, nz_c) in enumerate(draws):
                 au = pipe.next_audio_stream()
+                if distributed and blocks is not None:
+                    works = []
+
+                    def on_block_c(row0, n, out, _i=i, _works=works, _pend=pend):
+                        if row0 == blocks[0][0] and _pend is not None:
+                            _pend.wait()
+                        _works.append(gather_rows(_i, out, row0, n))
+
+                    y = pipe.submit(f0, control, phase_u=pu_c, noise=nz_c, row_blocks=blocks, on_block=on_block_c)
+                    ys.append(y)
+                    with torch.cuda.stream(au):
+                        pend = peer.finish(i % nbuf)[1] if peer is not None else _Works(works)
+                    continue
                 y = pipe.submit(f0, control, phase_u=pu_c, noise=nz_c)
                 ys.append(y)
                 if distributed:

@@ -342,6 +342,16 @@ int nws_forward_audio_ev(const NwsWeights* w, const NwsForwardAux* aux, const fl
                          const float* phase_u, const float* rand_phase, const float* noise, float* out, void* workspace,
                          size_t workspace_bytes, void* stream, void* wait_before_exciter, void* record_after_exciter);
 
+/* The audio half in two parts for multi-GPU callers that push sub-batches of finished waveforms to their peers while the
+ * reverb of the next sub-batch still runs: nws_forward_audio_pre = everything up to the reverb input of the
+ * whole batch (kept in the workspace), nws_forward_reverb_rows = the reverb of rows [row0, row0 + nrows) (row0 even) into the
+ * same rows of out (B, N).  pre + reverb_rows over all rows == nws_forward_audio, bit for bit. */
+int nws_forward_audio_pre(const NwsWeights* w, const NwsForwardAux* aux, const float* f0, int B, int T, float sample_rate,
+                          const float* phase_u, const float* rand_phase, const float* noise, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int nws_forward_reverb_rows(const NwsForwardAux* aux, int B, int T, int row0, int nrows, float* out, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 /*
  * Perceptual-loudness feature, the step before the synthesis path:
  * neural_waveshaping_synthesis/data/utils/loudness_extraction.py:10-67 (extract_perceptual_loudness) with the shipped

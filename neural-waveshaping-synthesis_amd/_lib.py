@@ -123,6 +123,9 @@ _PROTOTYPES = {
                                     _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
     "nws_forward_audio_ev": (C.c_int, [C.POINTER(NwsWeights), C.POINTER(NwsForwardAux), _fp, C.c_int, C.c_int, C.c_float,
                                        _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp, _fp, _fp]),
+    "nws_forward_audio_pre": (C.c_int, [C.POINTER(NwsWeights), C.POINTER(NwsForwardAux), _fp, C.c_int, C.c_int, C.c_float,
+                                        _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
+    "nws_forward_reverb_rows": (C.c_int, [C.POINTER(NwsForwardAux), C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_size_t, _fp]),
     "nws_loudness_dft_bytes": (C.c_size_t, [C.c_int]),
     "nws_loudness_dft_matrix": (C.c_int, [C.c_int, _fp, _fp]),
     "nws_loudness_frames": (C.c_int, [C.c_int, C.c_int]),

@@ -118,7 +118,7 @@ int control_half(const NwsWeights* w, const float* f0, const float* control, int
 
 int audio_half(const NwsWeights* w, const NwsForwardAux* aux, const float* f0, int B, int T, float sample_rate,
                const float* phase_u, const float* rand_phase, const float* noise, float* out, const Arena& a, void* stream,
-               void* wait_before_exciter = nullptr, void* record_after_exciter = nullptr) {
+               void* wait_before_exciter = nullptr, void* record_after_exciter = nullptr, bool with_reverb = true) {
   hipStream_t st = (hipStream_t)stream;
   int rc = NWS_OK;
   const size_t N = (size_t)T * NWS_HOP;
@@ -133,7 +133,8 @@ int audio_half(const NwsWeights* w, const NwsForwardAux* aux, const float* f0, i
     if (e != hipSuccess) return (int)e;
   }
   NWS_STAGE(4, nws_fir_noise(a.fir, noise, a.newt_out, B, T, a.pre, stream));
-  NWS_STAGE(5, nws_reverb(aux->plan, aux->reverb_tables, aux->reverb_spectrum, a.pre, B, (int)N, out, a.rv_ws, a.rv_bytes, stream));
+  if (with_reverb)
+    NWS_STAGE(5, nws_reverb(aux->plan, aux->reverb_tables, aux->reverb_spectrum, a.pre, B, (int)N, out, a.rv_ws, a.rv_bytes, stream));
   if (g_prof.ev != nullptr && g_prof.used < g_prof.slots) ++g_prof.used;
   return NWS_OK;
 }
@@ -211,6 +212,37 @@ int nws_forward_audio_ev(const NwsWeights* w, const NwsForwardAux* aux, const fl
   if (!a.ok) return NWS_ERR_WORKSPACE;
   return audio_half(w, aux, f0, B, T, sample_rate, phase_u, rand_phase, noise, out, a, stream, wait_before_exciter,
                     record_after_exciter);
+}
+
+// The audio half in two parts, so that a multi-GPU caller can push sub-batches of finished waveforms to its peers while the
+// reverb of the next sub-batch still runs ("gather sub-batches as they finish"): everything up to the reverb
+// input for the whole batch, then the reverb of rows [row0, row0 + nrows) into the same rows of `out`.
+int nws_forward_audio_pre(const NwsWeights* w, const NwsForwardAux* aux, const float* f0, int B, int T, float sample_rate,
+                          const float* phase_u, const float* rand_phase, const float* noise, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  if (!w || !aux_ok(aux)) return NWS_ERR_BAD_ARG;
+  if (!f0 || !phase_u || !rand_phase || !noise || !workspace) return NWS_ERR_BAD_ARG;
+  if (B <= 0 || T < 2) return NWS_ERR_BAD_ARG;
+  if ((long long)T * NWS_HOP > aux->plan->L) return NWS_ERR_BAD_ARG;
+  const Arena a = carve_arena(aux->plan, workspace, workspace_bytes, B, T, false);
+  if (!a.ok) return NWS_ERR_WORKSPACE;
+  return audio_half(w, aux, f0, B, T, sample_rate, phase_u, rand_phase, noise, nullptr, a, stream, nullptr, nullptr, false);
+}
+
+int nws_forward_reverb_rows(const NwsForwardAux* aux, int B, int T, int row0, int nrows, float* out /* (B, N): rows written */,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  if (!aux_ok(aux) || !out || !workspace || B <= 0 || T < 2 || row0 < 0 || nrows <= 0 || row0 + nrows > B) return NWS_ERR_BAD_ARG;
+  const Arena a = carve_arena(aux->plan, workspace, workspace_bytes, B, T, false);
+  if (!a.ok) return NWS_ERR_WORKSPACE;
+  const size_t N = (size_t)T * NWS_HOP;
+  // the transform scratch of the whole batch is partitioned by rows (two utterances share one complex transform), so the
+  // sub-batches of one forward may be in flight together as long as their rows are disjoint and row0 is even
+  if (row0 & 1) return NWS_ERR_BAD_ARG;
+  const size_t per_pair = 2 * (size_t)aux->plan->L * sizeof(float);
+  char* rv = static_cast<char*>(a.rv_ws) + (size_t)(row0 / 2) * per_pair;
+  const size_t left = a.rv_bytes - (size_t)(row0 / 2) * per_pair;
+  return nws_reverb(aux->plan, aux->reverb_tables, aux->reverb_spectrum, a.pre + (size_t)row0 * N, nrows, (int)N, out + (size_t)row0 * N, rv,
+                    left, stream);
 }
 
 int nws_profile_begin(int slots, unsigned stage_mask) {

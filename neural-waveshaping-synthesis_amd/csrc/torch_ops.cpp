@@ -181,6 +181,37 @@ Tensor forward_audio(const Tensor& wdesc, const Tensor& f0, const Tensor& phase_
   return out;
 }
 
+// the audio half in two parts (sub-batch gathers): up to the reverb input; then the reverb of a block of rows
+void forward_audio_pre(const Tensor& wdesc, const Tensor& f0, const Tensor& phase_u, const Tensor& rand_phase, const Tensor& noise,
+                       const Tensor& fir_design, const Tensor& plan, const Tensor& reverb_tables, const Tensor& reverb_spectrum,
+                       Tensor& workspace, double sample_rate) {
+  const NwsWeights* w = weights_of(wdesc);
+  check_dev(f0, "f0");
+  TORCH_CHECK(f0.dim() == 3 && f0.size(1) == 1 && f0.size(2) >= 2, "f0: expected (B, 1, T>=2), got ", f0.sizes());
+  const int64_t B = f0.size(0), T = f0.size(2);
+  check_draws(phase_u, rand_phase, noise, T, f0);
+  check_dev(workspace, "workspace", at::kByte);
+  check_same_device(f0, "f0", workspace, "workspace");
+  Aux a(fir_design, plan, reverb_tables, reverb_spectrum);
+  Launch L(f0);
+  nws_check(nws_forward_audio_pre(w, &a.aux, f0.data_ptr<float>(), (int)B, (int)T, (float)sample_rate, phase_u.data_ptr<float>(),
+                                  rand_phase.data_ptr<float>(), noise.data_ptr<float>(), workspace.data_ptr(),
+                                  (size_t)workspace.numel(), L.stream), "nws_forward_audio_pre");
+}
+
+void forward_reverb_rows(const Tensor& fir_design, const Tensor& plan, const Tensor& reverb_tables, const Tensor& reverb_spectrum,
+                         Tensor& workspace, int64_t T, int64_t row0, int64_t nrows, Tensor& out) {
+  check_dev(workspace, "workspace", at::kByte);
+  check_dev(out, "out");
+  check_same_device(out, "out", workspace, "workspace");
+  TORCH_CHECK(out.dim() == 2 && out.size(1) == T * NWS_HOP, "out: expected (B, ", T * NWS_HOP, "), got ", out.sizes());
+  TORCH_CHECK(row0 >= 0 && nrows > 0 && row0 + nrows <= out.size(0) && (row0 & 1) == 0, "forward_reverb_rows: bad row block");
+  Aux a(fir_design, plan, reverb_tables, reverb_spectrum);
+  Launch L(out);
+  nws_check(nws_forward_reverb_rows(&a.aux, (int)out.size(0), (int)T, (int)row0, (int)nrows, out.data_ptr<float>(), workspace.data_ptr(),
+                                    (size_t)workspace.numel(), L.stream), "nws_forward_reverb_rows");
+}
+
 // ---- stages ------------------------------------------------------------------------------------------------------------
 // exclusive fp64 prefix sums at 32-sample granularity (torch.cumsum of generators.py:59): f0 (B, T) frames or f0_up (B, 128 T)
 Tensor phase_carry(const OptTensor& f0, const OptTensor& f0_up) {
@@ -795,6 +826,10 @@ TORCH_LIBRARY(newt_hip, m) {
   m.def("forward_audio(Tensor wdesc, Tensor f0, Tensor phase_u, Tensor rand_phase, Tensor noise, Tensor fir_design, Tensor plan, "
         "Tensor reverb_tables, Tensor reverb_spectrum, Tensor(a!) workspace, float sample_rate, Tensor? out, int wait_event, "
         "int record_event) -> Tensor", &forward_audio);
+  m.def("forward_audio_pre(Tensor wdesc, Tensor f0, Tensor phase_u, Tensor rand_phase, Tensor noise, Tensor fir_design, Tensor plan, "
+        "Tensor reverb_tables, Tensor reverb_spectrum, Tensor(a!) workspace, float sample_rate) -> ()", &forward_audio_pre);
+  m.def("forward_reverb_rows(Tensor fir_design, Tensor plan, Tensor reverb_tables, Tensor reverb_spectrum, Tensor(a!) workspace, int T, "
+        "int row0, int nrows, Tensor(b!) out) -> ()", &forward_reverb_rows);
   m.def("phase_carry(Tensor? f0, Tensor? f0_up) -> Tensor", &phase_carry);
   m.def("exciter_newt(Tensor wdesc, Tensor? f0, Tensor? f0_up, Tensor carry, Tensor phase_u, Tensor rand_phase, Tensor? film, "
         "float sample_rate, bool want_exciter, bool want_newt) -> (Tensor, Tensor)", &exciter_newt);

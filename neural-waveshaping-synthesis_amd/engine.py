@@ -600,15 +600,43 @@ class Engine:
             check(_lib.lib().nws_forward_control(C.byref(w), ptr(f0), ptr(control), B, Cc, T, 1 if batched_gru else 0, ptr(ws),
                                                  ws.numel(), stream_ptr(dev)), "nws_forward_control")
 
-    def forward_audio(self, f0, B, T, phase_u, noise, ws, out=None, wait_event=None, record_event=None):
+    def forward_audio(self, f0, B, T, phase_u, noise, ws, out=None, wait_event=None, record_event=None, row_blocks=None,
+                      on_block=None):
         """frame MLPs .. reverb from the head of `ws` (forward_control must have completed in stream order / by event).
-        wait_event / record_event: torch.cuda.Event hooks right before / after the oscillator kernel (nws_forward_audio_ev)"""
+        wait_event / record_event: torch.cuda.Event hooks right before / after the oscillator kernel (nws_forward_audio_ev).
+        row_blocks = [(row0, nrows), ...] (even row0, nrows >= 4): the reverb runs block by block and `on_block(row0, nrows,
+        out)` is called after each block has been enqueued - a multi-GPU caller pushes that sub-batch to its peers while the
+        next block's reverb runs.  Same bits as the single call."""
         w, _, dev, wdesc = self._wd()
         same_device(dev, f0=f0, phase_u=phase_u, noise=noise, workspace=ws, out=out)
         N = T * _lib.HOP
         plan, tables, spec, plan_t = self._reverb_aux(N)
         sr = float(self._model_ref.sample_rate)
         o = ops()
+        if row_blocks is not None and len(row_blocks) > 1:
+            with torch.cuda.device(dev):
+                if out is None:
+                    out = torch.empty((B, N), dtype=torch.float32, device=dev)
+                aux = None
+                if o is not None:
+                    o.forward_audio_pre(wdesc, f0, phase_u, self._w[1][-2], noise, self._fir_design, plan_t, tables, spec, ws, sr)
+                else:
+                    aux = NwsForwardAux()
+                    aux.fir_design = ptr(self._fir_design)
+                    aux.plan = C.pointer(plan)
+                    aux.reverb_tables = ptr(tables)
+                    aux.reverb_spectrum = ptr(spec)
+                    check(_lib.lib().nws_forward_audio_pre(C.byref(w), C.byref(aux), ptr(f0), B, T, sr, ptr(phase_u), ptr(self._w[1][-2]),
+                                                           ptr(noise), ptr(ws), ws.numel(), stream_ptr(dev)), "nws_forward_audio_pre")
+                for row0, nrows in row_blocks:
+                    if o is not None:
+                        o.forward_reverb_rows(self._fir_design, plan_t, tables, spec, ws, T, int(row0), int(nrows), out)
+                    else:
+                        check(_lib.lib().nws_forward_reverb_rows(C.byref(aux), B, T, int(row0), int(nrows), ptr(out), ptr(ws), ws.numel(),
+                                                                 stream_ptr(dev)), "nws_forward_reverb_rows")
+                    if on_block is not None:
+                        on_block(int(row0), int(nrows), out)
+            return out
         if o is not None:
             return o.forward_audio(wdesc, f0, phase_u, self._w[1][-2], noise, self._fir_design, plan_t, tables, spec, ws, sr, out,
                                    wait_event.cuda_event if wait_event is not None else 0,

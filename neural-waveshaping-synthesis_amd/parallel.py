@@ -124,6 +124,23 @@ class PeerCopyAllGather:
         self._flag = torch.zeros(1, dtype=torch.float32, device=self.device)
         dist.barrier(group=group)   # nobody starts pushing before everybody has opened everything
 
+    def push_rows(self, y: torch.Tensor, slot: int, row0: int, nrows: int):
+        """Sub-batch form: push rows [row0, row0 + nrows) of this rank's shard into every peer's buffer on the
+        current stream; call `finish(slot)` after the last block."""
+        lo = self.rank * self.rows + row0
+        for k in range(self.world):
+            p = (self.rank + k) % self.world
+            self.remote[p][slot][lo:lo + nrows].copy_(y[row0:row0 + nrows], non_blocking=True)
+
+    def finish(self, slot: int):
+        """the completion signal of gather(), on its own (after push_rows of every block)"""
+        if self.backend == "gloo":
+            torch.cuda.current_stream(self.device).synchronize()
+            dist.barrier(group=self.group)
+            return self.full[slot], None
+        work = dist.all_reduce(self._flag, group=self.group, async_op=True)
+        return self.full[slot], work
+
     def gather(self, y: torch.Tensor, slot: int):
         if y.shape != (self.rows, self.n) or not y.is_contiguous():
             raise ValueError(f"expected a contiguous {(self.rows, self.n)} shard, got {tuple(y.shape)}")

@@ -87,7 +87,16 @@ class ForwardPipeline:
         an all-gather of its waveforms, say - is enqueued there)."""
         return self.audio[self._n % len(self.audio)]
 
-    def submit(self, f0, control, *, phase_u=None, noise=None, out=None):
+    @staticmethod
+    def row_blocks(B: int, chunks: int):
+        """B rows in `chunks` blocks of even size >= 4 (the reverb transforms two utterances at a time); None if that does not
+        divide"""
+        if chunks <= 1 or B % chunks or (B // chunks) % 2 or B // chunks < 4:
+            return None
+        n = B // chunks
+        return [(q * n, n) for q in range(chunks)]
+
+    def submit(self, f0, control, *, phase_u=None, noise=None, out=None, row_blocks=None, on_block=None):
         m = self.model
         f0 = _req(f0 if f0.is_contiguous() else f0.contiguous(), "f0")
         control = _req(control if control.is_contiguous() else control.contiguous(), "control")
@@ -131,7 +140,7 @@ class ForwardPipeline:
                                              record_event=slot.ev_exciter)
                 self._last_exciter = slot.ev_exciter
             else:
-                out = self.eng.forward_audio(f0, B, T, pu, nz, slot.ws, out=out)
+                out = self.eng.forward_audio(f0, B, T, pu, nz, slot.ws, out=out, row_blocks=row_blocks, on_block=on_block)
             slot.ev_audio.record(au)
         slot.used = True
         slot.keep = (f0, control, pu, nz)        # inputs stay alive until the slot is reused

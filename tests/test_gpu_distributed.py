@@ -94,3 +94,46 @@ def test_two_ranks_on_one_gpu_peer_copy_all_gather():
     assert j["n_gpus"] == 2 and j["exchange"]["kind"] == "copy"
     assert len(j["ms_per_step_per_rank"]) == 2 and len(j["exchange"]["gather_ms_per_rank"]) == 2
     assert j["pipeline_selfcheck"]["mismatching_all_ranks"] == 0 and j["pipeline_selfcheck"]["gathered_rows_match"]
+
+
+def test_sub_batch_exchange_two_ranks_and_rccl_world1():
+    """--gather-chunks (sub-batches pushed as each block's reverb finishes): the reverb of a batch runs block by
+    block (nws_forward_audio_pre + nws_forward_reverb_rows), every block leaves for the peers right behind its own reverb.
+    Two ranks sharing the GPU (peer-copy form) and RCCL at world size 1 (list-of-views all_gather): every gathered row and
+    every batch of the timed issue pattern bit-equal to the plain forward."""
+    args = ["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--batch1-iters", "0", "--frames", "16", "--batch", "16",
+            "--gather-chunks", "4"]
+    port = 29700 + (os.getpid() + 77) % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", *args]
+    r = subprocess.run(cmd, env=dict(ENV, NWS_BENCH_SHARE_GPU="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and j["exchange"]["kind"] == "copy" and j["exchange"]["chunks"] == 4
+    assert 0.0 < j["exchange"]["overlap_efficiency"] <= 1.5
+    assert j["pipeline_selfcheck"]["mismatching_all_ranks"] == 0 and j["pipeline_selfcheck"]["gathered_rows_match"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=dict(ENV, NWS_BENCH_FORCE_DIST="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    assert j["exchange"]["kind"] == "rccl" and j["exchange"]["chunks"] == 4
+    assert j["pipeline_selfcheck"]["mismatching_all_ranks"] == 0 and j["pipeline_selfcheck"]["gathered_rows_match"]
+
+
+def test_reverb_row_blocks_equal_the_single_call():
+    m = build_model(True)
+    eng = m._engine
+    B, T = 16, 40
+    g = torch.Generator(device="cuda").manual_seed(4)
+    f0 = 100 + 500 * torch.rand(B, 1, T, device="cuda", generator=g)
+    c = torch.randn(B, 2, T, device="cuda", generator=g)
+    pu, nz = torch.rand(101, device="cuda", generator=g), torch.rand(128 * T - 1, device="cuda", generator=g)
+    ws = eng.new_workspace(B, T)
+    eng.forward_control(f0, c, ws, batched_gru=False)
+    ref = eng.forward_audio(f0, B, T, pu, nz, ws).clone()
+    seen = []
+    out = eng.forward_audio(f0, B, T, pu, nz, ws, row_blocks=[(0, 4), (4, 4), (8, 8)], on_block=lambda r0, n, o: seen.append((r0, n)))
+    assert seen == [(0, 4), (4, 4), (8, 8)] and torch.equal(out, ref)
+    pm = importlib.import_module("neural-waveshaping-synthesis_amd.pipeline")
+    assert pm.ForwardPipeline.row_blocks(64, 4) == [(0, 16), (16, 16), (32, 16), (48, 16)]
+    assert pm.ForwardPipeline.row_blocks(4, 2) is None and pm.ForwardPipeline.row_blocks(64, 1) is None
