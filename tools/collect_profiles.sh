@@ -5,11 +5,11 @@
 #   gpurun_out/prof_<round>/pmc_*           counter passes (separate runs: SQ has 8 slots, FETCH_SIZE and WRITE_SIZE do not
 #                                           fit one pass; never combined with sys/hip/hsa traces)
 # then tools/pmc_digest.py condenses them; copy the digest files into profiles/<round>/ and commit.
-R=${1:-r02}
+R=${1:-r03}
 OUT=gpurun_out/prof_$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python bench.py --no-cpu-baseline --batch1-iters 0 --warmup 5 ${NWS_PROFILE_ARGS:-}"
+BENCH="python bench.py --no-cpu-baseline --batch1-iters 0 --warmup 5 --legs 0 --pmc off ${NWS_PROFILE_ARGS:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_default" -- $BENCH --steps 50 > "$OUT/trace_default.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_1stream" -- $BENCH --steps 30 --pipeline 0 --streams 1 > "$OUT/trace_1stream.log" 2>&1
 P="$BENCH --steps 6 --pipeline 0 --streams 1"
