@@ -426,6 +426,8 @@ int nws_g_bth_to_bht(const float* x, int B, int T, int H, float* y, void* stream
  * fp32 chain of generators.py:59: phase = fl(fl(tau * c) / sr).  f0_up_out optional. */
 int nws_g_phase(const float* f0, const float* f0_up, int B, int T, int hop, float sample_rate, float* f0_up_out,
                 float* phase_out, void* stream);
+/* F.upsample(x, T * hop, mode="linear") row by row: x (rows, T) -> y (rows, T * hop) (neural_waveshaping.py:75, shaping.py:69) */
+int nws_g_upsample(const float* x, int64_t rows, int T, int hop, float* y, void* stream);
 /* HarmonicOscillator.forward (generators.py:58-66) for K harmonics: out (B, K, N) */
 int nws_g_oscillator(const float* f0_up, const float* phase, const float* phase_u, const float* rand_phase, int K, int B, int N,
                      float sample_rate, float* out, void* stream);

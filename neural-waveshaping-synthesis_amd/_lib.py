@@ -148,6 +148,7 @@ _PROTOTYPES = {
                             C.c_size_t, _fp]),
     "nws_g_bth_to_bht": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "nws_g_phase": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp, _fp]),
+    "nws_g_upsample": (C.c_int, [_fp, C.c_int64, C.c_int, C.c_int, _fp, _fp]),
     "nws_g_oscillator": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp]),
     "nws_g_conv1x1": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "nws_g_shaper_apply": (C.c_int, [C.POINTER(NwsShaperDesc), _fp, C.c_int64, C.c_int64, _fp, _fp]),

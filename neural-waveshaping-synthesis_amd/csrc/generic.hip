@@ -139,6 +139,16 @@ __global__ __launch_bounds__(1024) void g_phase_kernel(const float* __restrict__
   }
 }
 
+// ---- F.upsample(x, T*hop, mode="linear") on (rows, T) -> (rows, T*hop) (neural_waveshaping.py:75, shaping.py:69) -----------
+__global__ __launch_bounds__(256) void g_upsample_kernel(const float* __restrict__ x, int T, int N, float scale, float* __restrict__ y) {
+  const size_t row = blockIdx.y;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const GLerp L = g_lerp_coeff(n, T, scale);
+  const float* xr = x + row * T;
+  y[row * N + n] = fmaf(L.w0, xr[L.i0], L.w1 * xr[L.i1]);
+}
+
 // ---- oscillator bank (generators.py:58-66): out[b][k-1][n] = sin(fl(fl(k phase) + shift_k)) * [fl(f0 k) < sr/2] --------
 __global__ __launch_bounds__(256) void g_oscillator_kernel(const float* __restrict__ f0_up, const float* __restrict__ phase,
                                                            const float* __restrict__ phase_u, const float* __restrict__ rand_phase,
@@ -466,6 +476,16 @@ int nws_g_phase(const float* f0, const float* f0_up, int B, int T, int hop, floa
   if (N > (1ll << 30)) return NWS_ERR_UNSUPPORTED;
   const float scale = (float)T / (float)N;
   g_phase_kernel<<<B, 1024, 0, (hipStream_t)stream>>>(f0, f0_up, T, (int)N, scale, sample_rate, f0_up_out, phase_out);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+int nws_g_upsample(const float* x, int64_t rows, int T, int hop, float* y, void* stream) {
+  if (!x || !y || rows <= 0 || T <= 0 || hop <= 0) return NWS_ERR_BAD_ARG;
+  if (rows > 65535) return NWS_ERR_UNSUPPORTED;
+  const long long N = (long long)T * hop;
+  if (N > (1ll << 30)) return NWS_ERR_UNSUPPORTED;
+  g_upsample_kernel<<<dim3((unsigned)((N + 255) / 256), (unsigned)rows), 256, 0, (hipStream_t)stream>>>(x, T, (int)N, (float)T / (float)N, y);
   NWS_CHECK_LAUNCH();
   return NWS_OK;
 }

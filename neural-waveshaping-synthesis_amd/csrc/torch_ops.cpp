@@ -656,6 +656,19 @@ Tensor g_oscillator(const Tensor& f0_up, const Tensor& phase_u, const Tensor& ra
   return out;
 }
 
+// F.upsample(x, T * hop, mode="linear") on the last axis of (..., T)
+Tensor g_upsample(const Tensor& x, int64_t hop) {
+  check_dev(x, "x");
+  TORCH_CHECK(x.dim() >= 1 && x.size(-1) >= 1 && hop >= 1, "upsample: expected (..., T) and hop >= 1");
+  const int64_t T = x.size(-1), rows = x.numel() / T;
+  Launch L(x);
+  auto shape = x.sizes().vec();
+  shape.back() = T * hop;
+  Tensor y = at::empty(shape, x.options());
+  nws_check(nws_g_upsample(x.data_ptr<float>(), rows, (int)T, (int)hop, y.data_ptr<float>(), L.stream), "nws_g_upsample");
+  return y;
+}
+
 Tensor g_conv1x1(const Tensor& x, const Tensor& w, const OptTensor& bias) {
   check_dev(x, "x");
   check_dev(w, "weight");
@@ -855,6 +868,7 @@ TORCH_LIBRARY(newt_hip, m) {
   m.def("g_gru(Tensor w_ih, Tensor w_hh, Tensor b_ih, Tensor b_hh, Tensor control, Tensor? h0) -> (Tensor, Tensor)", &g_gru);
   m.def("g_oscillator(Tensor f0_up, Tensor phase_u, Tensor rand_phase, float sample_rate) -> Tensor", &g_oscillator);
   m.def("g_conv1x1(Tensor x, Tensor weight, Tensor? bias) -> Tensor", &g_conv1x1);
+  m.def("g_upsample(Tensor x, int hop) -> Tensor", &g_upsample);
   m.def("g_shaper_apply(Tensor sdesc, Tensor x) -> Tensor", &g_shaper_apply);
   m.def("g_shaper_table(Tensor sdesc, Tensor like, int size, float tmin, float tmax) -> Tensor", &g_shaper_table);
   m.def("g_newt_apply(Tensor sdesc, Tensor exciter, Tensor film, Tensor mix_w, Tensor mix_b) -> Tensor", &g_newt_apply);

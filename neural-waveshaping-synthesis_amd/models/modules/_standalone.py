@@ -72,6 +72,33 @@ def no_autograd(inputs=(), params=()):
                       "require grad (wrap calls in torch.no_grad() to silence this)", stacklevel=3)
 
 
+_ONES = {}
+
+
+def sum_channels(x: torch.Tensor) -> torch.Tensor:
+    """(B, C, N) -> (B, N): the `x.sum(1)` of models/neural_waveshaping.py:86 as a 1x1 convolution with unit weights
+    (g_conv1x1_kernel: sequential adds in channel order)"""
+    x = contiguous(x, "x")
+    B, Cc, N = x.shape
+    key = (x.device, Cc)
+    ones = _ONES.get(key)
+    if ones is None:
+        ones = _ONES[key] = torch.ones((1, Cc), dtype=torch.float32, device=x.device)
+
+    def c_call(L):
+        with torch.cuda.device(x.device):
+            y = torch.empty((B, 1, N), dtype=torch.float32, device=x.device)
+            checked(L.nws_g_conv1x1(x.data_ptr(), ones.data_ptr(), None, B, Cc, 1, N, y.data_ptr(), stream_ptr(x.device)), "nws_g_conv1x1")
+        return y
+
+    return call("g_conv1x1", "nws_g_conv1x1", (x, ones, None), c_call)[:, 0].contiguous()
+
+
+def has_hooks(*modules) -> bool:
+    """forward (pre-)hooks registered on any of these modules"""
+    return any(m is not None and (m._forward_hooks or m._forward_pre_hooks) for m in modules)
+
+
 def call(op_name: str, c_name: str, op_args: tuple, c_call):
     """Run `torch.ops.newt_hip.<op_name>(*op_args)` or, on the ctypes binding, `c_call(lib)` (which returns the result)."""
     flat = []
@@ -88,4 +115,4 @@ def checked(rc: int, what: str):
     _lib.check(rc, what)
 
 
-__all__ = ["C", "Desc", "call", "no_autograd", "checked", "contiguous", "shaper_fields", "stream_ptr", "_req", "_lib", "ops"]
+__all__ = ["C", "Desc", "call", "has_hooks", "no_autograd", "sum_channels", "checked", "contiguous", "shaper_fields", "stream_ptr", "_req", "_lib", "ops"]

@@ -29,6 +29,49 @@ class FiLM(nn.Module):
         return sa.call("film", "nws_film", (x, gamma, beta), c_call)
 
 
+class Conv1x1(nn.Conv1d):
+    """nn.Conv1d(in, out, 1) with the reference's parameters / state-dict keys whose forward is a HIP kernel (g_conv1x1_kernel,
+    csrc/generic.hip): harmonic_mixer (models/neural_waveshaping.py:54) and newt.mixer (shaping.py:63-65) called on their own -
+    what the forward runs instead of the fused kernels when somebody has registered forward hooks on sub-modules."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=1, **kw):
+        if kernel_size not in (1, (1,)) or kw.get("groups", 1) != 1:
+            raise RuntimeError("Conv1x1: kernel_size 1, groups 1")
+        super().__init__(in_channels, out_channels, 1, **kw)
+
+    def forward(self, x):
+        x = sa.contiguous(x, "x")
+        if x.dim() != 3 or x.shape[1] != self.in_channels:
+            raise RuntimeError(f"Conv1d({self.in_channels}, {self.out_channels}, 1): expected (B, {self.in_channels}, N), got {tuple(x.shape)}")
+        wt = sa._req(self.weight.detach(), "weight")
+        bt = sa._req(self.bias.detach(), "bias") if self.bias is not None else None
+        sa.no_autograd(params=[self.weight])
+        B, Cin, N = x.shape
+
+        def c_call(L):
+            with torch.cuda.device(x.device):
+                y = torch.empty((B, self.out_channels, N), dtype=torch.float32, device=x.device)
+                sa.checked(L.nws_g_conv1x1(x.data_ptr(), wt.data_ptr(), bt.data_ptr() if bt is not None else None, B, Cin,
+                                           self.out_channels, N, y.data_ptr(), sa.stream_ptr(x.device)), "nws_g_conv1x1")
+            return y
+
+        return sa.call("g_conv1x1", "nws_g_conv1x1", (x, wt, bt), c_call)
+
+
+def upsample_linear(x, hop: int):
+    """F.upsample(x, T * hop, mode="linear") on the last axis of a CUDA tensor (neural_waveshaping.py:75, shaping.py:69)."""
+    x = sa.contiguous(x, "x")
+    T = x.shape[-1]
+
+    def c_call(L):
+        with torch.cuda.device(x.device):
+            y = torch.empty(tuple(x.shape[:-1]) + (T * hop,), dtype=torch.float32, device=x.device)
+            sa.checked(L.nws_g_upsample(x.data_ptr(), x.numel() // T, T, int(hop), y.data_ptr(), sa.stream_ptr(x.device)), "nws_g_upsample")
+        return y
+
+    return sa.call("g_upsample", "nws_g_upsample", (x, int(hop)), c_call)
+
+
 class TimeDistributedLayerNorm(nn.Module):
     """LayerNorm over the channel axis of a (B, C, T) tensor (reference dynamic.py:11-17)."""
 

@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from ... import ginlite as gin
 from . import _standalone as sa
-from .dynamic import FiLM, TimeDistributedMLP
+from .dynamic import Conv1x1, FiLM, TimeDistributedMLP, upsample_linear
 
 
 class Sine(nn.Module):
@@ -123,7 +123,7 @@ class NEWT(nn.Module):
         self.waveshaping_index = FiLM()
         self.shaping_fn = TrainableNonlinearity(n_waveshapers, shaping_fn_size, nonlinearity=Sine)
         self.normalising_coeff = FiLM()
-        self.mixer = nn.Sequential(nn.Conv1d(n_waveshapers, out_channels, 1))
+        self.mixer = nn.Sequential(Conv1x1(n_waveshapers, out_channels, 1))
         self._newt_desc = sa.Desc()
         self._g_newt = _GShaperCache()
 
@@ -177,6 +177,14 @@ class NEWT(nn.Module):
         T = film.shape[2]
         if exciter.shape[0] != film.shape[0] or exciter.shape[2] % T:
             raise RuntimeError(f"NEWT: exciter {tuple(exciter.shape)} does not match {T} control frames")
+        if sa.has_hooks(self.waveshaping_index, self.normalising_coeff, self.mixer, self.mixer[0], self._modules.get("shaping_fn")):
+            # somebody listens on the inner modules: run them one by one, exactly the reference's sequence (shaping.py:69-79)
+            fp = upsample_linear(film, exciter.shape[2] // T)
+            g_i, b_i, g_n, b_n = torch.split(fp, self.n_waveshapers, 1)
+            x = self.waveshaping_index(exciter, g_i, b_i)
+            x = self.shaping_fn(x)
+            x = self.normalising_coeff(x, g_n, b_n)
+            return self.mixer(x)
         if not self._specialised(exciter.shape[2] // T):
             return self._forward_generic(exciter, film)
         tensors, scalars = self._apply_fields()

@@ -180,3 +180,42 @@ def test_same_suite_through_the_ctypes_binding():
                         "-k", "not offline_render and not soak and not full_size"],
                        env=dict(os.environ, NWS_BACKEND="ctypes"), capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+
+
+def test_forward_hooks_on_sub_modules_fire(models, g):
+    """The reference's users (and tests/golden/make_golden.py itself) tap stages with forward hooks on sub-modules
+    (models/neural_waveshaping.py:76-88 calls them one by one).  The fused forward never calls the sub-modules, so with hooks
+    registered the forward runs module by module - the reference's own sequence, one HIP stage kernel each - and the taps are
+    the reference's taps; without hooks the fused kernels run again."""
+    exact, fast = models
+    f0, control = dev(g["f0"]), dev(g["control"])
+    pu, nz = dev(g["phase_u"]), dev(g["noise"])
+    for model, ykey, shaped_key in ((exact, "y_exact", "shaped_exact"), (fast, "y_lut", "shaped_lut")):
+        y_fused = model(f0, control, phase_u=pu, noise=nz)
+        taps = {}
+
+        def tap(name, what="out"):
+            def hook(mod, inp, out):
+                taps[name] = (inp[0] if what == "in" else out).detach().clone()
+            return hook
+
+        hs = [model.osc.register_forward_hook(tap("osc")), model.harmonic_mixer.register_forward_hook(tap("exciter")),
+              model.embedding.register_forward_hook(tap("embedding")), model.newt.mlp.register_forward_hook(tap("film")),
+              model.newt.waveshaping_index.register_forward_hook(tap("lut_arg")),
+              model.newt.normalising_coeff.register_forward_hook(tap("shaped", "in")),
+              model.h_generator.register_forward_hook(tap("H")), model.noise_synth.register_forward_hook(tap("noise_out")),
+              model.reverb.register_forward_hook(tap("pre_reverb", "in"))]
+        try:
+            y = model(f0, control, phase_u=pu, noise=nz)
+        finally:
+            for h in hs:
+                h.remove()
+        assert set(taps) == {"osc", "exciter", "embedding", "film", "lut_arg", "shaped", "H", "noise_out", "pre_reverb"}
+        for k, tol in dict(osc=2e-6, exciter=2e-5, embedding=1e-5, film=5e-5, lut_arg=5e-5, H=5e-5).items():
+            assert maxabs(taps[k].cpu().numpy(), g[k]) <= tol, k
+        assert maxabs(taps["shaped"].cpu().numpy(), g[shaped_key]) <= 5e-5
+        assert maxabs(taps["noise_out"].cpu().numpy()[:, 0], g["noise_out"]) <= 1e-6
+        e = rms(y.cpu().numpy() - g[ykey])
+        record("hooked_forward_" + ykey, rms_err=e, rms_vs_fused=rms((y - y_fused).cpu().numpy()))
+        assert e <= 1e-5
+        assert torch.equal(model(f0, control, phase_u=pu, noise=nz), y_fused)       # hooks gone: the fused kernels again
