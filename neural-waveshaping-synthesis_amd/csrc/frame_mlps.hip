@@ -16,6 +16,8 @@
 // per accumulator column: in-lane over 16 registers, one half-swap, one 4-wave LDS exchange.
 // Outputs that the sample-rate kernels read frame-major (film, fir) are transposed per wave
 // through a 4 KB LDS patch so every global store is a full 128 B segment.
+#include <cstdlib>
+
 #include "nws_common.h"
 
 namespace {
@@ -317,11 +319,12 @@ __device__ __forceinline__ void mma_tile(const AFrag<KS>& A, const char* xt, int
 }
 
 // write a 32-channel x 32-frame tile held in the D layout into an XT buffer (4 consecutive channels per store)
+template <int XB = kXtBytes>
 __device__ __forceinline__ void store_tile_xt(char* xt, int c0, const float v[16], int lane) {
   const int half = lane >> 5, col = lane & 31;
 #pragma unroll
   for (int g = 0; g < 4; ++g)
-    split4_store(xt, xt + kXtBytes, col, c0 + 8 * g + 4 * half, v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+    split4_store(xt, xt + XB, col, c0 + 8 * g + 4 * half, v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
 }
 
 // the 16 per-lane entries (channels 32 wave + frag_row(r, half)) of a per-channel parameter vector
@@ -378,11 +381,11 @@ __device__ __forceinline__ void ln_finish(float (&v)[16], float mean, float rstd
 
 // one accumulator chain for all three products (dependent 32x32x16 MFMAs issue back to back at full rate; the small cross
 // terms meet the same fp32 additions either way): 16 registers less than mma_tile, no merge pass
-template <int KS>
+template <int KS, int XB = kXtBytes>
 __device__ __forceinline__ void mma_tile1(const AFrag<KS>& A, const char* xt, int lane, f32x16& acc) {
   const int half = lane >> 5, col = lane & 31;
   const char* bh = xt + col * kRowB + half * 16;
-  const char* bl = bh + kXtBytes;
+  const char* bl = bh + XB;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     const f16x8 xh = *reinterpret_cast<const f16x8*>(bh + ks * 32);
@@ -566,6 +569,213 @@ __global__ __launch_bounds__(512, 4) void frame_mlps16_kernel(NwsWeights w, cons
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 64 frames per workgroup (round 3): the same wave layout (wave = (M-tile, path)), but every wave runs its
+// layer on TWO 32-frame N-tiles with ONE set of weight fragments: half the fragment bytes per frame (each workgroup streams
+// 745 KB from L2 at the CU's 64 B/clk whatever its tile: 35 % of the 32-frame kernel's time), two independent MFMA chains per
+// wave, half the barrier phases per frame.  155 KB of LDS: one workgroup (8 waves) per CU, <= 256 registers.
+constexpr int kFT2 = 64;
+constexpr int kXtBytes2 = kFT2 * kRowB;
+struct MlpLds64 {
+  char xt[4][2][kXtBytes2];    // E, X, Y, Z, each [hi|lo]
+  float red[2][2][4][kFT2];    // [path][mean | M2][wave][frame]
+  float gb[4][NWS_HIDDEN];
+};
+static_assert(sizeof(MlpLds64) <= 160 * 1024, "LDS");
+
+template <bool TAPS>
+__global__ __launch_bounds__(512, 2) void frame_mlps64_kernel(NwsWeights w, const float* __restrict__ gru_out, int T,
+                                                                float* __restrict__ emb_out, float* __restrict__ film_out,
+                                                                float* __restrict__ H_out, float* __restrict__ fir_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  MlpLds64& L = *reinterpret_cast<MlpLds64*>(smem_raw);
+  constexpr int XB = kXtBytes2;
+  constexpr int kTileB = kFT * kRowB;          // byte offset of the second N-tile (frames 32..63) inside an XT buffer
+  char* const E = L.xt[0][0];
+  char* const X = L.xt[1][0];
+  char* const Y = L.xt[2][0];
+  char* const Z = L.xt[3][0];
+  const f16x8* F = reinterpret_cast<const f16x8*>(w.mlp_frags);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mt = wave & 3, path = wave >> 2;
+  const int half = lane >> 5, col = lane & 31;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * kFT2;
+  const int frames_valid = T - t0 < kFT2 ? T - t0 : kFT2;
+  AFrag<8> A;
+  f32x16 acc0, acc1;
+
+  __builtin_amdgcn_sched_barrier(0);
+  load_frags<8>(A, F + (path ? frag_map(5).base : frag_map(0).base), mt, lane);  // proj | hgen hidden 0
+  for (int e = tid; e < kFT2 * (NWS_HIDDEN / 4); e += 512) {
+    const int f = e >> 5, c4 = (e & 31) * 4;
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (f < frames_valid) v = *reinterpret_cast<const float4*>(&gru_out[((size_t)b * T + t0 + f) * NWS_HIDDEN + c4]);
+    split4_store(X, X + XB, f, c4, v.x, v.y, v.z, v.w);
+  }
+  if (tid < kFT2 * 2 * 2) {     // K padding (channels 128..143) of Z
+    const int f = tid >> 2, part = tid & 3;
+    *reinterpret_cast<float4*>(Z + (part >> 1) * XB + f * kRowB + 256 + (part & 1) * 16) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+  __syncthreads();
+
+  // ---- emb = proj(gru_out) -> E (waves 0-3) ----
+  if (path == 0) {
+    float vb[16];
+    load_lane_params(vb, w.proj_b, mt, lane);
+    mma_tile1<8, XB>(A, X, lane, acc0);
+    mma_tile1<8, XB>(A, X + kTileB, lane, acc1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags<8>(A, F + frag_map(1).base, mt, lane);  // newt hidden 0
+    float v[16];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = vb[r] + (nt ? acc1[r] : acc0[r]);
+      store_tile_xt<XB>(E + nt * kTileB, 32 * mt, v, lane);
+      if (TAPS && emb_out != nullptr && 32 * nt + col < frames_valid) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) emb_out[((size_t)b * NWS_HIDDEN + 32 * mt + frag_row(r, half)) * T + t0 + 32 * nt + col] = v[r];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- hidden layers: Xout = LeakyReLU(LayerNorm(W Xin + b)) on both N-tiles; the next layer's fragments are requested as
+  // soon as both tiles' MFMAs have been issued ----
+  auto hidden = [&](const int fa_next, const int fb_next, const char* in, char* out, const float* bias, const float* g_a,
+                    const float* bt_a, const float* g_b, const float* bt_b) {
+    float v0[16], v1[16];
+    load_lane_params(v0, bias, mt, lane);
+    mma_tile1<8, XB>(A, in, lane, acc0);
+    mma_tile1<8, XB>(A, in + kTileB, lane, acc1);
+    const int row = tid >> 7;
+    const float p0 = (row == 0 ? g_a : row == 1 ? bt_a : row == 2 ? g_b : bt_b)[tid & 127];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      v1[r] = v0[r] + acc1[r];
+      v0[r] += acc0[r];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags<8>(A, F + frag_map(path ? fb_next : fa_next).base, mt, lane);
+    L.gb[row][tid & 127] = p0;
+    float mw, m2;
+    ln_partials(v0, mw, m2);
+    if (half == 0) {
+      L.red[path][0][mt][col] = mw;
+      L.red[path][1][mt][col] = m2;
+    }
+    ln_partials(v1, mw, m2);
+    if (half == 0) {
+      L.red[path][0][mt][32 + col] = mw;
+      L.red[path][1][mt][32 + col] = m2;
+    }
+    __syncthreads();
+    auto merge = [&](int f, float& mean, float& rstd) {
+      const float (*red)[4][kFT2] = L.red[path];
+      const float m0 = red[0][0][f], m1 = red[0][1][f], m2_ = red[0][2][f], m3 = red[0][3][f];
+      mean = ((m0 + m1) + (m2_ + m3)) * 0.25f;
+      const float d0 = m0 - mean, d1 = m1 - mean, d2 = m2_ - mean, d3 = m3 - mean;
+      const float between = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      const float within = (red[1][0][f] + red[1][1][f]) + (red[1][2][f] + red[1][3][f]);
+      rstd = 1.0f / sqrtf(fmaf(32.0f, between, within) * (1.0f / NWS_HIDDEN) + kLnEps);
+    };
+    float mean, rstd;
+    merge(col, mean, rstd);
+    ln_finish(v0, mean, rstd, L.gb[2 * path], L.gb[2 * path + 1], mt, lane);
+    store_tile_xt<XB>(out, 32 * mt, v0, lane);
+    merge(32 + col, mean, rstd);
+    ln_finish(v1, mean, rstd, L.gb[2 * path], L.gb[2 * path + 1], mt, lane);
+    store_tile_xt<XB>(out + kTileB, 32 * mt, v1, lane);
+    __syncthreads();
+  };
+  hidden(2, 6, E, path ? Y : X, path ? w.hgen_b[0] : w.newt_mlp_b[0], w.newt_ln_g[0], w.newt_ln_b[0], w.hgen_ln_g[0], w.hgen_ln_b[0]);
+  hidden(3, 7, path ? Y : X, path ? E : Z, path ? w.hgen_b[1] : w.newt_mlp_b[1], w.newt_ln_g[1], w.newt_ln_b[1], w.hgen_ln_g[1],
+         w.hgen_ln_b[1]);
+  hidden(4, 8, path ? E : Z, path ? Y : X, path ? w.hgen_b[2] : w.newt_mlp_b[2], w.newt_ln_g[2], w.newt_ln_b[2], w.hgen_ln_g[2],
+         w.hgen_ln_b[2]);
+
+  // ---- output layers.  E is dead: transposition patches of waves 0-3 ----
+  float* patch = reinterpret_cast<float*>(E) + mt * (kFT * kPS);
+  auto fv = [&](int nt) { return frames_valid - 32 * nt < 0 ? 0 : (frames_valid - 32 * nt > 32 ? 32 : frames_valid - 32 * nt); };
+  if (path == 0) {
+    float vb[16], v[16];
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {     // film M-tiles mt and mt + 4
+      const int tile = mt + 4 * pass;
+      load_lane_params(vb, w.newt_mlp_b[3], tile, lane);
+      mma_tile1<8, XB>(A, X, lane, acc0);
+      mma_tile1<8, XB>(A, X + kTileB, lane, acc1);
+      if (pass == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags<8>(A, F + frag_map(4).base, mt + 4, lane);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = vb[r] + (nt ? acc1[r] : acc0[r]);
+        store_tile_frame_major(patch, v, lane, film_out + ((size_t)b * T + t0 + 32 * nt) * NWS_FILM_CH + 32 * tile, NWS_FILM_CH, fv(nt));
+      }
+    }
+  } else {
+    // H (129 bands): M-tiles 0..3 from Y -> Z channels 0..127; wave 4 also M-tile 4 = row 128 (129..143 stay zero)
+    float vb[16], vh[16];
+    load_lane_params(vb, w.hgen_b[3], mt, lane);
+    const float b128 = w.hgen_b[3][128];
+    mma_tile1<8, XB>(A, Y, lane, acc0);
+    mma_tile1<8, XB>(A, Y + kTileB, lane, acc1);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) vh[r] = vb[r] + (nt ? acc1[r] : acc0[r]);
+      store_tile_xt<XB>(Z + nt * kTileB, 32 * mt, vh, lane);
+      if (TAPS && H_out != nullptr && 32 * nt + col < frames_valid) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H_out[((size_t)b * T + t0 + 32 * nt + col) * NWS_N_BANDS + 32 * mt + frag_row(r, half)] = vh[r];
+      }
+    }
+    if (mt == 0) {
+      AFrag<8> A4;
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags<8>(A4, F + frag_map(8).base, 4, lane);
+      mma_tile1<8, XB>(A4, Y, lane, acc0);
+      mma_tile1<8, XB>(A4, Y + kTileB, lane, acc1);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = 128 + frag_row(r, half);
+          vh[r] = c < NWS_N_BANDS ? (nt ? acc1[r] : acc0[r]) + b128 : 0.0f;   // only row 128 is real
+          if (TAPS && H_out != nullptr && c < NWS_N_BANDS && 32 * nt + col < frames_valid)
+            H_out[((size_t)b * T + t0 + 32 * nt + col) * NWS_N_BANDS + c] = vh[r];
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+          split4_store(Z + nt * kTileB, Z + nt * kTileB + XB, col, 128 + 8 * g + 4 * half, vh[4 * g], vh[4 * g + 1], vh[4 * g + 2], vh[4 * g + 3]);
+      }
+    }
+  }
+  // ---- fir = D[128 .. 255] * H  (upper half-taps = 4 M-tiles, K = 144 padded): waves 0-3 ----
+  AFrag<9> A9;
+  if (path == 0) {
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags<9>(A9, F + frag_map(9).base, mt, lane);
+  }
+  __syncthreads();
+  if (path == 0) {
+    float v[16];
+    mma_tile1<9, XB>(A9, Z, lane, acc0);
+    mma_tile1<9, XB>(A9, Z + kTileB, lane, acc1);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = nt ? acc1[r] : acc0[r];
+      store_tile_frame_major(patch, v, lane, fir_out + ((size_t)b * T + t0 + 32 * nt) * NWS_FIR_HALF + 32 * mt, NWS_FIR_HALF, fv(nt));
+    }
+  }
+}
+
 // one thread per fragment pair: 8 consecutive-k weights of one row, split into hi / lo
 __global__ void mlp_frags_kernel(NwsWeights w, const float* __restrict__ fir_design, f16x8* __restrict__ out) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -656,6 +866,30 @@ int nws_frame_mlps(const NwsWeights* w, const float* gru_out, const float* fir_d
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_mlps16_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpLds16));
     if (e != hipSuccess) return (int)e;
+  }
+  // more than one 32-frame tile per utterance: 64-frame tiles.  NWS_MLP_TILE=32 keeps the 32-frame kernel for A/B timing
+  // (same box, back to back at B=64, T=500: 66.4 us per call with 32-frame tiles, 62.5 with 64-frame tiles)
+  static const bool tile64 = [] {
+    const char* e = getenv("NWS_MLP_TILE");
+    return e == nullptr || atoi(e) != 32;
+  }();
+  if (w->mlp_frags != nullptr && T > kFT && tile64) {
+    static unsigned long long attr64 = 0;
+    if (nws_first_use_on_device(attr64)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_mlps64_kernel<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpLds64));
+      if (e != hipSuccess) return (int)e;
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_mlps64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)sizeof(MlpLds64));
+      if (e != hipSuccess) return (int)e;
+    }
+    const dim3 grid64((T + kFT2 - 1) / kFT2, B);
+    if (!emb_out && !H_out)
+      frame_mlps64_kernel<false><<<grid64, 512, sizeof(MlpLds64), (hipStream_t)stream>>>(*w, gru_out, T, nullptr, film_out, nullptr, fir_out);
+    else
+      frame_mlps64_kernel<true><<<grid64, 512, sizeof(MlpLds64), (hipStream_t)stream>>>(*w, gru_out, T, emb_out, film_out, H_out, fir_out);
+    NWS_CHECK_LAUNCH();
+    return NWS_OK;
   }
   const dim3 grid((T + kFT - 1) / kFT, B);
   if (w->mlp_frags != nullptr && !emb_out && !H_out)
