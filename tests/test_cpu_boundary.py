@@ -258,3 +258,54 @@ def test_build_guard_finds_swizzled_packed_forms():
     found = b.check_packed_swizzles(os.path.join(b.OBJ, "coexec_probe.o"))
     first = [i for k, i in found if "pk_probe_kernel" in k]
     assert len(first) == 4 and all("pk_probe" in k for k, _ in found), found      # the 4 hazardous fp32 forms of probe 1
+
+
+def test_precision_rule_is_a_worst_case_bound_from_the_weights():
+    """Engine.exciter_opts' automatic choice (precision.hybrid_w_error_bound): host logic, no GPU.  The shipped checkpoint's bound
+    is far above 1e-5 (-> every mixer product two-term); it scales linearly with ||ir||_1 and with the high-harmonic weights
+    and vanishes when those weights are zero (-> the cheaper products are admitted)."""
+    import importlib
+
+    from oracle.newt_oracle import OracleNEWT, load_weights_npz
+
+    prec = importlib.import_module("neural-waveshaping-synthesis_amd.precision")
+    path = os.path.join(ROOT, "tests", "golden", "weights_vn.npz")
+    w = {k: v for k, v in load_weights_npz(path).items() if not k.startswith("__")}
+    table = OracleNEWT(w, fast=True).lookup_table()
+    m = nws.NeuralWaveshaping.load_from_checkpoint(path)
+    b0 = prec.hybrid_w_error_bound(m, table)
+    assert b0["bound"] > 1e3 and b0["reverb_gain"] > 500
+    with torch.no_grad():
+        m.reverb.ir.mul_(0.5)
+    b1 = prec.hybrid_w_error_bound(m, table)
+    assert abs(b1["bound"] / b0["bound"] - (1 + 0.5 * (b0["reverb_gain"] - 1)) / b0["reverb_gain"]) < 1e-9
+    with torch.no_grad():
+        m.harmonic_mixer.weight[:, 15:].mul_(0.25)
+    b2 = prec.hybrid_w_error_bound(m, table)
+    assert abs(b2["bound"] / b1["bound"] - 0.25) < 1e-3
+    with torch.no_grad():
+        m.harmonic_mixer.weight[:, 15:].zero_()
+    assert prec.hybrid_w_error_bound(m, table)["bound"] == 0.0
+    g = prec.film_gain_bounds(m.newt.mlp)
+    assert g.shape == (256,) and float(g.min()) > 0
+
+
+def test_stream_bookkeeping_functions_are_consistent():
+    """Host-side helpers of the streaming ABI (csrc/stream.hip; no GPU needed): whatever the chunking, the emitted samples
+    add up to 128 F and the noise draws to the one-shot draw's 128 F - 1 samples plus the two look-ahead samples."""
+    L = _lib.lib()
+    for chunks in ([60], [1, 7, 16, 4, 31, 1], [2] * 30, [13, 47], [249, 51]):
+        seen, emitted, drawn, prev_start = 0, 0, 0, 0
+        for i, K in enumerate(chunks):
+            first, final = int(seen == 0), int(i == len(chunks) - 1)
+            emitted += L.nws_stream_out_samples(K, first, final)
+            drawn += L.nws_stream_noise_draws(K, first, seen)
+            start = L.nws_stream_noise_start(first, seen)
+            assert start >= prev_start and start % 128 == 0
+            prev_start = start
+            seen += K
+        F = sum(chunks)
+        assert emitted == 128 * F and drawn == 128 * (F - 1) + 129
+    pm = __import__("importlib").import_module("neural-waveshaping-synthesis_amd.pipeline")
+    assert pm.ForwardPipeline.row_blocks(64, 4) == [(0, 16), (16, 16), (32, 16), (48, 16)]
+    assert pm.ForwardPipeline.row_blocks(64, 3) is None and pm.ForwardPipeline.row_blocks(8, 4) is None
