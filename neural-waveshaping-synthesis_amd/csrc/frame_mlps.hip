@@ -873,7 +873,9 @@ int nws_frame_mlps(const NwsWeights* w, const float* gru_out, const float* fir_d
     const char* e = getenv("NWS_MLP_TILE");
     return e == nullptr || atoi(e) != 32;
   }();
-  if (w->mlp_frags != nullptr && T > kFT && tile64) {
+  // (only when the 64-frame grid still gives every CU a workgroup: at B = 1 the 16 workgroups of the 32-frame kernel finish
+  // a 4 s clip sooner than 8 twice as long ones - batch-1 latency 0.305 against 0.32 ms)
+  if (w->mlp_frags != nullptr && T > kFT && tile64 && (long long)B * ((T + kFT2 - 1) / kFT2) >= 256) {
     static unsigned long long attr64 = 0;
     if (nws_first_use_on_device(attr64)) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_mlps64_kernel<false>),

@@ -147,8 +147,7 @@ class NewtStream:
                     hit = None
             if hit is not None:
                 g, f0_in, c_in, _, out, pre = hit
-                f0_in.copy_(f0_2d)
-                c_in.copy_(control)
+                torch._foreach_copy_([f0_in, c_in], [f0_2d, control])      # one multi-tensor launch for both inputs
                 g.replay()
                 self._advance(K, M, first, final)
                 self._last_pre = pre
