@@ -135,6 +135,7 @@ class NewtStream:
             raise RuntimeError("a first chunk of one frame that is also not final emits 64 samples; nothing smaller exists")
         steady = (not first) and (not final) and self._last_K == K and self.frames_seen >= K + 2
         f0_2d = f0[:, 0, :]
+        self._check_weights()
         if steady and self._use_graph:
             hit = self._graphs.get((K, control.shape[1]))
             runs = self._steady_runs.get(K, 0) + 1
@@ -163,6 +164,22 @@ class NewtStream:
         self._last_pre = pre
         return out
 
+    def _check_weights(self):
+        """A captured hop holds raw pointers into the engine's derived tables (fragment tables, LUT pairs, FIR design, IR
+        spectrum).  If the engine has rebuilt them (somebody ran a forward after a weight update, `.to()`, `invalidate_cache`)
+        the graphs are dropped and re-captured; in-place updates nobody has told the engine about are looked for every 32nd
+        push (a full fingerprint walk costs ~12 us of host time: too much for every 256-sample hop)."""
+        eng = self.eng
+        self._pushes = getattr(self, "_pushes", 0) + 1
+        if self._pushes % 32 == 0 and eng._w is not None and eng._fingerprint() != eng._fp:
+            eng._wd()                                  # rebuilds (drains the device first)
+        if eng._w is not self.__dict__.get("_w_seen"):
+            if self._graphs:
+                torch.cuda.synchronize(self.dev)
+                self._graphs.clear()
+                self._steady_runs.clear()
+            self._w_seen = eng._w
+
     # ---- zero-copy hops: the caller writes into the captured hop's own input buffers and reads its output buffer ----------
     def static_io(self, K: int, channels: int = 2):
         """(f0_in (B, K), control_in (B, channels, K), out (B, 128 K)) of the captured steady-state hop of K frames - the
@@ -178,9 +195,10 @@ class NewtStream:
     def hop(self, K: int, channels: int = 2) -> torch.Tensor:
         """Replay the captured hop on whatever the caller left in static_io(K)'s input buffers; returns the static output
         buffer (overwritten by the next hop)."""
+        self._check_weights()
         hit = self._graphs.get((K, channels))
         if hit is None or self._last_K != K or self.finished:
-            raise RuntimeError("hop(): call static_io(K) first, and do not interleave other chunk sizes")
+            raise RuntimeError("hop(): call static_io(K) first (again after a weight update), and do not interleave other chunk sizes")
         hit[0].replay()
         self._advance(K, HOP * K, False, False)
         self._last_pre = hit[5]

@@ -107,3 +107,29 @@ def test_captured_hop_with_static_io_equals_push(setup):
         st = model.stream(B, graph=use_graph)
         outs.append(torch.cat([st.push(a, c) for a, c in chunks[:8]], dim=1))
     assert torch.isfinite(outs[1]).all() and abs(float(outs[0].std()) - float(outs[1].std())) <= 0.05 * float(outs[0].std())
+
+
+def test_stream_picks_up_weight_updates_and_recaptures(setup):
+    """a stream must not keep convolving with a stale IR (or replay a graph that points into freed tables) after the
+    model's weights change.  In-place update of reverb.ir in the middle of a stream: the hops after the engine has noticed it
+    (the next forward, or the stream's own periodic fingerprint walk) equal those of a fresh stream run on the new weights from
+    the same state - checked through the pre-reverb tap (unchanged by the IR) and the output (changed)."""
+    import copy
+
+    model, _, _ = setup
+    m = copy.deepcopy(model)
+    B, K = 1, 2
+    g = torch.Generator().manual_seed(21)
+    f0 = (200 + 100 * torch.rand(B, 1, K * 12, generator=g)).cuda()
+    control = torch.randn(B, 2, K * 12, generator=g).cuda()
+    pu, nz = torch.rand(101, generator=g).cuda(), torch.rand(128 * K * 12 - 1, generator=g).cuda()
+    s = m.stream(B, phase_u=pu, noise=nz)
+    outs = [s.push(f0[:, :, i * K:(i + 1) * K], control[:, :, i * K:(i + 1) * K]) for i in range(6)]
+    assert s._graphs                                             # steady state reached, hop captured
+    with torch.no_grad():
+        m.reverb.ir.mul_(0.0)                                    # in place: same storage, version bumped
+    m(f0[:, :, :4].contiguous(), control[:, :, :4].contiguous())   # any forward makes the engine rebuild its tables
+    y = s.push(f0[:, :, 12:14], control[:, :, 12:14])
+    # with a zero IR the output is the dry pre-reverb signal itself
+    assert torch.equal(y, s._last_pre) and not torch.equal(outs[-1], outs[-2])
+    assert not s._graphs or s._w_seen is m._engine._w
