@@ -37,10 +37,12 @@ from .engine import _req
 
 
 class _Slot:
-    __slots__ = ("ws", "ev_control", "ev_audio", "ev_exciter", "used", "keep")
+    __slots__ = ("ws", "ev_control", "ev_audio", "ev_exciter", "used", "keep", "pu", "nz")
 
     def __init__(self):
         self.ws = None
+        self.pu = None          # this slot's own buffers for the two hidden draws (filled on the control stream)
+        self.nz = None
         self.ev_control = torch.cuda.Event()
         self.ev_audio = torch.cuda.Event()
         self.ev_exciter = torch.cuda.Event()       # recorded right after this batch's oscillator + waveshaper kernel
@@ -80,6 +82,11 @@ class ForwardPipeline:
             for s in self.slots:
                 s.ws = self.eng.new_workspace(B, T)
                 s.used = False
+                # draw buffers owned by the slot: no allocation and no cross-stream record_stream per step (after a device
+                # synchronise the caching allocator walked hundreds of deferred-free events on the next allocation: 0.6 ms of
+                # host time in front of the first step of a timed region)
+                s.pu = torch.empty(_lib.N_HARMONICS, dtype=torch.float32, device=self.dev)
+                s.nz = torch.empty(_lib.HOP * T - 1, dtype=torch.float32, device=self.dev)
             self._shape = (B, T)
 
     def next_audio_stream(self):
@@ -119,19 +126,15 @@ class ForwardPipeline:
                 cs.wait_event(slot.ev_audio)        # the previous tenant of this workspace has been consumed
             # the two hidden draws of forward(), in the reference's order, on the side stream: two more small launches that
             # the audio streams do not have to carry (the generator advances in submit order either way)
-            pu = torch.rand_like(m.osc.rand_phase) if phase_u is None else phase_u      # RNG draw #1 (generators.py:55)
+            # (same generator consumption as torch.rand_like / torch.rand: the same uniform_ kernel on 101 resp. 128 T - 1 elements)
+            pu = torch.rand(_lib.N_HARMONICS, out=slot.pu) if phase_u is None else phase_u      # RNG draw #1 (generators.py:55)
             pu = _req(pu.reshape(-1), "phase_u", _lib.N_HARMONICS)
-            nz = torch.rand(m.control_hop * T - 1, device=self.dev) if noise is None else noise   # RNG draw #2 (:30)
+            nz = torch.rand(m.control_hop * T - 1, out=slot.nz) if noise is None else noise     # RNG draw #2 (:30)
             nz = _req(nz, "noise", m.control_hop * T - 1)
             self.eng.forward_control(f0, control, slot.ws, batched_gru=batched)
             slot.ev_control.record(cs)
-            # the draws were allocated on THIS control stream but are consumed on the audio stream: tell the caching
-            # allocator, or a later torch.rand on another control stream could be handed the block while the audio half of
-            # this batch still reads it (control_streams > 1 with a depth that is not a multiple of it)
-            if phase_u is None:
-                pu.record_stream(au)
-            if noise is None:
-                nz.record_stream(au)
+            # (the draws live in the slot's own buffers: the next tenant's control half waits for this batch's audio half
+            # - slot.ev_audio above - before it overwrites them)
         with torch.cuda.stream(au):
             au.wait_event(ready)
             au.wait_event(slot.ev_control)
