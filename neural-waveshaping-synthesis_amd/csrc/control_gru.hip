@@ -15,13 +15,16 @@
 // into the other half of a ping-pong LDS buffer: ONE workgroup barrier per step that waits on LDS only (raw s_barrier +
 // lgkmcnt(0); the 512 B h_t global store is never drained on the critical path), control values staged in LDS 1024
 // frames at a time.
-// Measured (MI355X, 500 steps, tools/gru_variants.py): this kernel 0.229 ms (0.458 us/step).  Round 1's layout - lane =
-// (unit, K-half), 16 ds_read_b128 per lane - 0.276 ms, of which the ablations price 0.29 us/step for the 96 packed FMAs
-// (one wave per SIMD issues one vector instruction per ~7 cycles whatever its class: 192 v_fmac_f32 instead took 1.05
-// us/step), 0.13 for the LDS broadcast of h, 0.04 for the transcendentals, 0.04 for the barrier.  Four units per lane
-// (4 reads, a longer reduction) 0.236 ms; eight waves (two per SIMD: the FMAs drop to 0.20 us/step, but reduction and
-// gate math are issued twice per SIMD) 0.285 ms; K-quarters interleaved at 16 B (the four addresses of a read in one 64 B
-// line) 0.238 ms; 4 K-slices + LDS partial-sum exchange + libm gates 0.457 ms (round 1).
+// Measured (MI355X, 500 steps, tools/gru_variants.py): this kernel 0.223 ms (0.446 us/step; 0.458 before round 3 pipelined
+// the reads of h by hand).  Cycle timeline of a step (variant 6, s_memtime probes, ~1070 cycles): LDS reads + 96 packed FMAs
+// ~640, cross-lane reduction ~125, gates ~125, h store + barrier ~110.  The FMA phase sits on what the vector pipe delivers:
+// tools/ubench/valu_rate.hip measures 6.4 cycles per v_pk_fma_f32 for a lone wave and 5.3-5.7 per SIMD with 2-8 waves, and the
+// same MAC rate from scalar v_fma_f32 (2.9-3.1 cycles each at >= 2 waves) - ~20-24 fp32 MACs per clock and SIMD whatever the
+// form, so the 49 152 MACs of a step cost >= 510-610 cycles on the four SIMDs of one CU.  Earlier measurements: round 1's
+// layout - lane = (unit, K-half), 16 ds_read_b128 per lane - 0.276 ms; 192 v_fmac_f32 instead of 96 packed FMAs 1.05
+// us/step; four units per lane (4 reads, a longer reduction) 0.236 ms; eight waves (two per SIMD: reduction and gate math
+// are issued twice per SIMD) 0.285 ms; K-quarters interleaved at 16 B (the four addresses of a read in one 64 B line) 0.238
+// ms; 4 K-slices + LDS partial-sum exchange + libm gates 0.457 ms (round 1).
 #include "nws_common.h"
 
 namespace {
@@ -42,7 +45,14 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // DBG != 0: timing ablations for nws_debug_control_gru (results wrong by design): 1 half the LDS reads of h, 2 half the
-// FMAs, 3 gates without transcendentals, 4 no workgroup barrier, 5 no LDS reads of h at all
+// FMAs, 3 gates without transcendentals, 4 no workgroup barrier, 5 no LDS reads of h at all, 6 correct results + a cycle
+// timeline of steps 200..207 of wave 0 (s_memtime after: barrier, FMA loop, reduction, gates; twice back to back at the
+// top for the probe's own cost) written over the head of gru_out[0] as int64
+__device__ __forceinline__ unsigned long long gru_tick(float pin) {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(pin) : "memory");
+  return t;
+}
 template <int DBG = 0>
 __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const float* __restrict__ control, int C, int T,
                                                              const float* __restrict__ h0, float* __restrict__ gru_out,
@@ -51,6 +61,7 @@ __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const
   const int tid = threadIdx.x;
   __shared__ __attribute__((aligned(16))) float h_lds[2][kH];
   __shared__ __attribute__((aligned(16))) float x_lds[2][kXChunk];  // control[:, 0:2] of the current chunk of frames
+  __shared__ unsigned long long ticks[DBG == 6 ? 8 * 6 : 1];
   // fused control-rate prologue of a forward (nws_control_gru_carry): the oscillator phase carries of utterance b are the
   // work of the EXTRA workgroup B + b of the same launch, on a CU of its own beside the recurrences (8 us there; as a
   // prologue of the recurrence's own workgroup they delayed its first step by 19 us, as a separate 64-workgroup launch in
@@ -112,6 +123,12 @@ __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const
     for (int tt = 0; tt < nt; ++tt) {
       const int t = t0 + tt;
       const int cur = t & 1;
+      const bool probe = DBG == 6 && t >= 200 && t < 208;
+      unsigned long long tk[6] = {0, 0, 0, 0, 0, 0};
+      if (probe) {
+        tk[0] = gru_tick(h_prev);
+        tk[1] = gru_tick(h_prev);
+      }
       const float x0 = x_lds[0][tt], x1 = x_lds[1][tt];
       const float ir = fmaf(wi_r1, x1, fmaf(wi_r0, x0, b_r));
       const float iz = fmaf(wi_z1, x1, fmaf(wi_z0, x0, b_z));
@@ -122,19 +139,33 @@ __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int g = 0; g < 3; ++g) acc[u][g] = f32x2{0.0f, 0.0f};
+      // four read buffers in rotation: the read of group q + 4 goes out as soon as group q has been consumed and stays
+      // there (left alone, hipcc issued reads 5..8 in pairs right in front of their first use: two exposed LDS latencies)
+      float4 hb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) hb[i] = hp[DBG == 1 ? (i & ~1) : i];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const float4 hv = DBG == 5 ? float4{h_prev, x0, x1, h_prev} : hp[DBG == 1 ? (q & ~1) : q];
+        const float4 hv = DBG == 5 ? float4{h_prev, x0, x1, h_prev} : hb[q & 3];
         const f32x2 h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
           for (int g = 0; g < 3; ++g) acc[u][g] = __builtin_elementwise_fma(wreg[u][g][2 * q], h01, acc[u][g]);
-        if (DBG == 2) continue;
+        if (DBG == 2) {
+          if (q + 4 < 8) hb[q & 3] = hp[q + 4];
+          continue;
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
           for (int g = 0; g < 3; ++g) acc[u][g] = __builtin_elementwise_fma(wreg[u][g][2 * q + 1], h23, acc[u][g]);
+        if (q + 4 < 8) hb[q & 3] = hp[DBG == 1 ? ((q + 4) & ~1) : q + 4];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (DBG == 6) {   // every accumulator is an input: no FMA can sink below the probe
+        asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]), "v"(acc[1][0]), "v"(acc[1][1]), "v"(acc[1][2]));
+        if (probe) tk[2] = gru_tick(acc[0][0].x);
       }
       float sg[3];
 #pragma unroll
@@ -147,19 +178,34 @@ __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const
       // sigmoid(x) = 1 / (1 + 2^(-x log2 e));  tanh(x) = 1 - 2 / (1 + 2^(2 x log2 e)) (saturates correctly: exp2 -> inf or 0);
       // hardware exp2 + reciprocal (each ~1 ulp): the error class of the libm forms inside torch's CPU GRU, a fraction of
       // their latency on the sequential critical path
+      if (probe) tk[3] = gru_tick(sg[0] + sg[1] + sg[2]);
       auto ex2 = [](float v) { return DBG == 3 ? 0.01f * v : __builtin_amdgcn_exp2f(v); };
       auto rcp = [](float v) { return DBG == 3 ? 0.5f * v : __builtin_amdgcn_rcpf(v); };
       const float r = rcp(1.0f + ex2(ir + sg[0]));
       const float z = rcp(1.0f + ex2(iz + sg[1]));
-      const float nn = fmaf(-2.0f, rcp(1.0f + ex2(fmaf(r, sg[2] + bh_n, in))), 1.0f);
-      const float hnew = fmaf(h_prev - nn, z, nn);
+      // h' = z h + (1 - z) n with n = 1 - 2 q:  h' = [z h + (1 - z)] - 2 (1 - z) q.  The bracket and the factor only need z,
+      // so ONE FMA follows the n gate's reciprocal; n itself (a rounding at magnitude 1) is never formed: against a float64
+      // GRU 1.9e-5 max-abs over 500 steps where "(h - n) z + n" gave 5.3e-5 and torch's CPU GRU 5.2e-5 (tools/gru_variants.py)
+      const float omz = 1.0f - z;
+      const float base = fmaf(z, h_prev, omz), fac = -2.0f * omz;
+      const float hnew = fmaf(fac, rcp(1.0f + ex2(fmaf(r, sg[2] + bh_n, in))), base);
       h_prev = hnew;
+      if (probe) tk[4] = gru_tick(hnew);
       if (writer) {
         h_lds[cur ^ 1][unit] = hnew;
         gru_out[((size_t)b * T + t) * kH + unit] = hnew;
       }
       if (DBG != 4) lds_barrier();
+      if (probe) {
+        tk[5] = gru_tick(hnew);
+        if (tid == 0)
+          for (int i = 0; i < 6; ++i) ticks[(t - 200) * 6 + i] = tk[i];
+      }
     }
+  }
+  if (DBG == 6) {
+    __syncthreads();
+    if (b == 0 && tid < 48 && T >= 208) reinterpret_cast<unsigned long long*>(gru_out)[tid] = ticks[tid];
   }
   if (hT != nullptr && writer) hT[(size_t)b * kH + unit] = h_prev;
 }
@@ -383,6 +429,7 @@ extern "C" int nws_debug_control_gru(int variant, const NwsWeights* w, const flo
     case 3: NWS_GRU_DBG(3); break;
     case 4: NWS_GRU_DBG(4); break;
     case 5: NWS_GRU_DBG(5); break;
+    case 6: NWS_GRU_DBG(6); break;
     default: return NWS_ERR_BAD_ARG;
   }
 #undef NWS_GRU_DBG

@@ -20,6 +20,7 @@ hipGraph and replayed (`graph=True`, the default): a 256-sample hop is then one 
 from __future__ import annotations
 
 import ctypes as C
+import time
 
 import torch
 
@@ -167,12 +168,15 @@ class NewtStream:
     def _check_weights(self):
         """A captured hop holds raw pointers into the engine's derived tables (fragment tables, LUT pairs, FIR design, IR
         spectrum).  If the engine has rebuilt them (somebody ran a forward after a weight update, `.to()`, `invalidate_cache`)
-        the graphs are dropped and re-captured; in-place updates nobody has told the engine about are looked for every 32nd
-        push (a full fingerprint walk costs ~12 us of host time: too much for every 256-sample hop)."""
+        the graphs are dropped and re-captured; in-place updates nobody has told the engine about are looked for at most every
+        250 ms of wall-clock (a full fingerprint walk costs ~12 us of host time: too much for every 256-sample hop, nothing once
+        per sixteen 16 ms hops)."""
         eng = self.eng
-        self._pushes = getattr(self, "_pushes", 0) + 1
-        if self._pushes % 32 == 0 and eng._w is not None and eng._fingerprint() != eng._fp:
-            eng._wd()                                  # rebuilds (drains the device first)
+        now = time.monotonic()
+        if now - self.__dict__.get("_last_walk", 0.0) >= 0.25:
+            self._last_walk = now
+            if eng._w is not None and eng._fingerprint() != eng._fp:
+                eng._wd()                              # rebuilds (drains the device first)
         if eng._w is not self.__dict__.get("_w_seen"):
             if self._graphs:
                 torch.cuda.synchronize(self.dev)

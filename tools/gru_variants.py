@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Timing of control_gru_kernel and its ablation variants (nws_debug_control_gru; see include/nws_hip.h) at B=64 and B=1,
-T=500.  Variant 0 is the product kernel; the others return wrong values by design.  GPU only."""
+T=500.  Variant 0 is the product kernel; 1-5 return wrong values by design; 6 is the product arithmetic with s_memtime
+probes: its cycle timeline of steps 200..207 is printed last.  GPU only."""
 import ctypes as C
 import importlib
 import os
@@ -41,3 +42,13 @@ for B in (64, 1):
             ts.append(e0.elapsed_time(e1) / 20)
         err = float((out - ref).abs().max())
         print(f"B={B} variant {v}: min {min(ts):.4f} ms = {min(ts) * 1e3 / T:.3f} us/step  max|d| vs product {err:.2e}")
+
+    if T >= 208:
+        _lib.check(_lib.lib().nws_debug_control_gru(6, C.byref(w), control.data_ptr(), B, 2, T, out.data_ptr(), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        tk = out.view(-1)[:96].view(torch.int64).cpu().view(8, 6)
+        d = (tk[:, 1:] - tk[:, :-1]).double()
+        probe = float(d[:, 0].median())
+        names = ("reads+FMAs", "reduction", "gates", "h store+barrier")
+        print(f"B={B} timeline (cycles per phase, median of 8 steps, the probe's own {probe:.0f} removed): "
+              + ", ".join(f"{n} {float(d[:, i + 1].median()) - probe:.0f}" for i, n in enumerate(names)))
