@@ -582,6 +582,7 @@ struct MlpLds64 {
   float gb[4][NWS_HIDDEN];
 };
 static_assert(sizeof(MlpLds64) <= 160 * 1024, "LDS");
+static_assert(8 * kFT * kPS * 4 <= 2 * kXtBytes2, "eight per-wave store patches inside the dead E buffer");
 
 template <bool TAPS>
 __global__ __launch_bounds__(512, 2) void frame_mlps64_kernel(NwsWeights w, const float* __restrict__ gru_out, int T,
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(512, 2) void frame_mlps64_kernel(NwsWeights w, cons
   f32x16 acc0, acc1;
 
   __builtin_amdgcn_sched_barrier(0);
-  load_frags<8>(A, F + (path ? frag_map(5).base : frag_map(0).base), mt, lane);  // proj | hgen hidden 0
+  load_frags<8>(A, F + frag_map(0).base, mt, lane);  // proj
   for (int e = tid; e < kFT2 * (NWS_HIDDEN / 4); e += 512) {
     const int f = e >> 5, c4 = (e & 31) * 4;
     float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -620,24 +621,20 @@ __global__ __launch_bounds__(512, 2) void frame_mlps64_kernel(NwsWeights w, cons
   }
   __syncthreads();
 
-  // ---- emb = proj(gru_out) -> E (waves 0-3) ----
-  if (path == 0) {
+  // ---- emb = proj(gru_out) -> E: the layer has 4 M-tiles x 2 N-tiles = one tile per wave (wave = (mt, N-tile `path`)) ----
+  {
     float vb[16];
     load_lane_params(vb, w.proj_b, mt, lane);
-    mma_tile1<8, XB>(A, X, lane, acc0);
-    mma_tile1<8, XB>(A, X + kTileB, lane, acc1);
+    mma_tile1<8, XB>(A, X + path * kTileB, lane, acc0);
     __builtin_amdgcn_sched_barrier(0);
-    load_frags<8>(A, F + frag_map(1).base, mt, lane);  // newt hidden 0
+    load_frags<8>(A, F + (path ? frag_map(5).base : frag_map(1).base), mt, lane);  // hgen hidden 0 | newt hidden 0
     float v[16];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int r = 0; r < 16; ++r) v[r] = vb[r] + acc0[r];
+    store_tile_xt<XB>(E + path * kTileB, 32 * mt, v, lane);
+    if (TAPS && emb_out != nullptr && 32 * path + col < frames_valid) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = vb[r] + (nt ? acc1[r] : acc0[r]);
-      store_tile_xt<XB>(E + nt * kTileB, 32 * mt, v, lane);
-      if (TAPS && emb_out != nullptr && 32 * nt + col < frames_valid) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) emb_out[((size_t)b * NWS_HIDDEN + 32 * mt + frag_row(r, half)) * T + t0 + 32 * nt + col] = v[r];
-      }
+      for (int r = 0; r < 16; ++r) emb_out[((size_t)b * NWS_HIDDEN + 32 * mt + frag_row(r, half)) * T + t0 + 32 * path + col] = v[r];
     }
   }
   __syncthreads();
@@ -756,23 +753,18 @@ __global__ __launch_bounds__(512, 2) void frame_mlps64_kernel(NwsWeights w, cons
       }
     }
   }
-  // ---- fir = D[128 .. 255] * H  (upper half-taps = 4 M-tiles, K = 144 padded): waves 0-3 ----
+  // ---- fir = D[128 .. 255] * H  (upper half-taps = 4 M-tiles, K = 144 padded) x 2 N-tiles: one tile per wave ----
   AFrag<9> A9;
-  if (path == 0) {
-    __builtin_amdgcn_sched_barrier(0);
-    load_frags<9>(A9, F + frag_map(9).base, mt, lane);
-  }
+  __builtin_amdgcn_sched_barrier(0);
+  load_frags<9>(A9, F + frag_map(9).base, mt, lane);
   __syncthreads();
-  if (path == 0) {
+  {
     float v[16];
-    mma_tile1<9, XB>(A9, Z, lane, acc0);
-    mma_tile1<9, XB>(A9, Z + kTileB, lane, acc1);
+    mma_tile1<9, XB>(A9, Z + path * kTileB, lane, acc0);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = nt ? acc1[r] : acc0[r];
-      store_tile_frame_major(patch, v, lane, fir_out + ((size_t)b * T + t0 + 32 * nt) * NWS_FIR_HALF + 32 * mt, NWS_FIR_HALF, fv(nt));
-    }
+    for (int r = 0; r < 16; ++r) v[r] = acc0[r];
+    float* patch8 = reinterpret_cast<float*>(E) + wave * (kFT * kPS);     // E is dead for every wave by now
+    store_tile_frame_major(patch8, v, lane, fir_out + ((size_t)b * T + t0 + 32 * path) * NWS_FIR_HALF + 32 * mt, NWS_FIR_HALF, fv(path));
   }
 }
 

@@ -2,7 +2,7 @@
 """What the control half costs the pipelined step: the audio halves alone (frame MLPs, oscillator + NEWT, noise, reverb) of
 prepared batches alternating over two audio streams, with pieces of the control half running beside them on a side stream
 WITHOUT dependencies.  One configuration per process (HIP maps streams onto a few hardware queues; stale streams of an
-earlier configuration would share them):  WHAT=none|rng|gru|all python tools/audio_only_rate.py.  GPU only.
+earlier configuration would share them):  WHAT=none|rng|gru|grub|all python tools/audio_only_rate.py.  GPU only.
 Measured (MI355X, B=64, T=500): audio halves alone 0.3455 ms/step on two streams (0.375 on one, 0.356 on three); with the
 per-utterance recurrence + carries beside them 0.3833-0.386; with the two RNG draws as well 0.387 - i.e. the control half
 costs the pipelined step ~40 us although it is off the critical path: its 64 workgroups hold 248 of the 512 registers of
@@ -53,6 +53,8 @@ with torch.no_grad():
                         torch.rand(128 * T - 1, device="cuda")
                     if what in ("gru", "all"):
                         eng.forward_control(f0, control, spare[i % 4], batched_gru=False)
+                    if what == "grub":      # the batched MFMA recurrence instead: 4 workgroups for 64 utterances
+                        eng.forward_control(f0, control, spare[i % 4], batched_gru=True)
             with torch.cuda.stream(streams[i % n_audio]):
                 eng.forward_audio(f0, B, T, pu, nz, slots[i % NSLOT], out=outs[i % NSLOT])
         host = (time.perf_counter() - t0) / K * 1e3
