@@ -148,7 +148,7 @@ struct NoiseMfmaLds {
   _Float16 rlo[2][8][kCopyHalfs];
   _Float16 hhi[kUtt][kRowHalfs];   // HALF the taps (128) of the frame being accumulated, times the utterance's scale:
   _Float16 hlo[kUtt][kRowHalfs];   // staging half rows keeps the block at 36 KB of LDS = 4 workgroups per CU
-  float unscale[kUtt];             // 1 / (tap scale * noise scale) per utterance
+  __attribute__((aligned(16))) float unscale[kUtt];   // 1 / (tap scale * noise scale) per utterance
   float win[3 * kHop];             // padded noise [128 (t-1), 128 (t-1) + 384), times the noise scale: frames t-1 and t
 };
 
@@ -311,19 +311,43 @@ __global__ __launch_bounds__(256, 4) void fir_noise_mfma_kernel(const float* __r
   accumulate(1, 0, std::false_type{});
   __syncthreads();
   stage_rows(prv, 1);
+  // the 16 values of the other branch this lane adds (cat + sum(1)): requested here, all at once, so that they arrive under
+  // the last 24 MFMAs (as "if (b < B) out = add_in[o] + v" per row hipcc serialised 16 load -> wait -> store round trips to
+  // memory at the end of every wave: 40 % of the kernel's time)
+  float addv[16];
+  const bool has_add = add_in != nullptr;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+    const int b = b0 + row < B ? b0 + row : B - 1;          // clamped: the load is always in bounds, the store is masked
+    addv[r] = has_add ? add_in[(size_t)b * N + (size_t)t * kHop + j] : 0.0f;
+  }
   __syncthreads();
   accumulate(1, 1, std::false_type{});
 
   const float ola = t == 0 ? 1.0f : 0.5f;  // overlap-add count: 1 in the first hop, else 2
+  float vout[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
-    const int b = b0 + row;
-    if (b < B) {
-      const size_t o = (size_t)b * N + (size_t)t * kHop + j;
-      float v = acc[r] * (ola * L.unscale[row]);
-      if (add_in != nullptr) v = add_in[o] + v;
-      out[o] = v;
+  for (int g = 0; g < 4; ++g) {
+    const float4 us = *reinterpret_cast<const float4*>(&L.unscale[8 * g + 4 * kh]);   // rows 8 g + 4 kh + (0..3)
+    const float u4[4] = {us.x, us.y, us.z, us.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v = acc[4 * g + i] * (ola * u4[i]);
+      vout[4 * g + i] = has_add ? addv[4 * g + i] + v : v;
+    }
+  }
+  // every value is final before the first store: 16 stores back to back, nothing to wait for in between (with the load, or
+  // a per-row branch, next to each store hipcc put an s_waitcnt vmcnt(0) - the previous store's acknowledgement - in front of it)
+  float* o = out + (size_t)(b0 + 4 * kh) * N + (size_t)t * kHop + j;
+  if (b0 + kUtt <= B) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * N] = vout[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2);
+      if (b0 + 4 * kh + row < B) o[(size_t)row * N] = vout[r];
     }
   }
 }
