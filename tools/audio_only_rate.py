@@ -32,7 +32,9 @@ pu = torch.rand(101, device="cuda")
 nz = torch.rand(128 * T - 1, device="cuda")
 with torch.no_grad():
     streams = [torch.cuda.Stream() for _ in range(n_audio)]
-    side = torch.cuda.Stream(priority=int(os.environ.get("PRIO", -1))) if what != "none" else None
+    n_side = int(os.environ.get("SIDE_STREAMS", 1))
+    sides = [torch.cuda.Stream(priority=int(os.environ.get("PRIO", -1))) for _ in range(n_side)] if what != "none" else None
+    side = sides[0] if sides else None
     slots = [eng.new_workspace(B, T) for _ in range(4)]
     spare = [eng.new_workspace(B, T) for _ in range(4)]
     for ws in slots + spare:
@@ -47,7 +49,7 @@ with torch.no_grad():
         t0 = time.perf_counter()
         for i in range(K):
             if side is not None:
-                with torch.cuda.stream(side):
+                with torch.cuda.stream(sides[i % n_side]):
                     if what in ("rng", "all"):
                         torch.rand(101, device="cuda")
                         torch.rand(128 * T - 1, device="cuda")
@@ -60,4 +62,4 @@ with torch.no_grad():
         host = (time.perf_counter() - t0) / K * 1e3
         torch.cuda.synchronize()
         el = (time.perf_counter() - t0) / K * 1e3
-    print(f"{n_audio} audio stream(s), side stream: {what}: {el:.4f} ms/step (host submit {host:.4f} ms/step)")
+    print(f"{n_audio} audio stream(s), {n_side if side is not None else 0} side stream(s): {what}: {el:.4f} ms/step (host submit {host:.4f} ms/step)")
