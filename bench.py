@@ -878,7 +878,7 @@ def main():
                 kernel_roofline("reverb (col125_fwd + row + col125_inv)", pmc, st.get("reverb"),
                                 hbm_note="memory-latency bound four-step FFT: 3 passes over (B, L) complex planes")]
             if pmc:   # the reverb's three launches: HBM traffic summed
-                tot = sum(pmc["kernels"].get(kn, {}).get("hbm_bytes_per_launch", 0.0) for kn in ("col125_fwd_kernel", "row_kernel", "col125_inv_kernel"))
+                tot = sum(pmc["kernels"].get(kn, {}).get("hbm_bytes_per_launch", 0.0) for kn in ("col125_fwd_kernel", "row512_kernel", "row_kernel", "col125_inv_kernel"))
                 if tot and st.get("reverb"):
                     roofline_all[-1]["hbm"] = {"traffic": tot, "achieved": tot / (st["reverb"] * 1e-3) / 1e12, "peak": PEAK_HBM_TBS,
                                                "unit": "TB/s", "frac": tot / (st["reverb"] * 1e-3) / 1e12 / PEAK_HBM_TBS}
