@@ -24,7 +24,10 @@ struct GLerp {
   float w0, w1;
 };
 __device__ __forceinline__ GLerp g_lerp_coeff(int n, int T, float scale) {
-  float src = ((float)n + 0.5f) * scale - 0.5f;
+  // torch's CPU upsample_linear1d, bit for bit at every hop: the source index is ONE fused multiply-add (its AVX2 / AVX-512
+  // builds contract scale * (dst + 0.5) - 0.5), the output fma(w0, x0, fl(w1 * x1)); for power-of-two hops the product is exact
+  // and nothing depends on it, at hop 10 / 25 / 40 the two-rounding form moved 1-3 % of the samples by an ulp
+  float src = fmaf((float)n + 0.5f, scale, -0.5f);
   src = src < 0.0f ? 0.0f : src;
   const int i0 = (int)src;
   GLerp c;
@@ -396,6 +399,69 @@ __global__ __launch_bounds__(256) void g_reverb_direct_kernel(const float* __res
   if (n < N) y[(size_t)b * N + n] = xb[n] + acc;
 }
 
+// ---- reverb at an ODD circular length: what the reference's rfft / irfft pair really returns there ----------------------
+// Reverb.forward (shaping.py:161-173) multiplies torch.fft.rfft of the two length-Lo signals ((Lo + 1) / 2 bins) and calls
+// torch.fft.irfft WITHOUT a length: the inverse then assumes an even signal of M = 2 (bins - 1) = Lo - 1 samples.  For even
+// Lo that is the circular convolution; for odd Lo (a reverb of an odd number of samples, e.g. sr = 11025, or an odd N beyond
+// it) it is
+//     y[n] = x[n] + (1/M) [ Re Y_0 + 2 sum_{0<k<M/2} Re(Y_k e^{2 pi i n k / M}) + Re(Y_{M/2}) (-1)^n ],   Y_k = X_k H_k (DFTs of length Lo)
+// - not a convolution, but what a drop-in has to return (found by the random-configuration sweep of tests/test_gpu_generic.py).
+// Evaluated as written, in float64 (the reference's transforms are fp32: this is closer to their exact value than they are
+// to each other across FFT libraries): O(Lo^2) per utterance, the slow-but-correct class of this file.
+__global__ void g_odd_tables_kernel(int Lo, double2* __restrict__ twLo, double2* __restrict__ twM) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < Lo) {
+    double s, c;
+    sincospi(2.0 * (double)j / (double)Lo, &s, &c);
+    twLo[j] = make_double2(c, s);
+  }
+  if (j < Lo - 1) {
+    double s, c;
+    sincospi(2.0 * (double)j / (double)(Lo - 1), &s, &c);
+    twM[j] = make_double2(c, s);
+  }
+}
+// X[row][k] = sum_n v[n] e^{-2 pi i n k / Lo}, k < K; v = x row (len samples), or [0, ir] when shift_one (ir_[0] = 0)
+__global__ void g_odd_dft_kernel(const float* __restrict__ v, int len, int row_stride, int shift_one, int Lo, int K,
+                                 const double2* __restrict__ twLo, double2* __restrict__ X) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = blockIdx.y;
+  if (k >= K) return;
+  const float* vr = v + (size_t)row * row_stride;
+  double re = 0.0, im = 0.0;
+  int idx = shift_one ? k % Lo : 0;          // n k mod Lo, advanced by k per sample
+  for (int n = 0; n < len; ++n) {
+    const double2 w = twLo[idx];
+    const double a = (double)vr[n];
+    re += a * w.x;
+    im -= a * w.y;
+    idx += k;
+    if (idx >= Lo) idx -= Lo;
+  }
+  X[(size_t)row * K + k] = make_double2(re, im);
+}
+__global__ void g_odd_inverse_kernel(const float* __restrict__ x, const double2* __restrict__ X, const double2* __restrict__ H,
+                                     int N, int M, int K, const double2* __restrict__ twM, float* __restrict__ y) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (n >= N) return;
+  const double2* Xr = X + (size_t)b * K;
+  double acc = 0.0;
+  int idx = n % M;                            // n k mod M for k = 1
+  const int step = idx;
+  for (int k = 1; k < K - 1; ++k) {
+    const double2 a = Xr[k], h = H[k], w = twM[idx];
+    const double yr = a.x * h.x - a.y * h.y, yi = a.x * h.y + a.y * h.x;
+    acc += yr * w.x - yi * w.y;
+    idx += step;
+    if (idx >= M) idx -= M;
+  }
+  const double y0 = Xr[0].x * H[0].x - Xr[0].y * H[0].y;
+  const double yq = Xr[K - 1].x * H[K - 1].x - Xr[K - 1].y * H[K - 1].y;
+  const double wet = (y0 + 2.0 * acc + ((n & 1) ? -yq : yq)) / (double)M;
+  y[(size_t)b * N + n] = x[(size_t)b * N + n] + (float)wet;
+}
+
 bool shaper_ok(const NwsShaperDesc* d) {
   if (!d || d->n_shapers <= 0) return false;
   if (d->lut) return d->lut_size >= 2 && d->lut_max > d->lut_min;
@@ -580,6 +646,23 @@ int nws_g_reverb_direct(const float* x, const float* ir, int ir_len, int B, int 
   if (!x || !ir || !y || ir_len <= 0 || B <= 0 || N <= 0) return NWS_ERR_BAD_ARG;
   if (B > 65535 || x == y) return NWS_ERR_UNSUPPORTED;
   const int Lc = N > ir_len + 1 ? N : ir_len + 1;
+  if (Lc & 1) {
+    // odd circular length: the reference's own (non-convolution) result, see g_odd_* above; scratch is stream-ordered
+    if (Lc > 65537 || Lc < 3) return NWS_ERR_UNSUPPORTED;
+    const int M = Lc - 1, K = M / 2 + 1;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bytes = ((size_t)Lc + M + K + (size_t)B * K) * sizeof(double2);
+    double2* buf = nullptr;
+    if (hipMallocAsync(reinterpret_cast<void**>(&buf), bytes, st) != hipSuccess || !buf) return NWS_ERR_WORKSPACE;
+    double2 *twLo = buf, *twM = twLo + Lc, *H = twM + M, *X = H + K;
+    g_odd_tables_kernel<<<(Lc + 255) / 256, 256, 0, st>>>(Lc, twLo, twM);
+    g_odd_dft_kernel<<<dim3((K + 127) / 128, 1), 128, 0, st>>>(ir, ir_len, 0, 1, Lc, K, twLo, H);
+    g_odd_dft_kernel<<<dim3((K + 127) / 128, B), 128, 0, st>>>(x, N, N, 0, Lc, K, twLo, X);
+    g_odd_inverse_kernel<<<dim3((N + 127) / 128, B), 128, 0, st>>>(x, X, H, N, M, K, twM, y);
+    const hipError_t e = hipGetLastError();
+    (void)hipFreeAsync(buf, st);
+    return e == hipSuccess ? NWS_OK : (int)e;
+  }
   g_reverb_direct_kernel<<<dim3((N + 255) / 256, B), 256, (1280 + 1024) * sizeof(float), (hipStream_t)stream>>>(x, ir, ir_len, N,
                                                                                                                Lc, y);
   NWS_CHECK_LAUNCH();

@@ -17,7 +17,7 @@ Fixtures written:
   g6_highf0.npz       B=1,T=500, F0 1-2 kHz (cumsum ~1e8, large sine arguments)
   weights_fl.npz / weights_tpt.npz   the other two shipped instruments (checkpoints/nws/{fl,tpt}/last.ckpt), same layout
   g7_fl.npz / g7_tpt.npz             B=1,T=125 (1 s) realistic vector per instrument: y_newt, y_fast, draws
-  g8_small.npz / g8_odd.npz          two NON-default gin configurations (random init, recorded weights + gin text): inputs, draws,
+  g8_small / g8_odd / g8_oddlen .npz three NON-default gin configurations (random init, recorded weights + gin text): inputs, draws,
                                      stage taps, y_newt, y_fast   (`... make_golden.py generic` regenerates only these)
 (`python tests/golden/make_golden.py instruments` regenerates only the fl / tpt four.)
 The RNG draws made inside forward are recorded by wrapping torch.rand / torch.rand_like.
@@ -276,6 +276,32 @@ NeuralWaveshaping.sample_rate = 8000
 NeuralWaveshaping.control_hop = 10
 NeuralWaveshaping.n_waveshapers = 5
 """,
+    # found by the random-configuration sweep of tests/test_gpu_generic.py: a reverb of an ODD number of samples (rfft of 1029
+    # points, irfft back to 1028: shaping.py:171-173 passes no length) and a hop that is not a power of two with F0 up to 0.3 sr
+    # over 40 frames (the upsampling's fused index arithmetic decides single ulps of a phase that reaches thousands of radians)
+    "g8_oddlen": """
+Reverb.sr = 1029
+Reverb.length_in_seconds = 1
+noise_synth/FIRNoiseSynth.hop_length = 25
+noise_synth/FIRNoiseSynth.ir_length = 60
+noise_synth/TimeDistributedMLP.depth = 3
+noise_synth/TimeDistributedMLP.out_size = 31
+noise_synth/TimeDistributedMLP.hidden_size = 12
+noise_synth/TimeDistributedMLP.in_size = 21
+TrainableNonlinearity.depth = 3
+NEWT.shaping_fn_size = 5
+NEWT.out_channels = 2
+NEWT.control_embedding_size = 21
+NEWT.n_waveshapers = 9
+HarmonicOscillator.sample_rate = 8000
+HarmonicOscillator.n_harmonics = 24
+ControlModule.embedding_size = 21
+ControlModule.hidden_size = 25
+ControlModule.control_size = 2
+NeuralWaveshaping.sample_rate = 8000
+NeuralWaveshaping.control_hop = 25
+NeuralWaveshaping.n_waveshapers = 9
+""",
 }
 
 
@@ -299,11 +325,14 @@ def generic_configs():
             model.newt.mlp.net[9].bias[:2 * S] *= 0.5
             model.newt.shaping_fn.input_scale.mul_(0.3)
         exact_newt = model.newt
-        fast_newt = FastNEWT(exact_newt, table_size=1024 if name == "g8_odd" else 4096, table_min=-4.0 if name == "g8_odd" else -3.0)
-        B, T = (2, 16) if name == "g8_small" else (3, 50)
+        fast_newt = FastNEWT(exact_newt, table_size=4096 if name == "g8_small" else 1024, table_min=-3.0 if name == "g8_small" else -4.0)
+        B, T = {"g8_small": (2, 16), "g8_odd": (3, 50), "g8_oddlen": (2, 40)}[name]
         torch.manual_seed(5)
         f0 = 150.0 + 500.0 * torch.rand(B, 1, 1) + 30.0 * torch.randn(B, 1, T).cumsum(-1) / 4
-        f0[-1, 0, T // 2:] = 0.6 * model.sample_rate                       # above Nyquist: every harmonic masked
+        if name == "g8_oddlen":
+            f0 = 100.0 + 0.3 * model.sample_rate * torch.rand(B, 1, 1) * torch.rand(B, 1, T)
+        else:
+            f0[-1, 0, T // 2:] = 0.6 * model.sample_rate                   # above Nyquist: every harmonic masked
         control = torch.randn(B, 3, T)                                     # one extra channel, ignored (:70-71)
         taps = {}
 

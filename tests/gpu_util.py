@@ -19,7 +19,8 @@ def record(name, **metrics):
             data = json.load(open(REPORT))
         except Exception:
             data = {}
-    data[name] = {k: (float(v) if np.isscalar(v) or isinstance(v, (np.floating, float)) else v) for k, v in metrics.items()}
+    data[name] = {k: (float(v) if not isinstance(v, str) and (np.isscalar(v) or isinstance(v, (np.floating, float))) else v)
+                  for k, v in metrics.items()}
     json.dump(data, open(REPORT, "w"), indent=1, sort_keys=True)
 
 

@@ -1,6 +1,6 @@
 """-m gpu: the runtime-size path (csrc/generic.hip) - NeuralWaveshaping.forward and the sub-modules for NON-default gin
 configurations, against vectors recorded from the real reference built from the same gin text (tests/golden/make_golden.py
-generic: g8_small.npz, g8_odd.npz).  Bar: BASELINE.json's 1e-4 RMS end to end; stage tolerances next to each check."""
+generic: g8_small.npz, g8_odd.npz, g8_oddlen.npz), and a seeded sweep of random configurations against the oracle.  Bar: BASELINE.json's 1e-4 RMS end to end; stage tolerances next to each check."""
 import json
 
 import numpy as np
@@ -13,7 +13,7 @@ from gpu_util import dev, maxabs, record
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["g8_small", "g8_odd"])
+@pytest.fixture(params=["g8_small", "g8_odd", "g8_oddlen"])
 def cfg(request):
     import nws_amd as nws
 
@@ -156,3 +156,88 @@ def test_asymmetric_window_leaves_the_fused_path(weights):
     assert e <= 1e-4, e
     ref_n = OracleNEWT(w2, fast=False).fir_noise(H.cpu(), nzs).numpy()
     assert maxabs(out.cpu().numpy(), ref_n) <= 1e-6
+
+
+def _random_gin(rng):
+    """A random point of the reference's gin surface (every size the modules take, models/neural_waveshaping.py:31-62), small
+    enough for the oracle to finish in a second."""
+    hop = int(rng.choice([8, 12, 16, 25, 40]))
+    ir = 2 * int(rng.integers(hop // 2 + 1, 2 * hop + 1))                  # even, >= hop + 2
+    S = int(rng.integers(1, 13))
+    emb = int(rng.integers(4, 25))
+    sr = int(rng.choice([8000, 16000, 22050]))
+    text = f"""
+Reverb.sr = {int(rng.integers(300, 1200))}
+Reverb.length_in_seconds = 1
+noise_synth/FIRNoiseSynth.hop_length = {hop}
+noise_synth/FIRNoiseSynth.ir_length = {ir}
+noise_synth/TimeDistributedMLP.depth = {int(rng.integers(3, 6))}
+noise_synth/TimeDistributedMLP.out_size = {ir // 2 + 1}
+noise_synth/TimeDistributedMLP.hidden_size = {int(rng.integers(5, 31))}
+noise_synth/TimeDistributedMLP.in_size = {emb}
+TrainableNonlinearity.depth = {int(rng.integers(2, 5))}
+NEWT.shaping_fn_size = {int(rng.integers(2, 10))}
+NEWT.out_channels = {int(rng.integers(1, 3))}
+NEWT.control_embedding_size = {emb}
+NEWT.n_waveshapers = {S}
+HarmonicOscillator.sample_rate = {sr}
+HarmonicOscillator.n_harmonics = {int(rng.integers(2, 41))}
+ControlModule.embedding_size = {emb}
+ControlModule.hidden_size = {int(rng.integers(3, 41))}
+ControlModule.control_size = 2
+NeuralWaveshaping.sample_rate = {sr}
+NeuralWaveshaping.control_hop = {hop}
+NeuralWaveshaping.n_waveshapers = {S}
+"""
+    return text, hop, sr, S
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18, 19, 20])
+def test_random_gin_configurations_match_the_oracle(seed):
+    """Ten seeded random points of the gin surface, randomly initialised by the product's own constructors: the runtime-size
+    path (csrc/generic.hip) against the oracle run on the same state dict and draws, exact shapers and FastNEWT.  The oracle is
+    pinned on the reference for two such configurations (tests/test_oracle_golden.py, g8_*); this sweep walks sizes nobody chose
+    by hand (1 shaper, 2 harmonics, a GRU of 3 units, odd hops ...).  Its first run found two deviations nobody had looked for: the
+    upsampling's source index must be ONE fused multiply-add to reproduce torch's CPU kernel at hops that are not powers of two,
+    and a reverb of an odd number of samples goes through rfft(Lo) / irfft(Lo - 1) in the reference, which is not a circular
+    convolution (csrc/generic.hip g_odd_*); both are now also pinned on the real reference (g8_oddlen.npz)."""
+    import nws_amd as nws
+    from oracle.newt_oracle import OracleNEWT
+
+    rng = np.random.default_rng(seed)
+    text, hop, sr, S = _random_gin(rng)
+    nws.gin.clear_config()
+    try:
+        nws.gin.parse_config(text)
+        torch.manual_seed(seed)
+        m = nws.NeuralWaveshaping().eval()
+        with torch.no_grad():
+            # as tests/golden/make_golden.py does for g8_*: an audible IR, and the LUT argument kept inside the table
+            L = m.reverb.ir.numel()
+            m.reverb.ir.copy_(torch.randn_like(m.reverb.ir) * 0.05 * torch.exp(-torch.arange(L) / (L / 4.0)))
+            m.newt.mlp.net[-1].weight[:2 * S] *= 0.5
+            m.newt.mlp.net[-1].bias[:2 * S] *= 0.5
+            m.newt.shaping_fn.input_scale.mul_(0.3)
+        w = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+        m = m.cuda()
+        assert not m._engine.specialised()
+        B, T = int(rng.integers(1, 4)), int(rng.integers(3, 24))
+        f0 = (100.0 + 0.3 * sr * rng.random((B, 1, 1)) * rng.random((B, 1, T))).astype(np.float32)   # some harmonics cross Nyquist
+        control = rng.standard_normal((B, 2, T)).astype(np.float32)
+        K = w["harmonic_mixer.weight"].shape[1]
+        pu = rng.random(K).astype(np.float32)
+        nz = rng.random(hop * T - 1).astype(np.float32)
+        kw = dict(sample_rate=sr, control_hop=hop, table_size=512, table_min=-4.0, table_max=4.0)
+        for fast in (False, True):
+            if fast:
+                m.newt = nws.FastNEWT(m.newt, table_size=512, table_min=-4.0, table_max=4.0)
+            ref = OracleNEWT(w, fast=fast, lut_python_loop=False, **kw)(f0, control, pu, nz).numpy()
+            with torch.no_grad():
+                y = m(dev(f0), dev(control), phase_u=dev(pu), noise=dev(nz)).cpu().numpy()
+            assert y.shape == ref.shape, (y.shape, ref.shape)
+            e, scale = rms(y - ref), max(rms(ref), 1e-3)
+            record(f"generic_random_seed{seed}_{'fast' if fast else 'exact'}", rms_err=e, out_rms=rms(ref), gin=" ".join(text.split()))
+            assert e <= 1e-4 and e <= 1e-5 * scale, (seed, fast, e, rms(ref), text)     # measured: 0.5 .. 1.1e-7 on signals of 0.08 .. 0.46 RMS
+    finally:
+        nws.gin.clear_config()
+        nws.gin.parse_config_file(nws.DEFAULT_GIN)

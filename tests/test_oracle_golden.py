@@ -98,7 +98,7 @@ def test_g5_lut_bit_exact(oracles):
     assert np.array_equal(g["probe_out"][:, -1], g["probe_out"][:, -2])
 
 
-@pytest.mark.parametrize("name", ["g8_small", "g8_odd"])
+@pytest.mark.parametrize("name", ["g8_small", "g8_odd", "g8_oddlen"])
 def test_g8_non_default_gin_configurations(name):
     """The oracle is generic in every gin-configurable size; pinned on two non-default configurations recorded from the
     real reference (random init; 60 harmonics / 32 shapers of width 16, depth 3 / GRU 96 / embedding 80 / hop 64 / 128-tap
