@@ -663,6 +663,31 @@ def test_batch64_rows_match_single_and_oracle(models, oracle):
         assert e <= 1e-4
 
 
+@pytest.mark.parametrize("B,T", [(1, 2), (3, 31), (15, 33), (16, 64), (17, 65), (33, 129), (130, 70), (70, 257)])
+def test_shape_sweep_matches_the_oracle(models, oracle, B, T):
+    """Batch / frame counts on both sides of every kernel-selection threshold of the fused path: fewer than 16 utterances (the
+    per-utterance noise kernel) and more (the shared-noise MFMA form, with partial 32-utterance tiles: 17, 33, 130), fewer than
+    256 frame tiles (32-frame MLP kernel) and more (64-frame tiles with a partial last tile: T = 70, 257), odd batch sizes (the
+    reverb packs two utterances per transform), circular lengths 32 000 (row pass of 256 points) and 32 896 = 128 x 257 (the MFMA
+    column pass), the time-domain reverb of short buffers (T = 2).  Three rows of each against the oracle, exact and FastNEWT;
+    rows with F0 = 0 and F0 beyond Nyquist ride along."""
+    g = torch.Generator().manual_seed(1000 * B + T)
+    f0 = 80.0 + 1500.0 * torch.rand(B, 1, 1, generator=g) * (0.5 + torch.rand(B, 1, T, generator=g))
+    f0[0, 0, : T // 2] = 0.0
+    f0[-1, 0, T // 2:] = 9000.0
+    control = torch.randn(B, 2, T, generator=g)
+    pu, nz = torch.rand(101, generator=g), torch.rand(128 * T - 1, generator=g)
+    rows = sorted({0, B // 2, B - 1})
+    for which, (m, o) in enumerate(zip(models, oracle)):
+        with torch.no_grad():
+            y = m(f0.cuda(), control.cuda(), phase_u=pu.cuda(), noise=nz.cuda()).cpu().numpy()
+        assert y.shape == (B, 128 * T)
+        ref = o(f0[rows], control[rows], pu, nz).numpy()
+        errs = [rms(y[r] - ref[i]) for i, r in enumerate(rows)]
+        record(f"shape_sweep_B{B}_T{T}_{'fast' if which else 'exact'}", rms_err_max=max(errs), out_rms=rms(ref))
+        assert max(errs) <= 1e-4 and max(errs) <= 2e-5 * max(rms(ref), 1e-3), (B, T, which, errs, rms(ref))
+
+
 def test_default_rng_path_and_determinism(models):
     _, fast = models
     f0 = 220 + 50 * torch.rand(2, 1, 16, device="cuda")
