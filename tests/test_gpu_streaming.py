@@ -19,12 +19,12 @@ def setup(weights):
     return build_model(True), OracleNEWT(weights, fast=True, lut_python_loop=False), weights
 
 
-@pytest.mark.parametrize("chunks", [[60], [1, 7, 16, 4, 31, 1], [2] * 30, [13, 47]])
-def test_stream_equals_one_shot(setup, chunks):
+@pytest.mark.parametrize("chunks,B", [([60], 3), ([1, 7, 16, 4, 31, 1], 3), ([2] * 30, 3), ([13, 47], 3),
+                                      ([1, 7, 16, 4, 31, 1], 17), ([2] * 12 + [20], 33)])   # >= 16 streams: the shared-noise MFMA kernel on windows
+def test_stream_equals_one_shot(setup, chunks, B):
     model, oracle, weights = setup
     F = sum(chunks)
     g = torch.Generator().manual_seed(F * 7 + len(chunks))
-    B = 3
     f0 = (120 + 600 * torch.rand(B, 1, 1, generator=g)) * (1 + 0.03 * torch.randn(B, 1, F, generator=g))
     control = torch.randn(B, 2, F, generator=g)
     pu, nz = torch.rand(101, generator=g), torch.rand(128 * F - 1, generator=g)
@@ -49,7 +49,7 @@ def test_stream_equals_one_shot(setup, chunks):
     tail_ref = full[:, 128 * F:128 * F + 32000]
     tail = s.reverb_tail().cpu().numpy()[:, :tail_ref.shape[1]]
     e_tail = rms(tail - tail_ref)
-    record(f"stream_chunks_{len(chunks)}x", pre_max_abs_err=e_pre, pre_max=float(np.abs(pre_ref).max()), y_rms_err=e_y,
+    record(f"stream_chunks_{len(chunks)}x_B{B}", pre_max_abs_err=e_pre, pre_max=float(np.abs(pre_ref).max()), y_rms_err=e_y,
            y_rms=rms(y_ref), tail_rms_err=e_tail, tail_rms=rms(tail_ref))
     assert e_pre <= 2e-6 * max(1.0, float(np.abs(pre_ref).max()) / 1e-2)   # pre-reverb level is ~1e-2: ~1e-6 absolute
     assert e_y <= 1e-4 and e_tail <= 1e-4
