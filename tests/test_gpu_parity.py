@@ -688,6 +688,28 @@ def test_shape_sweep_matches_the_oracle(models, oracle, B, T):
         assert max(errs) <= 1e-4 and max(errs) <= 2e-5 * max(rms(ref), 1e-3), (B, T, which, errs, rms(ref))
 
 
+@pytest.mark.parametrize("size,lo,hi", [(1000, -2.5, 3.5), (4096, -4.0, 4.0), (512, -3.0, 3.0), (4096, -3.0, 3.0)])
+def test_fastnewt_table_parameters(weights, size, lo, hi):
+    """FastNEWT's gin-configurable table (shaping.py:82-105: table_size, table_min, table_max) on the FUSED path: only a
+    power-of-two size over a range of exactly 6 takes the folded-index kernel, everything else the general pair-table kernel;
+    both against the oracle built with the same three numbers (g1's inputs reach outside [-2.5, 3.5]: the below-range
+    extrapolation and the flat top of the reference's lookup are part of the comparison)."""
+    import nws_amd as nws
+    from oracle.newt_oracle import OracleNEWT
+
+    g = load_npz("g1_realistic.npz")
+    m = build_model(False)
+    m.newt = nws.FastNEWT(m.newt, table_size=size, table_min=lo, table_max=hi)
+    assert m._engine.specialised()
+    ref = OracleNEWT(weights, fast=True, lut_python_loop=False, table_size=size, table_min=lo, table_max=hi)(
+        g["f0"], g["control"], g["phase_u"], g["noise"]).numpy()
+    with torch.no_grad():
+        y = m(dev(g["f0"]), dev(g["control"]), phase_u=dev(g["phase_u"]), noise=dev(g["noise"])).cpu().numpy()
+    e = rms(y - ref)
+    record(f"fastnewt_table_{size}_{lo}_{hi}", rms_err=e, out_rms=rms(ref))
+    assert e <= 1e-4 and e <= 2e-4 * rms(ref), (size, lo, hi, e, rms(ref))
+
+
 def test_default_rng_path_and_determinism(models):
     _, fast = models
     f0 = 220 + 50 * torch.rand(2, 1, 16, device="cuda")
