@@ -710,6 +710,36 @@ def test_fastnewt_table_parameters(weights, size, lo, hi):
     assert e <= 1e-4 and e <= 2e-4 * rms(ref), (size, lo, hi, e, rms(ref))
 
 
+@pytest.mark.parametrize("sr", [22050, 8000])
+def test_fused_path_at_other_sample_rates(weights, sr):
+    """sample_rate is a gin parameter of NeuralWaveshaping and HarmonicOscillator (neural_waveshaping.py:35, generators.py:40-44):
+    it sets the phase increment and the anti-aliasing mask, not a size, so the fused kernels serve it; against the oracle."""
+    import nws_amd as nws
+    from conftest import GOLDEN
+    from oracle.newt_oracle import OracleNEWT
+    import os
+
+    g = load_npz("g1_realistic.npz")
+    nws.ensure_default_config()
+    try:
+        nws.gin.parse_config(f"NeuralWaveshaping.sample_rate = {sr}\nHarmonicOscillator.sample_rate = {sr}\n")
+        for fast in (False, True):
+            # hyper-parameters stored with a checkpoint win over gin, as in Lightning's load_from_checkpoint: pass the override
+            m = nws.NeuralWaveshaping.load_from_checkpoint(os.path.join(GOLDEN, "weights_vn.npz"), sample_rate=sr).cuda().eval()
+            if fast:
+                m.newt = nws.FastNEWT(m.newt)
+            assert float(m.sample_rate) == sr and float(m.osc.sample_rate) == sr and m._engine.specialised()
+            ref = OracleNEWT(weights, sample_rate=sr, fast=fast, lut_python_loop=False)(g["f0"], g["control"], g["phase_u"], g["noise"]).numpy()
+            with torch.no_grad():
+                y = m(dev(g["f0"]), dev(g["control"]), phase_u=dev(g["phase_u"]), noise=dev(g["noise"])).cpu().numpy()
+            e = rms(y - ref)
+            record(f"sample_rate_{sr}_{'fast' if fast else 'exact'}", rms_err=e, out_rms=rms(ref))
+            assert e <= 1e-4 and e <= 2e-4 * rms(ref), (sr, fast, e, rms(ref))
+    finally:
+        nws.gin.clear_config()
+        nws.gin.parse_config_file(nws.DEFAULT_GIN)
+
+
 def test_default_rng_path_and_determinism(models):
     _, fast = models
     f0 = 220 + 50 * torch.rand(2, 1, 16, device="cuda")
