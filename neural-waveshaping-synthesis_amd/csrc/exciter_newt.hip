@@ -513,6 +513,22 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
   const int N = T * NWS_HOP;
   constexpr int kThreads = 256 * HPB;
 
+  // this lane's own inputs (two F0 frames or the upsampled sample, the 32-sample carry) are requested FIRST, in front of the
+  // staging traffic below: the VM counter retires in order, so with these loads behind the staging ones the prologue paid
+  // three dependent round trips to memory (staging -> F0 -> carry) before its barrier; now they are all in flight together
+  const bool hop_live = HPB == 1 || j < T;
+  const int n = (hop_live ? j : jb) * kTile + w4 * 32 + col;
+  const NwsLerp lc = nws_lerp_coeff(n, T);
+  float f0_a, f0_b = 0.0f;
+  if (f0_up != nullptr) {
+    f0_a = f0_up[(size_t)b * N + n];
+  } else {
+    const float* x = f0 + (size_t)b * T;
+    f0_a = x[lc.i0];
+    f0_b = x[lc.i1];
+  }
+  const double carry_in = carry[(size_t)b * (N / 32) + (n >> 5)];
+
   // ---- stage the workgroup constants in LDS ----
   if (w.mixer_frags != nullptr) {
     // pre-split fragment table (nws_mixer_frags): 28 KB = 28 pieces of 1 KB, copied by the LDS-DMA path
@@ -632,19 +648,10 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
 
   // ---- per-sample phase: fp64 prefix sum -> fp32 rounding chain of the reference ----
   // (a second hop past the end of an odd-length utterance only helped with the staging above)
-  const bool hop_live = HPB == 1 || j < T;
-  const int n = (hop_live ? j : jb) * kTile + w4 * 32 + col;
-  const NwsLerp lc = nws_lerp_coeff(n, T);
-  float f0n;
-  if (f0_up != nullptr) {
-    f0n = f0_up[(size_t)b * N + n];
-  } else {
-    const float* x = f0 + (size_t)b * T;
-    f0n = nws_lerp(x[lc.i0], x[lc.i1], lc.w0, lc.w1);
-  }
+  const float f0n = f0_up != nullptr ? f0_a : nws_lerp(f0_a, f0_b, lc.w0, lc.w1);
   const double cs_local = scan32_f64((double)f0n);  // inclusive prefix sum over the wave's 32 samples (both halves alike)
   double cs = cs_local;
-  cs += carry[(size_t)b * (N / 32) + (n >> 5)];
+  cs += carry_in;
   const float csum = (float)cs;                                 // fl32 of the double prefix sum
   // math.tau * cumsum / sample_rate with a TRUE division: for sr = 16000 the reciprocal + one FMA correction below is the
   // correctly rounded quotient for every fp32 numerator (checked exhaustively over all mantissas), 3 instructions
