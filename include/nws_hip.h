@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NWS_ABI_VERSION 3
+#define NWS_ABI_VERSION 4
 
 #define NWS_N_HARMONICS 101
 #define NWS_N_SHAPERS 64
@@ -206,15 +206,28 @@ int nws_fir_noise(const float* fir /* (B,T,128): upper half-taps, see nws_frame_
 int nws_fir_noise_window(const float* fir, const float* noise, int noise_len, int origin, const float* add_in, int B, int T,
                          float* out, void* stream);
 
-/* ---- learned reverb (models/modules/shaping.py:161-173): y = x + circconv_L(x, [0, ir])[:N], L = max(N, ir_len+1) ---- */
+/* ---- learned reverb (models/modules/shaping.py:161-173): y = x + circconv_Lc(x, [0, ir])[:N], Lc = max(N, ir_len+1) ----
+ * A plan exists for EVERY even circular length (the reference takes any N; for an odd Lc its rfft / irfft pair is not a
+ * circular convolution at all - runtime-size path, nws_g_reverb_direct).  Two forms:
+ *   direct (Lc == 0): the L-point four-step transform IS the circular convolution, L = max(N, ir_len+1) = N1 * N2 with
+ *     N1 = 125 (radix-5 column pass) or N1 <= 128 (DFT-matrix column pass on the matrix cores);
+ *   overlap-save (Lc > 0): every other length.  The signal is read as Lc-periodic (zeros between N and Lc); block j of
+ *     L = 125 * 2^k points starts `hist` = ir_len samples before output j * (L - hist), its last L - hist points are
+ *     final samples of the circular convolution - the wrap-around is in the loads, nothing is folded afterwards.
+ *     nblk = ceil(N / (L - hist)) transforms per utterance pair instead of one. */
 typedef struct NwsReverbPlan {
-  int32_t L;   /* circular length */
-  int32_t N1;  /* column-DFT size  (L = N1 * N2) */
-  int32_t N2;  /* row-FFT size, power of two */
-  int32_t reserved;
+  int32_t L;     /* transform length */
+  int32_t N1;    /* column-DFT size  (L = N1 * N2) */
+  int32_t N2;    /* row-FFT size, power of two, 32 .. 4096 */
+  int32_t Lc;    /* 0: direct; else the reference's circular length, served by overlap-save blocks of L points */
+  int32_t hist;  /* overlap-save: samples of history in front of every block (= ir_len); 0 when direct */
+  int32_t nblk;  /* transforms per utterance pair (1 when direct) */
+  int32_t reserved[2];
 } NwsReverbPlan;
 
 int nws_reverb_plan(int N, int ir_len_plus1, NwsReverbPlan* plan /* host */);
+/* 1 when `plan` renders Reverb.forward for N samples (ir_len_plus1 > 0: and for that impulse-response length), else 0 */
+int nws_reverb_plan_serves(const NwsReverbPlan* plan, int N, int ir_len_plus1);
 /* bytes of the constant tables (DFT matrices + twiddles) and of the IR spectrum for a plan */
 size_t nws_reverb_table_bytes(const NwsReverbPlan* plan);
 size_t nws_reverb_spectrum_bytes(const NwsReverbPlan* plan);

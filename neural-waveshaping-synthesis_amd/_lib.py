@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnws_hip.so")
 
-ABI_VERSION = 3          # include/nws_hip.h NWS_ABI_VERSION
+ABI_VERSION = 4          # include/nws_hip.h NWS_ABI_VERSION
 EXCITER_VALU_FILM = 1    # NwsWeights.exciter_opts bits (include/nws_hip.h)
 EXCITER_ONE_TERM = 2
 EXCITER_HYBRID = 4
@@ -51,7 +51,12 @@ class NwsWeights(C.Structure):
 
 
 class NwsReverbPlan(C.Structure):
-    _fields_ = [("L", C.c_int32), ("N1", C.c_int32), ("N2", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("L", C.c_int32), ("N1", C.c_int32), ("N2", C.c_int32), ("Lc", C.c_int32), ("hist", C.c_int32), ("nblk", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
+
+    def as_tensor(self):
+        import torch
+        return torch.tensor([self.L, self.N1, self.N2, self.Lc, self.hist, self.nblk, 0, 0], dtype=torch.int32)
 
 
 class NwsForwardAux(C.Structure):
@@ -103,6 +108,7 @@ _PROTOTYPES = {
     "nws_reverb_linear_chunk": (C.c_int, [C.POINTER(NwsReverbPlan), _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, C.c_int, _fp, _fp,
                                           C.c_size_t, _fp]),
     "nws_reverb_plan": (C.c_int, [C.c_int, C.c_int, C.POINTER(NwsReverbPlan)]),
+    "nws_reverb_plan_serves": (C.c_int, [C.POINTER(NwsReverbPlan), C.c_int, C.c_int]),
     "nws_reverb_table_bytes": (C.c_size_t, [C.POINTER(NwsReverbPlan)]),
     "nws_reverb_spectrum_bytes": (C.c_size_t, [C.POINTER(NwsReverbPlan)]),
     "nws_reverb_workspace_bytes": (C.c_size_t, [C.POINTER(NwsReverbPlan), C.c_int]),

@@ -171,7 +171,7 @@ int nws_forward(const NwsWeights* w, const NwsForwardAux* aux, const float* f0, 
   if (!w || !aux_ok(aux)) return NWS_ERR_BAD_ARG;
   if (!f0 || !control || !phase_u || !rand_phase || !noise || !out || !workspace) return NWS_ERR_BAD_ARG;
   if (B <= 0 || T < 2 || C < 2) return NWS_ERR_BAD_ARG;
-  if ((long long)T * NWS_HOP > aux->plan->L) return NWS_ERR_BAD_ARG;
+  if (T > (1 << 23) || !nws_reverb_plan_serves(aux->plan, T * NWS_HOP, 0)) return NWS_ERR_BAD_ARG;
   const Arena a = carve_arena(aux->plan, workspace, workspace_bytes, B, T, false);
   if (!a.ok) return NWS_ERR_WORKSPACE;
   // one stream, one call: the per-utterance recurrence (64 CUs for 64 utterances) has the shorter latency
@@ -195,7 +195,7 @@ int nws_forward_audio(const NwsWeights* w, const NwsForwardAux* aux, const float
   if (!w || !aux_ok(aux)) return NWS_ERR_BAD_ARG;
   if (!f0 || !phase_u || !rand_phase || !noise || !out || !workspace) return NWS_ERR_BAD_ARG;
   if (B <= 0 || T < 2) return NWS_ERR_BAD_ARG;
-  if ((long long)T * NWS_HOP > aux->plan->L) return NWS_ERR_BAD_ARG;
+  if (T > (1 << 23) || !nws_reverb_plan_serves(aux->plan, T * NWS_HOP, 0)) return NWS_ERR_BAD_ARG;
   const Arena a = carve_arena(aux->plan, workspace, workspace_bytes, B, T, false);
   if (!a.ok) return NWS_ERR_WORKSPACE;
   return audio_half(w, aux, f0, B, T, sample_rate, phase_u, rand_phase, noise, out, a, stream);
@@ -207,7 +207,7 @@ int nws_forward_audio_ev(const NwsWeights* w, const NwsForwardAux* aux, const fl
   if (!w || !aux_ok(aux)) return NWS_ERR_BAD_ARG;
   if (!f0 || !phase_u || !rand_phase || !noise || !out || !workspace) return NWS_ERR_BAD_ARG;
   if (B <= 0 || T < 2) return NWS_ERR_BAD_ARG;
-  if ((long long)T * NWS_HOP > aux->plan->L) return NWS_ERR_BAD_ARG;
+  if (T > (1 << 23) || !nws_reverb_plan_serves(aux->plan, T * NWS_HOP, 0)) return NWS_ERR_BAD_ARG;
   const Arena a = carve_arena(aux->plan, workspace, workspace_bytes, B, T, false);
   if (!a.ok) return NWS_ERR_WORKSPACE;
   return audio_half(w, aux, f0, B, T, sample_rate, phase_u, rand_phase, noise, out, a, stream, wait_before_exciter,
@@ -223,7 +223,7 @@ int nws_forward_audio_pre(const NwsWeights* w, const NwsForwardAux* aux, const f
   if (!w || !aux_ok(aux)) return NWS_ERR_BAD_ARG;
   if (!f0 || !phase_u || !rand_phase || !noise || !workspace) return NWS_ERR_BAD_ARG;
   if (B <= 0 || T < 2) return NWS_ERR_BAD_ARG;
-  if ((long long)T * NWS_HOP > aux->plan->L) return NWS_ERR_BAD_ARG;
+  if (T > (1 << 23) || !nws_reverb_plan_serves(aux->plan, T * NWS_HOP, 0)) return NWS_ERR_BAD_ARG;
   const Arena a = carve_arena(aux->plan, workspace, workspace_bytes, B, T, false);
   if (!a.ok) return NWS_ERR_WORKSPACE;
   return audio_half(w, aux, f0, B, T, sample_rate, phase_u, rand_phase, noise, nullptr, a, stream, nullptr, nullptr, false);
@@ -238,7 +238,7 @@ int nws_forward_reverb_rows(const NwsForwardAux* aux, int B, int T, int row0, in
   // the transform scratch of the whole batch is partitioned by rows (two utterances share one complex transform), so the
   // sub-batches of one forward may be in flight together as long as their rows are disjoint and row0 is even
   if (row0 & 1) return NWS_ERR_BAD_ARG;
-  const size_t per_pair = 2 * (size_t)aux->plan->L * sizeof(float);
+  const size_t per_pair = 2 * (size_t)aux->plan->nblk * (size_t)aux->plan->L * sizeof(float);
   char* rv = static_cast<char*>(a.rv_ws) + (size_t)(row0 / 2) * per_pair;
   const size_t left = a.rv_bytes - (size_t)(row0 / 2) * per_pair;
   return nws_reverb(aux->plan, aux->reverb_tables, aux->reverb_spectrum, a.pre + (size_t)row0 * N, nrows, (int)N, out + (size_t)row0 * N, rv,

@@ -13,6 +13,14 @@
 // Two utterances are packed into one complex transform (z = x_a + i x_b; the IR is real, so
 // Re/Im of the circular convolution are the two results): no Hermitian untangling anywhere.
 // The spectrum is kept in the transform's own (k1,k2) order, which a pointwise product does not care about.
+//
+// Lengths the direct form does not serve well (N1 neither 125 nor <= 128: the DFT-matrix column pass is O(N1^2)) run as
+// OVERLAP-SAVE on the same kernels: the input is read as an Lc-periodic signal (zeros between N and Lc), block j is an
+// L = 125 * 2^k point transform that starts hist = len(ir) samples before output j * (L - hist); its last L - hist points are
+// final samples of the length-Lc circular convolution.  The wrap-around lives in the column pass's loads; the row pass sees
+// pairs * nblk independent transforms.  So every even Lc has a plan (Reverb.forward takes any N, shaping.py:161-173).
+#include <stdlib.h>
+
 #include "nws_common.h"
 
 namespace {
@@ -21,6 +29,7 @@ __device__ __forceinline__ int frag_row(int r, int half) { return (r & 3) + 8 * 
 
 struct PlanDev {
   int L, N1, N2, NP, M2;
+  int Lc, hist, nblk, P;   // overlap-save: circular length, history per block, blocks per pair, outputs per block (direct: L, 0, 1, L)
 };
 
 __host__ __device__ inline int round_up32(int v) { return (v + 31) & ~31; }
@@ -32,6 +41,10 @@ inline PlanDev plan_dev(const NwsReverbPlan* p) {
   d.N2 = p->N2;
   d.NP = round_up32(p->N1);
   d.M2 = 2 * d.NP;
+  d.Lc = p->Lc > 0 ? p->Lc : p->L;
+  d.hist = p->Lc > 0 ? p->hist : 0;
+  d.nblk = p->Lc > 0 ? p->nblk : 1;
+  d.P = d.L - d.hist;
   return d;
 }
 
@@ -168,6 +181,7 @@ __device__ __forceinline__ void fft125_tile(float2* bufA, float2* bufB, const fl
   }
 }
 
+template <bool OLS>
 __global__ __launch_bounds__(kColThreads) void col125_fwd_kernel(PlanDev d, const float2* __restrict__ tw125_g,
                                                          const float* __restrict__ x, int B, int N, long long x_stride,
                                                          float* __restrict__ Ure, float* __restrict__ Uim) {
@@ -181,13 +195,19 @@ __global__ __launch_bounds__(kColThreads) void col125_fwd_kernel(PlanDev d, cons
   if (tid < 125) tw125[tid] = tw125_g[tid];
   const float* x0 = 2 * p < B ? x + (size_t)(2 * p) * x_stride : nullptr;
   const float* x1 = 2 * p + 1 < B ? x + (size_t)(2 * p + 1) * x_stride : nullptr;
+  const int blk = OLS ? blockIdx.z : 0;
+  const size_t slot = (size_t)p * d.nblk + blk;
   // all loads issued before the first LDS write (memory-latency bound: bytes in flight are what counts)
   {
     float2 v[kColPer];
 #pragma unroll
     for (int i = 0; i < kColPer; ++i) {
       const int e = tid + kColThreads * i;
-      const long long n = (long long)d.N2 * (e >> 5) + c0 + (e & 31);
+      int n = d.N2 * (e >> 5) + c0 + (e & 31);
+      if (OLS) {   // position n of block blk = sample (blk P - hist + n) of the Lc-periodic signal (N .. Lc-1: zeros)
+        n += blk * d.P - d.hist;
+        n = n < 0 ? n + d.Lc : (int)((unsigned)n % (unsigned)d.Lc);
+      }
       const bool in = n < N;
       v[i] = make_float2((in && x0) ? x0[n] : 0.0f, (in && x1) ? x1[n] : 0.0f);
     }
@@ -199,13 +219,14 @@ __global__ __launch_bounds__(kColThreads) void col125_fwd_kernel(PlanDev d, cons
 #pragma unroll
   for (int i = 0; i < kColPer; ++i) {
     const int e = tid + kColThreads * i;
-    const size_t o = ((size_t)p * 125 + (e >> 5)) * d.N2 + c0 + (e & 31);
+    const size_t o = (slot * 125 + (e >> 5)) * d.N2 + c0 + (e & 31);
     const float2 v = bufB[e];
     Ure[o] = v.x;
     Uim[o] = v.y;
   }
 }
 
+template <bool OLS>
 __global__ __launch_bounds__(kColThreads) void col125_inv_kernel(PlanDev d, const float2* __restrict__ tw125_g,
                                                          const float* __restrict__ Ure, const float* __restrict__ Uim,
                                                          const float* __restrict__ x, int B, int N,
@@ -218,12 +239,14 @@ __global__ __launch_bounds__(kColThreads) void col125_inv_kernel(PlanDev d, cons
   const int p = blockIdx.y;
   const int c0 = blockIdx.x * 32;
   if (tid < 125) tw125[tid] = tw125_g[tid];
+  const int blk = OLS ? blockIdx.z : 0;
+  const size_t slot = (size_t)p * d.nblk + blk;
   {
     float2 v[kColPer];
 #pragma unroll
     for (int i = 0; i < kColPer; ++i) {
       const int e = tid + kColThreads * i;
-      const size_t o = ((size_t)p * 125 + (e >> 5)) * d.N2 + c0 + (e & 31);
+      const size_t o = (slot * 125 + (e >> 5)) * d.N2 + c0 + (e & 31);
       v[i] = make_float2(Ure[o], Uim[o]);
     }
 #pragma unroll
@@ -232,13 +255,18 @@ __global__ __launch_bounds__(kColThreads) void col125_inv_kernel(PlanDev d, cons
   const int rows_out = (N + d.N2 - 1) / d.N2;
   const bool has1 = 2 * p + 1 < B;
   // the dry signal is independent of the transform: fetch it before the FFT so that its latency hides under it
+  // (overlap-save: position i of block blk is output blk P + i - hist; the first hist positions are wrapped history)
   float dry0[kColPer], dry1[kColPer];
+  long long nout[kColPer];
 #pragma unroll
   for (int i = 0; i < kColPer; ++i) {
     const int e = tid + kColThreads * i;
-    const long long n = (long long)d.N2 * (e >> 5) + c0 + (e & 31);
-    const bool in = x != nullptr && e < rows_out * 32 && n < N;
-    const size_t o0 = (size_t)(2 * p) * N + n;
+    const int pos = d.N2 * (e >> 5) + c0 + (e & 31);
+    const long long n = OLS ? (long long)blk * d.P + pos - d.hist : (long long)pos;
+    const bool keep = OLS ? (pos >= d.hist && n < N) : (e < rows_out * 32 && n < N);
+    nout[i] = keep ? n : -1;
+    const bool in = x != nullptr && keep;
+    const size_t o0 = (size_t)(2 * p) * N + (keep ? n : 0);
     dry0[i] = in ? x[o0] : 0.0f;
     dry1[i] = (in && has1) ? x[o0 + N] : 0.0f;
   }
@@ -247,10 +275,9 @@ __global__ __launch_bounds__(kColThreads) void col125_inv_kernel(PlanDev d, cons
 #pragma unroll
   for (int i = 0; i < kColPer; ++i) {
     const int e = tid + kColThreads * i;
-    const long long n = (long long)d.N2 * (e >> 5) + c0 + (e & 31);
-    if (e < rows_out * 32 && n < N) {
+    if (nout[i] >= 0) {
       const float2 v = bufB[e];
-      const size_t o0 = (size_t)(2 * p) * N + n;
+      const size_t o0 = (size_t)(2 * p) * N + nout[i];
       y[o0] = dry0[i] + v.x;
       if (has1) y[o0 + N] = dry1[i] + v.y;
     }
@@ -393,7 +420,7 @@ __device__ __forceinline__ float2* stockham(float2* x, float2* y, const float2* 
   return x;
 }
 
-template <bool SPECTRUM_ONLY>
+template <bool SPECTRUM_ONLY, int kMaxPer>
 __global__ __launch_bounds__(256) void row_kernel(PlanDev d, float* __restrict__ Ure, float* __restrict__ Uim,
                                                   const float2* __restrict__ tw, const float2* __restrict__ rowtw_g,
                                                   const float* __restrict__ Hre, const float* __restrict__ Him,
@@ -407,9 +434,8 @@ __global__ __launch_bounds__(256) void row_kernel(PlanDev d, float* __restrict__
   const int p = blockIdx.y;
   const size_t base = ((size_t)p * d.N1 + k1) * d.N2;
   const size_t hbase = (size_t)k1 * d.N2;
-  // everything this row needs from memory is requested up front (N2 <= 1024: at most 4 elements per thread): the IR
+  // everything this row needs from memory is requested up front (N2 <= 256 kMaxPer elements per thread): the IR
   // spectrum is only used between the two transforms, its latency hides under the forward one
-  constexpr int kMaxPer = 4;
   float2 z[kMaxPer], t4[kMaxPer], h4[kMaxPer];
 #pragma unroll
   for (int e = 0; e < kMaxPer; ++e) {
@@ -723,13 +749,30 @@ void launch_rows(const PlanDev& d, int pairs, float* Ure, float* Uim, const floa
     row512_kernel<SPECTRUM_ONLY><<<(rows + 3) / 4, 256, 0, st>>>(d, rows, Ure, Uim, tw, reinterpret_cast<const float2*>(t + off_r8(d)), Sre_in, Sim_in,
                                                                 Sre_out, Sim_out);
   } else {
-    row_kernel<SPECTRUM_ONLY><<<dim3(d.N1, pairs), 256, (size_t)(2 * d.N2 + d.N2 / 2) * sizeof(float2), st>>>(d, Ure, Uim, tw, rowtw, Sre_in, Sim_in, Sre_out, Sim_out);
+    // `pairs` counts transforms (utterance pairs x overlap-save blocks): grid.y in slices of 65535
+    for (int q0 = 0; q0 < pairs; q0 += 65535) {
+      const int nq = pairs - q0 < 65535 ? pairs - q0 : 65535;
+      float* ure = Ure + (size_t)q0 * d.L;
+      float* uim = Uim + (size_t)q0 * d.L;
+      const size_t lds = (size_t)(2 * d.N2 + d.N2 / 2) * sizeof(float2);
+      if (d.N2 <= 1024)
+        row_kernel<SPECTRUM_ONLY, 4><<<dim3(d.N1, nq), 256, lds, st>>>(d, ure, uim, tw, rowtw, Sre_in, Sim_in, Sre_out, Sim_out);
+      else
+        row_kernel<SPECTRUM_ONLY, 8><<<dim3(d.N1, nq), 256, lds, st>>>(d, ure, uim, tw, rowtw, Sre_in, Sim_in, Sre_out, Sim_out);
+    }
   }
 }
 
+constexpr int kMaxN2 = 2048;          // row transform sizes: 32 .. 2048 (40 KB of LDS per row at 2048)
+constexpr int kDenseMaxN1 = 128;      // DFT-matrix column pass: O(N1^2) per column, cheaper than overlap-save up to about here
+constexpr int kDenseLastResort = 8192;
+
 bool plan_ok(const NwsReverbPlan* p) {
-  return p && p->L > 0 && p->N1 > 0 && p->N2 >= 32 && p->N2 <= 1024 && (p->N2 & (p->N2 - 1)) == 0 &&
-         (long long)p->N1 * p->N2 == p->L;
+  if (!(p && p->L > 0 && p->N1 > 0 && p->N2 >= 32 && p->N2 <= kMaxN2 && (p->N2 & (p->N2 - 1)) == 0 &&
+        (long long)p->N1 * p->N2 == p->L))
+    return false;
+  if (p->Lc == 0) return p->hist == 0 && p->nblk == 1;
+  return p->N1 == 125 && p->Lc > p->hist && p->hist >= 0 && p->hist < p->L && p->nblk >= 1 && p->nblk <= 65535 && (p->Lc & 1) == 0;
 }
 
 }  // namespace
@@ -737,18 +780,76 @@ bool plan_ok(const NwsReverbPlan* p) {
 extern "C" {
 
 int nws_reverb_plan(int N, int ir_len_plus1, NwsReverbPlan* plan) {
-  if (!plan || N <= 0 || ir_len_plus1 <= 0) return NWS_ERR_BAD_ARG;
-  const int L = N > ir_len_plus1 ? N : ir_len_plus1;
+  if (!plan || N <= 0 || ir_len_plus1 <= 0 || N > (1 << 30) || ir_len_plus1 > (1 << 30)) return NWS_ERR_BAD_ARG;
+  const int Lc = N > ir_len_plus1 ? N : ir_len_plus1;
+  *plan = NwsReverbPlan{};
   int n2 = 1;
-  while ((L % (n2 * 2)) == 0 && n2 < 1024) n2 *= 2;
-  if (n2 < 32) return NWS_ERR_UNSUPPORTED;
-  const int n1 = L / n2;
-  if (n1 > 8192) return NWS_ERR_UNSUPPORTED;
-  plan->L = L;
-  plan->N1 = n1;
-  plan->N2 = n2;
-  plan->reserved = 0;
-  return NWS_OK;
+  while ((Lc % (n2 * 2)) == 0 && n2 < kMaxN2) n2 *= 2;
+  // a smaller row size that leaves exactly 125 columns (e.g. 128000 = 125 x 1024 although 2048 | 256000 = 125 x 2048 is fine too)
+  for (int m = n2; m >= 32; m >>= 1)
+    if (Lc / m == 125 && Lc % m == 0) n2 = m;
+  const int n1 = n2 >= 32 ? Lc / n2 : 0;
+  int dense_max = kDenseMaxN1;
+  if (const char* e = getenv("NWS_REVERB_DENSE_MAX")) dense_max = atoi(e);   // measurements only
+  if (n2 >= 32 && (n1 == 125 || n1 <= dense_max)) {
+    plan->L = Lc;
+    plan->N1 = n1;
+    plan->N2 = n2;
+    plan->nblk = 1;
+    return NWS_OK;
+  }
+  // overlap-save on 125 x 2^k transforms; NWS_REVERB_OLS_N2 pins the row size (measurements)
+  if ((Lc & 1) == 0) {
+    const int hist = ir_len_plus1 - 1;
+    int forced = 0;
+    if (const char* e = getenv("NWS_REVERB_OLS_N2")) forced = atoi(e);
+    double best = 0.0;
+    int best_n2 = 0;
+    for (int m = 256; m <= kMaxN2; m <<= 1) {
+      const long long Lt = 125LL * m;
+      const long long P = Lt - hist;
+      if (P < Lt / 4) continue;                       // at least a quarter of every transform is output
+      const long long nb = (N + P - 1) / P;
+      if (nb > 65535) continue;
+      if (forced && m != forced) continue;
+      // measured per-point cost of a transform (tools/reverb_lengths.py, B = 64): the wave-per-row row pass of N2 = 512 against
+      // the workgroup-per-row Stockham form of the other sizes
+      const double cost = (double)nb * (double)Lt * (m == 512 ? 1.0 : m <= 1024 ? 1.35 : 1.55);
+      if (best_n2 == 0 || cost < best) {
+        best = cost;
+        best_n2 = m;
+      }
+    }
+    if (best_n2) {
+      const long long P = 125LL * best_n2 - hist;
+      plan->L = 125 * best_n2;
+      plan->N1 = 125;
+      plan->N2 = best_n2;
+      plan->Lc = Lc;
+      plan->hist = hist;
+      plan->nblk = (int)((N + P - 1) / P);
+      return NWS_OK;
+    }
+  }
+  // an impulse response too long for the largest block: the DFT-matrix column pass at any N1 it can hold
+  if (n2 >= 32 && n1 <= kDenseLastResort) {
+    plan->L = Lc;
+    plan->N1 = n1;
+    plan->N2 = n2;
+    plan->nblk = 1;
+    return NWS_OK;
+  }
+  return NWS_ERR_UNSUPPORTED;
+}
+
+int nws_reverb_plan_serves(const NwsReverbPlan* plan, int N, int ir_len_plus1) {
+  if (!plan_ok(plan) || N <= 0) return 0;
+  if (plan->Lc == 0) return N <= plan->L && (ir_len_plus1 <= 0 || ir_len_plus1 <= plan->L);
+  const int lc = ir_len_plus1 > 0 ? (N > ir_len_plus1 ? N : ir_len_plus1) : (N > plan->hist + 1 ? N : plan->hist + 1);
+  if (lc != plan->Lc) return 0;
+  if (ir_len_plus1 > 0 && ir_len_plus1 - 1 != plan->hist) return 0;
+  const long long P = (long long)plan->L - plan->hist;
+  return (N + P - 1) / P <= plan->nblk;
 }
 
 size_t nws_reverb_table_bytes(const NwsReverbPlan* plan) {
@@ -764,8 +865,8 @@ size_t nws_reverb_spectrum_bytes(const NwsReverbPlan* plan) {
 size_t nws_reverb_workspace_bytes(const NwsReverbPlan* plan, int B) {
   if (!plan_ok(plan) || B <= 0) return 0;
   const size_t pairs = (size_t)(B + 1) / 2;
-  // planar U (2 * pairs * L) ; the IR-spectrum build needs 3 L (ir_, Ure, Uim)
-  const size_t f = 2 * pairs * (size_t)plan->L;
+  // planar U (2 * pairs * nblk * L) ; the IR-spectrum build needs 3 L (ir_, Ure, Uim)
+  const size_t f = 2 * pairs * (size_t)plan->nblk * (size_t)plan->L;
   const size_t g = 3 * (size_t)plan->L;
   return (f > g ? f : g) * sizeof(float);
 }
@@ -773,12 +874,12 @@ size_t nws_reverb_workspace_bytes(const NwsReverbPlan* plan, int B) {
 static int ensure_col125_attrs() {
   static unsigned long long attr_devices = 0;
   if (nws_first_use_on_device(attr_devices)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(col125_fwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCol125Lds);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(col125_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)kCol125Lds);
-    if (e != hipSuccess) return (int)e;
+    const void* fns[4] = {reinterpret_cast<const void*>(col125_fwd_kernel<false>), reinterpret_cast<const void*>(col125_fwd_kernel<true>),
+                          reinterpret_cast<const void*>(col125_inv_kernel<false>), reinterpret_cast<const void*>(col125_inv_kernel<true>)};
+    for (const void* fn : fns) {
+      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCol125Lds);
+      if (e != hipSuccess) return (int)e;
+    }
   }
   return NWS_OK;
 }
@@ -807,8 +908,13 @@ int nws_reverb_ir_spectrum(const NwsReverbPlan* plan, const void* tables, const 
                            void* workspace, size_t workspace_bytes, void* stream) {
   if (!plan_ok(plan) || !tables || !ir || !spectrum || !workspace || ir_len <= 0) return NWS_ERR_BAD_ARG;
   if (ir_len + 1 > plan->L) return NWS_ERR_BAD_ARG;
+  if (plan->Lc > 0 && ir_len != plan->hist) return NWS_ERR_BAD_ARG;
   if (workspace_bytes < nws_reverb_workspace_bytes(plan, 1)) return NWS_ERR_WORKSPACE;
-  const PlanDev d = plan_dev(plan);
+  PlanDev d = plan_dev(plan);
+  d.Lc = d.L;   // the spectrum of [0, ir] zero-padded to the TRANSFORM length: one plain transform in either mode
+  d.hist = 0;
+  d.nblk = 1;
+  d.P = d.L;
   const float* t = static_cast<const float*>(tables);
   hipStream_t st = (hipStream_t)stream;
   float* irp = static_cast<float*>(workspace);
@@ -821,8 +927,8 @@ int nws_reverb_ir_spectrum(const NwsReverbPlan* plan, const void* tables, const 
   build_irz_kernel<<<(d.L + 255) / 256, 256, 0, st>>>(ir, ir_len, d.L, Sim + d.L);
   NWS_CHECK_LAUNCH();
   if (d.N1 == 125) {
-    col125_fwd_kernel<<<dim3(d.N2 / 32, 1), kColThreads, kCol125Lds, st>>>(d, reinterpret_cast<const float2*>(t + off_tw125(d)),
-                                                                    irp, 1, ir_len + 1, 0, Ure, Uim);
+    col125_fwd_kernel<false><<<dim3(d.N2 / 32, 1), kColThreads, kCol125Lds, st>>>(d, reinterpret_cast<const float2*>(t + off_tw125(d)),
+                                                                           irp, 1, ir_len + 1, 0, Ure, Uim);
   } else {
     const dim3 g1(d.N2 / 32, (d.M2 / 32 + 3) / 4, 1);
     col_fwd_kernel<<<g1, 256, 0, st>>>(t + off_afwd(d), d, irp, 1, ir_len + 1, 0, Ure, Uim);
@@ -836,7 +942,7 @@ int nws_reverb_ir_spectrum(const NwsReverbPlan* plan, const void* tables, const 
 int nws_reverb(const NwsReverbPlan* plan, const void* tables, const void* spectrum, const float* x, int B, int N,
                float* y, void* workspace, size_t workspace_bytes, void* stream) {
   if (!plan_ok(plan) || !tables || !spectrum || !x || !y || !workspace || B <= 0 || N <= 0) return NWS_ERR_BAD_ARG;
-  if (N > plan->L) return NWS_ERR_BAD_ARG;
+  if (!nws_reverb_plan_serves(plan, N, 0)) return NWS_ERR_BAD_ARG;
   if (workspace_bytes < nws_reverb_workspace_bytes(plan, B)) return NWS_ERR_WORKSPACE;
   const PlanDev d = plan_dev(plan);
   const int pairs = (B + 1) / 2;
@@ -844,18 +950,31 @@ int nws_reverb(const NwsReverbPlan* plan, const void* tables, const void* spectr
   const float* t = static_cast<const float*>(tables);
   hipStream_t st = (hipStream_t)stream;
   float* Ure = static_cast<float*>(workspace);
-  float* Uim = Ure + (size_t)pairs * d.L;
+  float* Uim = Ure + (size_t)pairs * d.nblk * d.L;
   const float* Sre = static_cast<const float*>(spectrum);
   const float* Sim = Sre + d.L;
+  const float2* tw125 = reinterpret_cast<const float2*>(t + off_tw125(d));
+  if (plan->Lc > 0) {
+    // overlap-save: nblk transforms per pair, only as many as N needs (a plan made for N serves shorter calls with the same Lc)
+    PlanDev e = d;
+    e.nblk = (int)(((long long)N + d.P - 1) / d.P);
+    Uim = Ure + (size_t)pairs * e.nblk * d.L;
+    col125_fwd_kernel<true><<<dim3(d.N2 / 32, pairs, e.nblk), kColThreads, kCol125Lds, st>>>(e, tw125, x, B, N, (long long)N, Ure, Uim);
+    NWS_CHECK_LAUNCH();
+    launch_rows<false>(e, pairs * e.nblk, Ure, Uim, t, Sre, Sim, nullptr, nullptr, st);
+    NWS_CHECK_LAUNCH();
+    col125_inv_kernel<true><<<dim3(d.N2 / 32, pairs, e.nblk), kColThreads, kCol125Lds, st>>>(e, tw125, Ure, Uim, x, B, N, y);
+    NWS_CHECK_LAUNCH();
+    return NWS_OK;
+  }
   if (N <= kDirectMaxN && B <= 65535) {
     reverb_direct_kernel<<<dim3((N + 255) / 256, B), 256, (size_t)3 * N * sizeof(float), st>>>(x, Sim + d.L, N, d.L, y);
     NWS_CHECK_LAUNCH();
     return NWS_OK;
   }
 
-  const float2* tw125 = reinterpret_cast<const float2*>(t + off_tw125(d));
   if (d.N1 == 125) {
-    col125_fwd_kernel<<<dim3(d.N2 / 32, pairs), kColThreads, kCol125Lds, st>>>(d, tw125, x, B, N, (long long)N, Ure, Uim);
+    col125_fwd_kernel<false><<<dim3(d.N2 / 32, pairs), kColThreads, kCol125Lds, st>>>(d, tw125, x, B, N, (long long)N, Ure, Uim);
   } else {
     const dim3 g1(d.N2 / 32, (d.M2 / 32 + 3) / 4, pairs);
     col_fwd_kernel<<<g1, 256, 0, st>>>(t + off_afwd(d), d, x, B, N, (long long)N, Ure, Uim);
@@ -864,7 +983,7 @@ int nws_reverb(const NwsReverbPlan* plan, const void* tables, const void* spectr
   launch_rows<false>(d, pairs, Ure, Uim, t, Sre, Sim, nullptr, nullptr, st);
   NWS_CHECK_LAUNCH();
   if (d.N1 == 125) {
-    col125_inv_kernel<<<dim3(d.N2 / 32, pairs), kColThreads, kCol125Lds, st>>>(d, tw125, Ure, Uim, x, B, N, y);
+    col125_inv_kernel<false><<<dim3(d.N2 / 32, pairs), kColThreads, kCol125Lds, st>>>(d, tw125, Ure, Uim, x, B, N, y);
   } else {
     const int rows_out = (N + d.N2 - 1) / d.N2;
     const int nt = (rows_out + 31) / 32;
@@ -881,7 +1000,7 @@ int nws_reverb_linear_chunk(const NwsReverbPlan* plan, const void* tables, const
                             const float* tail_in, float* tail_out, int tail_len, float* y, void* workspace,
                             size_t workspace_bytes, void* stream) {
   if (!plan_ok(plan) || !tables || !spectrum || !x || !y || !tail_in || !tail_out || !workspace) return NWS_ERR_BAD_ARG;
-  if (B <= 0 || M <= 0 || tail_len <= 0 || M + tail_len > plan->L) return NWS_ERR_BAD_ARG;
+  if (B <= 0 || M <= 0 || tail_len <= 0 || M + tail_len > plan->L || plan->Lc != 0) return NWS_ERR_BAD_ARG;
   const PlanDev d = plan_dev(plan);
   const int pairs = (B + 1) / 2;
   const size_t need = (2 * (size_t)pairs * d.L + (size_t)B * d.L) * sizeof(float);
@@ -895,7 +1014,7 @@ int nws_reverb_linear_chunk(const NwsReverbPlan* plan, const void* tables, const
   const float* Sim = Sre + d.L;
   const float2* tw125 = reinterpret_cast<const float2*>(t + off_tw125(d));
   if (d.N1 == 125) {
-    col125_fwd_kernel<<<dim3(d.N2 / 32, pairs), kColThreads, kCol125Lds, st>>>(d, tw125, x, B, M, (long long)M, Ure, Uim);
+    col125_fwd_kernel<false><<<dim3(d.N2 / 32, pairs), kColThreads, kCol125Lds, st>>>(d, tw125, x, B, M, (long long)M, Ure, Uim);
   } else {
     const dim3 g1(d.N2 / 32, (d.M2 / 32 + 3) / 4, pairs);
     col_fwd_kernel<<<g1, 256, 0, st>>>(t + off_afwd(d), d, x, B, M, (long long)M, Ure, Uim);
@@ -904,7 +1023,7 @@ int nws_reverb_linear_chunk(const NwsReverbPlan* plan, const void* tables, const
   launch_rows<false>(d, pairs, Ure, Uim, t, Sre, Sim, nullptr, nullptr, st);
   NWS_CHECK_LAUNCH();
   if (d.N1 == 125) {
-    col125_inv_kernel<<<dim3(d.N2 / 32, pairs), kColThreads, kCol125Lds, st>>>(d, tw125, Ure, Uim, nullptr, B, d.L, wet);
+    col125_inv_kernel<false><<<dim3(d.N2 / 32, pairs), kColThreads, kCol125Lds, st>>>(d, tw125, Ure, Uim, nullptr, B, d.L, wet);
   } else {
     const int nt = (d.N1 + 31) / 32;
     const dim3 g3(d.N2 / 32, (2 * nt + 3) / 4, pairs);

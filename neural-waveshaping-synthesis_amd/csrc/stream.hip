@@ -385,7 +385,7 @@ int nws_stream_step(const NwsWeights* w, const float* fir_design, const NwsRever
   } else {
     if (!plan || !reverb_tables || !reverb_spectrum || L.x_lin == 0) return NWS_ERR_BAD_ARG;
     const int N = ir_len + M;
-    if (N > plan->L) return NWS_ERR_BAD_ARG;
+    if (N > plan->L || plan->Lc != 0) return NWS_ERR_BAD_ARG;
     stream_combine_kernel<<<dim3((M + 255) / 256, B), 256, 0, st>>>(P, M, pre, F(L.ring), counters);
     NWS_CHECK_LAUNCH();
     stream_gather_kernel<<<dim3((N + 255) / 256, B), 256, 0, st>>>(F(L.ring), ir_len, M, N, 0, F(L.x_lin), counters);
@@ -410,7 +410,7 @@ int nws_stream_reverb_tail(const NwsReverbPlan* plan, const void* reverb_tables,
   const Layout L = layout(B, max_frames, ir_len, 0);
   if (L.nzwin > state_bytes) return NWS_ERR_WORKSPACE;
   const int N = 2 * ir_len + 1;
-  if (N > plan->L) return NWS_ERR_BAD_ARG;
+  if (N > plan->L || plan->Lc != 0) return NWS_ERR_BAD_ARG;
   const size_t lin = al((size_t)B * N * sizeof(float));
   const size_t rvb = nws_reverb_workspace_bytes(plan, B);
   if (workspace_bytes < 2 * lin + rvb) return NWS_ERR_WORKSPACE;

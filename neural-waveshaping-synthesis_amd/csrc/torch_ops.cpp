@@ -58,10 +58,10 @@ struct Launch {
 };
 
 NwsReverbPlan plan_of(const Tensor& plan) {
-  TORCH_CHECK(plan.device().is_cpu() && plan.scalar_type() == at::kInt && plan.is_contiguous() && plan.numel() == 4,
-              "plan: expected a CPU int32 tensor [L, N1, N2, 0] (nws_reverb_plan)");
+  TORCH_CHECK(plan.device().is_cpu() && plan.scalar_type() == at::kInt && plan.is_contiguous() && plan.numel() == 8,
+              "plan: expected a CPU int32 tensor [L, N1, N2, Lc, hist, nblk, 0, 0] (the NwsReverbPlan of nws_reverb_plan)");
   const int32_t* p = plan.data_ptr<int32_t>();
-  return NwsReverbPlan{p[0], p[1], p[2], p[3]};
+  return NwsReverbPlan{p[0], p[1], p[2], p[3], p[4], p[5], {p[6], p[7]}};
 }
 
 // the spectrum / table tensors must be the ones built for THIS plan: the kernels index them by plan.L / N1 / N2 (a tensor made
@@ -384,7 +384,8 @@ Tensor reverb(const Tensor& plan_t, const Tensor& tables, const Tensor& spectrum
   TORCH_CHECK(x.dim() == 2, "Reverb: expected (B, N), got ", x.sizes());
   check_reverb_buffers(plan, tables, spectrum);
   const int64_t B = x.size(0), N = x.size(1);
-  TORCH_CHECK(N <= plan.L, "Reverb: ", N, " samples do not fit the plan's circular length ", plan.L);
+  TORCH_CHECK(nws_reverb_plan_serves(&plan, (int)N, 0), "Reverb: the plan [L ", plan.L, ", Lc ", plan.Lc, ", hist ", plan.hist, ", nblk ", plan.nblk,
+              "] was not made for ", N, " samples");
   Launch L(x);
   const size_t nbytes = nws_reverb_workspace_bytes(&plan, (int)B);
   Tensor ws = at::empty({(int64_t)nbytes}, x.options().dtype(at::kByte));
@@ -408,6 +409,7 @@ std::tuple<Tensor, Tensor> reverb_linear_chunk(const Tensor& plan_t, const Tenso
   const int64_t B = x.size(0), M = x.size(1), tail_len = tail_in.size(1);
   check_reverb_buffers(plan, tables, spectrum);
   check_same_device(x, "x", spectrum, "reverb.ir spectrum");
+  TORCH_CHECK(plan.Lc == 0, "reverb_linear_chunk: needs a direct plan (one transform of M + tail_len samples)");
   TORCH_CHECK(M + tail_len <= plan.L, "reverb_linear_chunk: chunk of ", M, " + tail of ", tail_len, " samples wraps around L = ", plan.L);
   Launch L(x);
   const size_t nbytes = (size_t)(2 * ((B + 1) / 2) * plan.L + B * plan.L) * sizeof(float);
@@ -595,7 +597,7 @@ Tensor forward_generic(const Tensor& gdesc, const Tensor& f0, const Tensor& cont
     check_dev(*tables, "reverb_tables");
     check_dev(*spectrum, "reverb_spectrum");
     check_reverb_buffers(plan, *tables, *spectrum);
-    TORCH_CHECK(N <= plan.L, "forward_generic: ", N, " samples do not fit the plan's circular length ", plan.L);
+    TORCH_CHECK(nws_reverb_plan_serves(&plan, (int)N, m->ir_len + 1), "forward_generic: the reverb plan was not made for ", N, " samples");
     TORCH_CHECK((size_t)reverb_workspace.numel() >= nws_reverb_workspace_bytes(&plan, (int)B), "reverb workspace too small");
   }
   Launch L(f0);

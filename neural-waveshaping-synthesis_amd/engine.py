@@ -98,15 +98,23 @@ except Exception:   # pragma: no cover
     pass
 
 
-_TABLE_CACHE: dict = {}  # (device index, L) -> (plan, tables tensor, plan tensor)
+_TABLE_CACHE: dict = {}  # (device index, L, N1, N2) -> tables tensor (twiddles / DFT matrices of one transform length)
+_PLAN_CACHE: dict = {}   # (device index, n_samples, ir_len_plus1) -> (plan, tables tensor, plan tensor)
 
 
 def reverb_plan_and_tables(device: torch.device, n_samples: int, ir_len_plus1: int):
+    """The reverb plan for a clip of n_samples (every even circular length has one: direct four-step transform or overlap-save
+    blocks, csrc/reverb_fft.hip), the constant tables of its transform length (shared by all plans of that length) and the
+    plan as the CPU int32 tensor the torch ops take."""
+    pkey = (device.index, int(n_samples), int(ir_len_plus1))
+    hit = _PLAN_CACHE.get(pkey)
+    if hit is not None:
+        return hit
     plan = NwsReverbPlan()
     check(_lib.lib().nws_reverb_plan(int(n_samples), int(ir_len_plus1), C.byref(plan)), "nws_reverb_plan")
-    key = (device.index, plan.L)
-    hit = _TABLE_CACHE.get(key)
-    if hit is None:
+    key = (device.index, plan.L, plan.N1, plan.N2)
+    tables = _TABLE_CACHE.get(key)
+    if tables is None:
         nbytes = _lib.lib().nws_reverb_table_bytes(C.byref(plan))
         with torch.cuda.device(device):
             tables = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
@@ -114,8 +122,11 @@ def reverb_plan_and_tables(device: torch.device, n_samples: int, ir_len_plus1: i
             # one-time: make the tables visible to every stream before anybody can use them (callers may issue forwards
             # round-robin on several streams; the builder stream is whichever one got here first)
             torch.cuda.current_stream(device).synchronize()
-        hit = (plan, tables, torch.tensor([plan.L, plan.N1, plan.N2, 0], dtype=torch.int32))
-        _TABLE_CACHE[key] = hit
+        _TABLE_CACHE[key] = tables
+    hit = (plan, tables, plan.as_tensor())
+    if len(_PLAN_CACHE) >= 256:
+        _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+    _PLAN_CACHE[pkey] = hit
     return hit
 
 

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_strings():
     L = _lib.lib()
-    assert L.nws_abi_version() == _lib.ABI_VERSION == 3
+    assert L.nws_abi_version() == _lib.ABI_VERSION == 4
     assert b"unsupported" in L.nws_error_string(-1)
     assert b"bad argument" in L.nws_error_string(-2)
     assert L.nws_error_string(0) == b"ok"
@@ -43,7 +43,7 @@ def test_abi_version_and_error_strings():
 def test_struct_layouts_match_header_sizes():
     # the library reports sizeof() of its own structs: the ctypes declarations must agree byte for byte
     L = _lib.lib()
-    assert C.sizeof(_lib.NwsReverbPlan) == 16 == L.nws_sizeof(1)
+    assert C.sizeof(_lib.NwsReverbPlan) == 32 == L.nws_sizeof(1)
     assert C.sizeof(_lib.NwsWeights) == L.nws_sizeof(0)
     assert C.sizeof(_lib.NwsForwardAux) == L.nws_sizeof(2)
     n_ptr = sum(1 for _, t in _lib.NwsWeights._fields_ if t is _lib._fp) + 4 * 4 + 3 * 4
@@ -51,19 +51,50 @@ def test_struct_layouts_match_header_sizes():
 
 
 @pytest.mark.parametrize("N,L,N1,N2", [(64000, 64000, 125, 512), (256, 32000, 125, 256), (32000, 32000, 125, 256),
-                                       (128 * 501, 64128, 501, 128), (128 * 512, 65536, 64, 1024)])
+                                       (128 * 1000, 128000, 125, 1024), (128 * 2000, 256000, 125, 2048),
+                                       (128 * 504, 64512, 63, 1024), (128 * 512, 65536, 32, 2048)])
 def test_reverb_plan_is_host_only(N, L, N1, N2):
     plan = _lib.NwsReverbPlan()
     assert _lib.lib().nws_reverb_plan(N, 32000, C.byref(plan)) == 0
-    assert (plan.L, plan.N1, plan.N2) == (L, N1, N2)
+    assert (plan.L, plan.N1, plan.N2, plan.Lc, plan.hist, plan.nblk) == (L, N1, N2, 0, 0, 1)     # direct: one transform IS the circular convolution
     assert _lib.lib().nws_reverb_workspace_bytes(C.byref(plan), 3) == max(2 * 2 * L, 3 * L) * 4
     assert _lib.lib().nws_reverb_spectrum_bytes(C.byref(plan)) == 3 * L * 4   # Sre | Sim | [0, ir] in the time domain (short-buffer form)
+    assert _lib.lib().nws_reverb_plan_serves(C.byref(plan), N, 32000) == 1
 
 
-def test_reverb_plan_rejects_unsupported_lengths():
+def test_every_clip_length_has_a_reverb_plan():
+    """Reverb.forward takes any N (shaping.py:161-173); VERDICT r3 #1: lengths whose odd part exceeded 8192 were refused.  Every
+    N = 128 T now plans - direct when the circular length is 125 x 2^k or (<= 128) x 2^k, else overlap-save on 125 x 2^k blocks
+    that cover every output exactly once and keep a sensible share of each transform."""
+    L = _lib.lib()
     plan = _lib.NwsReverbPlan()
-    assert _lib.lib().nws_reverb_plan(100, 88200, C.byref(plan)) == -1   # 88200 = 2^3 * 11025: no power-of-two row FFT
+    Ts = list(range(2, 4100)) + [8191, 8192, 8193, 9375, 10001, 16384, 20000, 37500, 37501, 65537, 131074, 1 << 20, (1 << 23)]
+    for T in Ts:
+        N = 128 * T
+        assert L.nws_reverb_plan(N, 32000, C.byref(plan)) == 0, T
+        assert plan.L == plan.N1 * plan.N2 and L.nws_reverb_plan_serves(C.byref(plan), N, 32000) == 1
+        if plan.Lc == 0:
+            assert plan.L == max(N, 32000) and plan.nblk == 1 and (plan.N1 == 125 or plan.N1 <= 128)
+        else:
+            P = plan.L - plan.hist
+            assert plan.Lc == max(N, 32000) and plan.hist == 31999 and plan.N1 == 125
+            assert (plan.nblk - 1) * P < N <= plan.nblk * P and 4 * P >= plan.L
+            assert L.nws_reverb_workspace_bytes(C.byref(plan), 4) == 2 * 2 * plan.nblk * plan.L * 4
+        assert L.nws_reverb_plan_serves(C.byref(plan), N + 128, 32000) == (1 if plan.Lc == 0 and N + 128 <= plan.L else 0)
+    # other impulse-response lengths (runtime-size path): even circular lengths always plan, odd ones never (the reference's
+    # rfft / irfft pair is not a circular convolution there: generators of csrc/generic.hip)
+    assert L.nws_reverb_plan(100, 88200, C.byref(plan)) == 0 and (plan.L, plan.Lc, plan.hist, plan.nblk) == (128000, 88200, 88199, 1)
+    assert L.nws_reverb_plan(441000, 44100, C.byref(plan)) == 0 and plan.Lc == 441000 and plan.hist == 44099
+    assert L.nws_reverb_plan(1000, 1030, C.byref(plan)) == 0 and (plan.L, plan.Lc) == (32000, 1030)
+    assert L.nws_reverb_plan(1001, 900, C.byref(plan)) == -1
+    assert L.nws_reverb_plan(100, 1029, C.byref(plan)) == -1
+
+
+def test_reverb_plan_rejects_bad_arguments():
+    plan = _lib.NwsReverbPlan()
     assert _lib.lib().nws_reverb_plan(0, 32000, C.byref(plan)) == -2
+    assert _lib.lib().nws_reverb_plan(64000, 0, C.byref(plan)) == -2
+    assert _lib.lib().nws_reverb_plan((1 << 30) + 2, 32000, C.byref(plan)) == -2
 
 
 def test_bad_arguments_return_codes_without_touching_the_gpu():

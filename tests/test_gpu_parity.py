@@ -392,8 +392,12 @@ def test_fir_noise_batched_mfma_path(models, oracle, B, T):
     assert maxabs(out2, add.cpu().numpy() + out) <= 1e-6
 
 
-# 256, 640, 1024: the time-domain form of short buffers (csrc/reverb_fft.hip reverb_direct_kernel); 1152 and up: the FFT
-@pytest.mark.parametrize("N", [256, 640, 1024, 1152, 4096, 32000, 64000, 128 * 501])
+# 256, 640, 1024: the time-domain form of short buffers (csrc/reverb_fft.hip reverb_direct_kernel); 1152 and up: the FFT -
+# direct plans with 125 columns (32000, 64000, 128 x 2000 = 125 x 2048) or a DFT-matrix column pass (128 x 504 = 63 x 1024,
+# 128 x 512 = 32 x 2048), and overlap-save plans for every other length: 128 x 251 (two blocks of 64000 whose history wraps
+# around Lc = 32128 twice), 128 x 501 (one block of 128000), 128 x 8193 = 65.5 s and 128 x 9375 = 75 s (blocks of 256000)
+@pytest.mark.parametrize("N", [256, 640, 1024, 1152, 4096, 32000, 128 * 251, 64000, 128 * 501, 128 * 504, 128 * 512, 128 * 2000,
+                               128 * 8193, 128 * 9375])
 def test_reverb_stage(models, oracle, N):
     m, _ = models
     torch.manual_seed(N)
@@ -405,6 +409,55 @@ def test_reverb_stage(models, oracle, N):
     assert err <= 3e-6 * rms(ref), (err, rms(ref))   # both sides are fp32 FFTs; relative 1e-6 class
     y2 = m.reverb(x.cuda()).cpu().numpy()             # stand-alone module forward uses the same kernels
     assert np.array_equal(y, y2)
+
+
+@pytest.mark.parametrize("n2", [256, 512, 1024, 2048])
+def test_reverb_overlap_save_block_sizes(models, oracle, n2, monkeypatch):
+    """Every block size of the overlap-save plan (125 x 256 .. 125 x 2048 points; NWS_REVERB_OLS_N2 pins what the cost model
+    would choose) against torch's FFT result, on a length whose history wraps (N = 128 x 1001: Lc = N)."""
+    import ctypes as C
+    from nws_amd import _lib
+    if n2 == 256:
+        pytest.skip("125 x 256 = 32000 points cannot hold 31999 samples of history plus output")
+    monkeypatch.setenv("NWS_REVERB_OLS_N2", str(n2))
+    m, _ = models
+    N = 128 * 1001
+    plan = _lib.NwsReverbPlan()
+    assert _lib.lib().nws_reverb_plan(N, 32000, C.byref(plan)) == 0
+    assert (plan.N1, plan.N2, plan.Lc, plan.hist) == (125, n2, N, 31999) and plan.nblk == -(-N // (125 * n2 - 31999))
+    from nws_amd import engine as nws_engine
+    nws_engine._PLAN_CACHE.clear()
+    try:
+        torch.manual_seed(n2)
+        x = torch.randn(5, N)
+        ref = oracle[0].reverb(x).numpy()
+        y = m._engine.reverb(x.cuda()).cpu().numpy()
+    finally:
+        nws_engine._PLAN_CACHE.clear()
+    err = rms(y - ref)
+    record(f"reverb_ols_n2_{n2}", rms_err=err, ref_rms=rms(ref))
+    assert err <= 3e-6 * rms(ref), (err, rms(ref))
+
+
+@pytest.mark.parametrize("T", [8193, 9375, 10001, 37500])
+def test_long_clips_render_and_match_the_oracle(models, oracle, T):
+    """One-shot forwards of lengths the round-3 reverb plan refused (65.5 s, 75 s, 80 s, 5 min - Colab cell 18
+    renders whole files): B = 2, FastNEWT, row 1 against the oracle's forward (row 0 differs: its F0 glides), <= 1e-4 RMS."""
+    m, o = models[1], oracle[1]
+    g = torch.Generator().manual_seed(T)
+    t = torch.arange(T, dtype=torch.float32) / 125.0
+    f0 = torch.stack([220.0 * 2.0 ** (t / t[-1]), 330.0 + 6.0 * torch.sin(2 * np.pi * 5.5 * t)])[:, None, :]
+    control = torch.randn(2, 2, T, generator=g).cumsum(-1) * 0.05
+    control = (control - control.mean(-1, keepdim=True)) / control.std(-1, keepdim=True)
+    pu, nz = torch.rand(101, generator=g), torch.rand(128 * T - 1, generator=g)
+    with torch.no_grad():
+        y = m(f0.cuda(), control.cuda(), phase_u=pu.cuda(), noise=nz.cuda()).cpu().numpy()
+    assert y.shape == (2, 128 * T) and np.isfinite(y).all()
+    ref = o(f0[1:2], control[1:2], pu, nz).numpy()
+    err = rms(y[1:2] - ref)
+    record(f"long_clip_T{T}", rms_err=err, out_rms=rms(ref), seconds=T * 128 / 16000.0)
+    assert err <= 1e-4 and err <= 2e-4 * rms(ref), (T, err, rms(ref))
+    assert rms(y[0]) > 1e-3 and rms(y[0] - y[1]) > 1e-3
 
 
 def test_lut_table_and_lookup(models, oracle):
