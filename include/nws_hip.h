@@ -457,10 +457,10 @@ int nws_g_film_shaper(const NwsShaperDesc* d, const float* exciter, const float*
 int nws_g_fir_design(const float* H, const float* window, int fir_len, int B, int T, float* fir_out, void* stream);
 int nws_g_fir_noise(const float* fir, const float* noise, int fir_len, int hop, int B, int T, const float* add_in,
                     int add_channels, float* out, void* stream);
-/* Reverb.forward without a transform plan (any lengths; the four-step FFT of nws_reverb needs L = N1 * 2^k, N1 <= 8192, 32 | L):
+/* Reverb.forward without a transform plan (nws_reverb_plan serves every even circular length; this entry point is what is left):
  * the circular convolution summed in the time domain when L = max(N, ir_len + 1) is even; for ODD L the reference's own
- * rfft(L) / irfft(L - 1) result (shaping.py:171-173 passes no length to irfft), evaluated in float64 with stream-ordered
- * scratch (hipMallocAsync); NWS_ERR_UNSUPPORTED for odd L > 65537 */
+ * rfft(L) / irfft(L - 1) result (shaping.py:171-173 passes no length to irfft: not a circular convolution), evaluated in float64
+ * at O(L^2) with stream-ordered scratch (hipMallocAsync); NWS_ERR_UNSUPPORTED for odd L > 2^22 */
 int nws_g_reverb_direct(const float* x, const float* ir, int ir_len, int B, int N, float* y, void* stream);
 
 size_t nws_forward_generic_workspace_bytes(const NwsGenericModel* m, int B, int T);

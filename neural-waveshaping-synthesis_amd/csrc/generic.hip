@@ -668,7 +668,7 @@ int nws_g_reverb_direct(const float* x, const float* ir, int ir_len, int B, int 
   const int Lc = N > ir_len + 1 ? N : ir_len + 1;
   if (Lc & 1) {
     // odd circular length: the reference's own (non-convolution) result, see g_odd_* above; scratch is stream-ordered
-    if (Lc > 65537 || Lc < 3) return NWS_ERR_UNSUPPORTED;
+    if (Lc > (1 << 22) || Lc < 3) return NWS_ERR_UNSUPPORTED;   // O(Lc^2) in float64: seconds at 2^20, not a real-time path
     const int M = Lc - 1, K = M / 2 + 1;
     hipStream_t st = (hipStream_t)stream;
     const size_t bytes = ((size_t)Lc + M + K + (size_t)B * K) * sizeof(double2);

@@ -335,7 +335,7 @@ class Reverb(nn.Module):
 
         probe = NwsReverbPlan()
         if sa._lib.lib().nws_reverb_plan(int(N), int(ir.numel()) + 1, C.byref(probe)) != 0:
-            # circular length without a (N1 <= 8192) x 2^k factorisation: time-domain form (csrc/generic.hip)
+            # odd circular length (every even one has a plan): the reference's own rfft / irfft expression (csrc/generic.hip)
             def d_call(lib):
                 y = torch.empty_like(x)
                 with torch.cuda.device(x.device):
