@@ -187,7 +187,7 @@ int nws_frame_mlps(const NwsWeights* w, const float* gru_out, const float* fir_d
 
 /* pre-split weight fragments for the fp16 two-term frame-MLP kernel (valid while |layer inputs| stay inside fp16 range:
  * the caller checks the weight-norm bounds, see engine.py) */
-#define NWS_MLP_FRAGS_BYTES 745472
+#define NWS_MLP_FRAGS_BYTES 1474560
 int nws_mlp_frags(const NwsWeights* w, const float* fir_design /* (256,132) */, void* frags_out, void* stream);
 
 /* D[n][k]: fir[n] = sum_k D[n][k] H[k]  (irfft + roll(128) + window folded), (256, 132) fp32, cols 129..131 = 0. */
@@ -470,6 +470,11 @@ int nws_forward_generic(const NwsGenericModel* m, const float* f0, const float* 
                         const float* phase_u, const float* rand_phase, const float* noise, const NwsReverbPlan* plan,
                         const void* reverb_tables, const void* reverb_spectrum, void* reverb_workspace,
                         size_t reverb_workspace_bytes, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Measurements / tests: which frame-MLP kernel nws_frame_mlps launches - 0 automatic (wave-resident frames from 8192 frames up,
+ * tile kernels below; env NWS_MLP_KERNEL=tiles|frames), 1 the tile kernels, 2 wave-resident frames at any size. */
+int nws_debug_frame_mlps_kernel(int mode);
+int nws_debug_frame_mlps_probe(void* buf /* device, 4096 B: cycle timeline written by mode 2 + (6 << 8) */);
 
 /* Diagnostics only: ablation variants of the fused kernel for timing (1 no sin, 2 no LUT gather, 3 no shaper tail,
  * 4 no MFMA; 0 = product kernel).  Outputs of variants != 0 are meaningless. */

@@ -22,7 +22,7 @@ HIDDEN = 128
 HOP = 128
 FIR_LEN = 256
 FIR_HALF = 128           # taps per row handed from the frame MLPs to the noise kernels: h[128 .. 255] (include/nws_hip.h)
-MLP_FRAGS_BYTES = 745472
+MLP_FRAGS_BYTES = 1474560
 N_BANDS = 129
 FILM_CH = 256
 SHAPER_WIDTH = 8
@@ -102,6 +102,8 @@ _PROTOTYPES = {
     "nws_control_gru_batched": (C.c_int, [C.POINTER(NwsWeights), _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
     "nws_frame_mlps": (C.c_int, [C.POINTER(NwsWeights), _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp]),
     "nws_mlp_frags": (C.c_int, [C.POINTER(NwsWeights), _fp, _fp, _fp]),
+    "nws_debug_frame_mlps_kernel": (C.c_int, [C.c_int]),
+    "nws_debug_frame_mlps_probe": (C.c_int, [_fp]),
     "nws_fir_design_matrix": (C.c_int, [_fp, _fp, _fp]),
     "nws_fir_noise": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp]),
     "nws_fir_noise_window": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp, _fp]),

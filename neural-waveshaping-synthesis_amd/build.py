@@ -86,6 +86,57 @@ def check_packed_swizzles(obj):
     return found
 
 
+def _vgprs(tok):
+    """'v[4:7]' -> {4..7}, 'v9' -> {9}; anything else (sgprs, constants, agprs) -> empty"""
+    import re
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def check_valu_mfma_hazard(obj, wait_states=2):
+    """gfx940-class rule: a VGPR written by a (non-matrix) VALU instruction must not be read by a v_mfma within the next
+    `wait_states` wait states.  hipcc places those itself for the instructions it schedules, but it does not see through INLINE
+    ASM: round 4 found a layer's first MFMA reading a stale B operand that an inline-asm v_fma_mixhi_f16 had written two
+    instructions earlier (csrc/frame_mlps.hip, wr_split2).  Every v_mfma in the device code is checked against the
+    instructions in front of it (s_nop N counts N + 1 wait states; branch targets end the look-back).
+    Returns [(kernel, producer, mfma), ...]."""
+    import re
+    found, kernel, window = [], None, []      # window: [(wait states this instruction accounts for, dest vgprs, text)]
+    for line in device_disassembly(obj).splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            kernel, window = m.group(1), []
+            continue
+        parts = line.split("//")[0].split("\t")
+        text = " ".join(" ".join(parts[1:]).split()) if len(parts) > 1 else ""
+        if not text:
+            continue
+        op = text.split()[0]
+        ops = [t.strip() for t in text[len(op):].split(",")]
+        if op.startswith("v_mfma") or op.startswith("v_smfmac"):
+            srcs = set().union(*[_vgprs(t.split()[0]) for t in ops[1:4] if t])
+            left = wait_states
+            for ws, dst, ptext in reversed(window):
+                if left <= 0:
+                    break
+                if dst & srcs:
+                    found.append((kernel, ptext, text))
+                left -= ws
+        if op == "s_nop":
+            window.append((int(ops[0], 0) + 1, set(), text))
+        elif op.startswith("s_cbranch") or op in ("s_branch", "s_barrier", "s_endpgm", "s_setpc_b64"):
+            window = []
+        elif op.startswith("v_") and not op.startswith("v_mfma") and not op.startswith("v_smfmac") and not op.startswith("v_cmp"):
+            window.append((1, _vgprs(ops[0].split()[0]) if ops and ops[0] else set(), text))
+        else:
+            window.append((1, set(), text))
+        window = window[-8:]
+    return found
+
+
 def build_torch_ops(force=False, verbose=True):
     """torch.ops.newt_hip.*: one host-only translation unit (no kernels) compiled with g++ against the torch headers and linked
     to libnws_hip.so next to it.  Needs an importable torch; returns None (with a note) when there is none - the ctypes
@@ -162,6 +213,11 @@ def build_hip(force=False, verbose=True):
             lines = "\n".join(f"  {k}: {i}" for k, i in swz[:12])
             raise RuntimeError(f"{src}: packed fp32 instructions with a swizzled src1 low lane (co-execution hazard, see "
                                f"check_packed_swizzles):\n{lines}")
+        haz = check_valu_mfma_hazard(obj)
+        if haz:
+            lines = "\n".join(f"  {k}: {p}  ->  {m}" for k, p, m in haz[:12])
+            raise RuntimeError(f"{src}: v_mfma reads a VGPR that a VALU instruction wrote less than 2 wait states earlier (inline asm "
+                               f"in front of a matrix instruction? see check_valu_mfma_hazard):\n{lines}")
         if verbose and "\n".join(rest).strip():
             print("\n".join(rest), file=sys.stderr)
         return obj

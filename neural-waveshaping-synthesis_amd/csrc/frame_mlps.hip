@@ -17,6 +17,7 @@
 // Outputs that the sample-rate kernels read frame-major (film, fir) are transposed per wave
 // through a 4 KB LDS patch so every global store is a full 128 B segment.
 #include <cstdlib>
+#include <cstring>
 
 #include "nws_common.h"
 
@@ -255,7 +256,7 @@ __host__ __device__ constexpr FragMap frag_map(int id) {
                  : FragMap{41984, 4, 9};   // rows 128..255 of D only (upper half-taps)
 }
 constexpr int kFragTotal = 46592;  // x 16 B = 745472 B
-static_assert(kFragTotal * 16 == NWS_MLP_FRAGS_BYTES, "fragment table size");
+static_assert(kFragTotal * 16 + 712 * 1024 == NWS_MLP_FRAGS_BYTES, "fragment tables: tile kernels | wave-resident kernel");
 
 struct MlpLds16 {
   char xt[4][2][kXtBytes];     // four activation buffers E, X, Y, Z, each [hi|lo]; dead ones double as store patches
@@ -768,6 +769,447 @@ __global__ __launch_bounds__(512, 2) void frame_mlps64_kernel(NwsWeights w, cons
   }
 }
 
+// =====================================================================================================================
+// Wave-resident frames (round 4).  The kernels above give every wave one M-tile of a layer and pass the
+// activations from wave to wave through LDS: ten workgroup-wide phases per tile, each an MFMA burst, a cross-wave LayerNorm
+// exchange, a split and a barrier (MFMA busy 23 %, 77 % of the wave cycles waiting).  Here a wave OWNS 32 frames and runs the
+// whole chain on them in registers:
+//   * the D layout of a 32x32x16 MFMA gives lane (frame j, half h) the channels 32 mt + 8 q + 4 h + i of its frame, and the B
+//     operand of the next layer wants lane (j, h) to hold eight k indices of the same frame - the contraction order is free,
+//     so the weight fragments are stored in the order the accumulators come out (kperm_d below) and a layer's output becomes
+//     the next layer's operand with no LDS round trip and no cross-lane traffic;
+//   * LayerNorm statistics are in-lane sums over 64 values plus ONE half swap - no cross-wave exchange, no barrier;
+//   * the weights are what is shared: every layer's pre-split fragments (64-72 KB) are copied into LDS by the DMA path
+//     (global_load_lds_dwordx4) one layer ahead, double buffered, and read by all eight waves as A operands (ds_read_b128,
+//     lane-linear, conflict-free) - 8 x 32 = 256 frames per 712 KB of fragment traffic instead of 64;
+//   * newt.mlp and h_generator are separate workgroups (blockIdx.y; both compute proj: 9 % more MFMAs) so that one layer of
+//     one path fits a 72 KB slot; B x T = 32000 frames -> 125 + 125 workgroups, one round on 256 CUs, two waves per SIMD;
+//   * the output layers (film, fir) run TRANSPOSED (activations as the A operand, weights as B: the same register contents),
+//     so the accumulators come out as lane = channel, register = frame and every store instruction writes two full 128 B
+//     segments of frame-major rows straight from registers - no transposition patches;
+//   * band 128 of H (the 129th row of h_generator's last layer) is a 128-term fp32 dot product on the vector pipe.
+// Frames are the flattened (b, t) index: every tensor here is frame-major and contiguous, so tiles need not respect
+// utterance boundaries.  6 workgroup barriers per 256 frames (they only guard the reuse of a weight slot).
+// Measured on MI355X at B x T = 64 x 500 (rocprofv3, one stream, inside whole forwards): 41.5 us against 57.7 us for
+// frame_mlps64_kernel; tools/mlp_variants.py, tools/mlp_timeline.py.  What the time is: 1164 MFMAs per SIMD (37 K cycles of the
+// matrix pipe) and ~2 x 2700 vector instructions that do not overlap them (no MFMAs: 15 us; no LayerNorm arithmetic -3.6, no split
+// -5.8); s_setprio around the MFMA phases -5 %.  Measured and dropped: waves 4..7 half a layer out of phase with waves 0..3 (a SIMD
+// would always have one wave in its MFMA phase and one in its vector phase): same time; the three products of a K-step issued
+// across the M-tiles instead of per accumulator: same time.
+// =====================================================================================================================
+constexpr int kWrFrames = 256;
+constexpr int kWrSlot = 72 * 1024;
+constexpr int kWrPar = 1600;
+struct WrLds {
+  char slot[2][kWrSlot];
+  float par[kWrPar];   // proj_b | 3 x (bias, ln gain, ln offset) | out-layer bias (256) resp. bias (128), w128 (128), b128
+};
+static_assert(sizeof(WrLds) <= 160 * 1024, "LDS");
+
+// second fragment table (behind the first): chunk offsets in KB; [M-tile][K-step][hi | lo][lane] x 16 B per chunk
+constexpr int kT2Base = kFragTotal * 16;
+constexpr int kT2Kb[2][6] = {{0, 64, 128, 192, 256, 320}, {0, 384, 448, 512, 576, 640}};
+constexpr int kT2Bytes = 712 * 1024;
+static_assert(kT2Base + kT2Bytes == NWS_MLP_FRAGS_BYTES, "fragment table size");
+
+// contraction order of a layer whose input is (a) the GRU output read from memory: lane half h holds channels 64 h .. 64 h + 63
+// of its frame; (b) a previous layer's accumulators: K-step (mt, g) holds registers 8 g .. 8 g + 7 of M-tile mt
+__host__ __device__ constexpr int kperm_in(int ks, int h, int i) { return 64 * h + 8 * ks + i; }
+__host__ __device__ constexpr int kperm_d(int ks, int h, int i) { return 32 * (ks >> 1) + 16 * (ks & 1) + 4 * h + i + (i >= 4 ? 4 : 0); }
+
+struct WrAct {
+  f16x8 hi[9], lo[9];   // K-steps 0..7: 128 channels of this lane's frame; 8: band 128 of H (FIR design only)
+};
+
+// (hi, lo) split in plain arithmetic: the results feed MFMAs straight from registers, and hipcc does not see through inline
+// asm when it places the wait states a VALU-write -> MFMA-read pair needs (split2's v_fma_mix as inline asm gave wrong first
+// products of a layer here; the tile kernels pass their splits through LDS)
+// hi = the top 11 significant bits (a mask: exactly representable in fp16 wherever fp16 is normal), lo = the exact remainder
+// rounded to fp16: 22 bits per value like round-then-subtract, with two v_and instead of two conversions back to fp32.
+// (Below 2^-14 the fp16 conversion of hi rounds by <= 2^-25 absolute that lo does not see: nothing against O(1) activations.)
+__device__ __forceinline__ void wr_split2(float a, float b, f16x2& hi, f16x2& lo) {
+  const float ha = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & 0xFFFFE000u);
+  const float hb = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) & 0xFFFFE000u);
+  hi = __builtin_convertvector(f32x2{ha, hb}, f16x2);
+  lo = __builtin_convertvector(f32x2{a - ha, b - hb}, f16x2);
+}
+__device__ __forceinline__ void wr_pack8(const float (&y)[8], f16x8& hi, f16x8& lo) {
+  f16x2 h0, l0, h1, l1, h2, l2, h3, l3;
+  wr_split2(y[0], y[1], h0, l0);
+  wr_split2(y[2], y[3], h1, l1);
+  wr_split2(y[4], y[5], h2, l2);
+  wr_split2(y[6], y[7], h3, l3);
+  hi = f16x8{h0.x, h0.y, h1.x, h1.y, h2.x, h2.y, h3.x, h3.y};
+  lo = f16x8{l0.x, l0.y, l1.x, l1.y, l2.x, l2.y, l3.x, l3.y};
+}
+
+// this wave's share (1/8) of a chunk: global -> LDS by the DMA path, 1 KB per instruction
+__device__ __forceinline__ void wr_dma(const char* __restrict__ src, char* dst, int kb, int wave, int lane) {
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int per = kb * 128;   // bytes per wave: 8192 or 9216
+  const char* s = src + wave * per + lane * 16;
+  char* d = dst + wave * per;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) __builtin_amdgcn_global_load_lds((gptr_t)(s + j * 1024), (lptr_t)(d + j * 1024), 16, 0, 0);
+  if (kb == 72) __builtin_amdgcn_global_load_lds((gptr_t)(s + 8192), (lptr_t)(d + 8192), 16, 0, 0);
+}
+
+// NMT M-tiles of one layer against the lane's frame: acc[mt] += W[mt] X (standard orientation: weights as A, activations as B;
+// accumulators = channels x frames) or, TRANSPOSED, acc[mt] += X^T W[mt]^T (activations as A, weights as B: frames x channels).
+// The weight fragments come from LDS (lane-linear 1 KB pieces, [mt][ks][hi | lo]).  Steps run K-major over the M-tiles (NMT
+// independent accumulator chains) and the fragments of step s + 2 are requested before the three MFMAs of step s are issued:
+// left to itself hipcc requests each pair right in front of its first use and the matrix pipe idles for an LDS latency per
+// three MFMAs (measured: 34 us of a 49 us kernel in the MFMA phases against 16 us of MFMA time).
+#ifndef NWS_WR_PRIO
+#define NWS_WR_PRIO 1
+#endif
+
+template <int KS, int NMT, bool TRANSPOSED, bool ZERO = false, bool NOLDS = false, bool PRIO = NWS_WR_PRIO>
+__device__ __forceinline__ void wr_layer_mma(const char* slot, int mt0, const WrAct& x, f32x16* acc, int lane) {
+  const char* a = slot + (size_t)mt0 * KS * 2048 + lane * 16;
+  constexpr int S = KS * NMT;
+  f16x8 wh[3], wl[3];
+  auto ld = [&](int s2, int b) {
+    if (NOLDS && s2 > 2) return;    // timing ablation: the first three steps' fragments serve every step
+    const int mt = s2 % NMT, ks = s2 / NMT;
+    wh[b] = *reinterpret_cast<const f16x8*>(a + (mt * KS + ks) * 2048);
+    wl[b] = *reinterpret_cast<const f16x8*>(a + (mt * KS + ks) * 2048 + 1024);
+  };
+  ld(0, 0);
+  if (S > 1) ld(1, 1);
+  __builtin_amdgcn_sched_barrier(0x6);
+  if (PRIO) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+  for (int s2 = 0; s2 < S; ++s2) {
+    const int mt = s2 % NMT, ks = s2 / NMT, b = s2 % 3;
+    if (s2 + 2 < S) ld(s2 + 2, (s2 + 2) % 3);
+    __builtin_amdgcn_sched_barrier(0x6);
+    if (!TRANSPOSED) {
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[b], x.lo[ks], (ZERO && ks == 0) ? f32x16{} : acc[mt], 0, 0, 0);
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[b], x.hi[ks], acc[mt], 0, 0, 0);
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[b], x.hi[ks], acc[mt], 0, 0, 0);
+    } else {
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x.lo[ks], wh[b], (ZERO && ks == 0) ? f32x16{} : acc[mt], 0, 0, 0);
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x.hi[ks], wl[b], acc[mt], 0, 0, 0);
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x.hi[ks], wh[b], acc[mt], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0x6);   // vector / scalar ALU work may move across (the previous layer's split is interleaved
+                                           // here by the compiler), LDS reads and MFMAs stay in this order
+  }
+  if (PRIO) __builtin_amdgcn_s_setprio(0);
+}
+
+// the lane's 64 entries of a per-channel vector (channels 32 mt + 8 q + 4 h + i) as four accumulator-shaped tiles
+__device__ __forceinline__ void wr_lane_vec(const float* par, int half, f32x16 (&v)[4]) {
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 t = *reinterpret_cast<const float4*>(par + 32 * mt + 8 * q + 4 * half);
+      v[mt][4 * q + 0] = t.x;
+      v[mt][4 * q + 1] = t.y;
+      v[mt][4 * q + 2] = t.z;
+      v[mt][4 * q + 3] = t.w;
+    }
+}
+
+// four accumulator tiles (128 channels of the lane's frame) -> operand of the next layer
+template <bool CHEAP = false>
+__device__ __forceinline__ void wr_pack(const f32x16 (&v)[4], WrAct& out) {
+  if (CHEAP) {   // timing ablation: no split arithmetic
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      out.hi[ks] = __builtin_bit_cast(f16x8, f32x4{v[ks >> 1][8 * (ks & 1)], v[ks >> 1][8 * (ks & 1) + 1], v[ks >> 1][8 * (ks & 1) + 2], v[ks >> 1][8 * (ks & 1) + 3]});
+      out.lo[ks] = __builtin_bit_cast(f16x8, f32x4{v[ks >> 1][8 * (ks & 1) + 4], v[ks >> 1][8 * (ks & 1) + 5], v[ks >> 1][8 * (ks & 1) + 6], v[ks >> 1][8 * (ks & 1) + 7]});
+    }
+    return;
+  }
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float y[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) y[i] = v[mt][8 * g + i];
+      wr_pack8(y, out.hi[2 * mt + g], out.lo[2 * mt + g]);
+    }
+}
+
+// LeakyReLU(LayerNorm(v)) over the 128 channels of the lane's frame (v includes the bias), in place
+__device__ __forceinline__ void wr_layer_norm(f32x16 (&v)[4], const float* g, const float* bt, int half) {
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    s0 += v[0][r];
+    s1 += v[1][r];
+    s2 += v[2][r];
+    s3 += v[3][r];
+  }
+  float s = (s0 + s1) + (s2 + s3);
+  s += nws_swap_halves(s);
+  const float mean = s * (1.0f / NWS_HIDDEN);
+  float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    v[0][r] -= mean;
+    v[1][r] -= mean;
+    v[2][r] -= mean;
+    v[3][r] -= mean;
+    q0 = fmaf(v[0][r], v[0][r], q0);
+    q1 = fmaf(v[1][r], v[1][r], q1);
+    q2 = fmaf(v[2][r], v[2][r], q2);
+    q3 = fmaf(v[3][r], v[3][r], q3);
+  }
+  float q = (q0 + q1) + (q2 + q3);
+  q += nws_swap_halves(q);
+  const float rstd = 1.0f / sqrtf(q * (1.0f / NWS_HIDDEN) + kLnEps);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int c = 32 * mt + 8 * qd + 4 * half;
+      const float4 g4 = *reinterpret_cast<const float4*>(g + c), b4 = *reinterpret_cast<const float4*>(bt + c);
+      const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float y = fmaf(v[mt][4 * qd + i] * rstd, gg[i], bb[i]);
+        v[mt][4 * qd + i] = fmaxf(y, 0.01f * y);
+      }
+    }
+}
+
+// a transposed accumulator tile (lane = channel, register r = frame f0 + frag_row(r, half)) -> frame-major rows of LD floats: two
+// full 128 B segments per store instruction.  Buffer stores: ONE per-lane byte offset for every tile of the wave (the tile's
+// channel offset and the row r & 3 ride in the instruction's immediate, the row group r >> 2 in a scalar offset) and the
+// descriptor's size drops the rows of frames >= F - no address arithmetic and no guards on the vector pipe.
+template <int LD, bool BIAS>
+__device__ __forceinline__ void wr_store_rows(__amdgpu_buffer_rsrc_t out, const f32x16& acc, int lane_off, int tile, float bias) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, BIAS ? acc[r] + bias : acc[r]), out,
+                                          lane_off + ((r & 3) * LD + 32 * tile) * 4, 8 * (r >> 2) * LD * 4, 0);
+}
+
+// ABL: timing ablations (results meaningless): 1 no LayerNorm / LeakyReLU arithmetic, 2 no MFMAs (and no weight reads), 3 MFMAs without their weight reads from LDS, 5 no
+// (hi, lo) split arithmetic; 6: product arithmetic + cycle timeline (s_memtime probes, tools/mlp_timeline.py)
+template <bool TAPS, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void frame_mlps_wr_kernel(NwsWeights w, const float* __restrict__ gru_out, int F, int T,
+                                                                 float* __restrict__ emb_out, float* __restrict__ film_out,
+                                                                 float* __restrict__ H_out, float* __restrict__ fir_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  WrLds& L = *reinterpret_cast<WrLds*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int path = blockIdx.y;                      // 0: proj + newt.mlp -> film; 1: proj + h_generator -> H -> fir
+  const int half = lane >> 5, col = lane & 31;
+  const int f0 = blockIdx.x * kWrFrames + 32 * wave; // first frame of this wave
+  const int frame = f0 + col;                        // this lane's frame (standard orientation)
+  const char* T2 = static_cast<const char*>(w.mlp_frags) + kT2Base;
+  char* const S0 = L.slot[0];
+  char* const S1 = L.slot[1];
+
+  // ---- prologue.  Weight chunk 0 is requested first (the long pole: 64 KB per workgroup), then the parameter vectors (<= 4
+  // values per thread) and this lane's GRU row, all unconditional loads in flight together; hipcc waits for every outstanding
+  // request in front of the first use of a loaded register while an LDS-bound load is in flight, so chunk 1 is requested only
+  // after that point, LAST: the first barrier waits for everything but the eight most recent requests (memory reads return in
+  // order) and the first layer runs while chunk 1 is still arriving ----
+  wr_dma(T2 + (size_t)kT2Kb[0][0] * 1024, S0, 64, wave, lane);
+  const int grp = wave >> 1, pc = tid & 127;
+  float pv[4];
+  {
+    // vector n of the parameter block goes to par[128 n ..]; quarter `grp` of the workgroup fetches vectors grp, grp + 4, ...
+    // (compile-time struct indices selected by scalar compares: a run-time index into the by-value struct would be a private copy)
+    auto sel4 = [&](const float* a, const float* b, const float* c, const float* d) { return grp == 0 ? a : grp == 1 ? b : grp == 2 ? c : d; };
+    const float* const hb0 = path ? w.hgen_b[0] : w.newt_mlp_b[0];
+    const float* const hg0 = path ? w.hgen_ln_g[0] : w.newt_ln_g[0];
+    const float* const ht0 = path ? w.hgen_ln_b[0] : w.newt_ln_b[0];
+    const float* const hb1 = path ? w.hgen_b[1] : w.newt_mlp_b[1];
+    const float* const hg1 = path ? w.hgen_ln_g[1] : w.newt_ln_g[1];
+    const float* const ht1 = path ? w.hgen_ln_b[1] : w.newt_ln_b[1];
+    const float* const hb2 = path ? w.hgen_b[2] : w.newt_mlp_b[2];
+    const float* const hg2 = path ? w.hgen_ln_g[2] : w.newt_ln_g[2];
+    const float* const ht2 = path ? w.hgen_ln_b[2] : w.newt_ln_b[2];
+    const float* const ob = path ? w.hgen_b[3] : w.newt_mlp_b[3];
+    const float* const ox = path ? w.hgen_w[3] + (size_t)128 * NWS_HIDDEN : w.newt_mlp_b[3] + 128;
+    pv[0] = sel4(w.proj_b, hb0, hg0, ht0)[pc];
+    pv[1] = sel4(hb1, hg1, ht1, hb2)[pc];
+    pv[2] = sel4(hg2, ht2, ob, ox)[pc];
+    pv[3] = w.proj_b[pc];   // (vector 12 does not exist: quarter 0 rewrites vector 0 with the same values)
+  }
+  const float b128 = path ? w.hgen_b[3][128] : 0.0f;
+  float4 in[16];
+  {
+    // (frames >= F read the last row: their results are never stored)
+    const float4* src = reinterpret_cast<const float4*>(gru_out + (size_t)(frame < F ? frame : F - 1) * NWS_HIDDEN + 64 * half);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) in[k] = src[k];
+  }
+  L.par[128 * grp + pc] = pv[0];
+  L.par[128 * (4 + grp) + pc] = pv[1];
+  L.par[128 * (8 + grp) + pc] = pv[2];
+  if (grp == 0) L.par[pc] = pv[3];
+  if (tid == 0) L.par[1536] = b128;
+  // (the conversion of the GRU row stays in front of the request for chunk 1: a first use of a loaded register behind it
+  // would make hipcc wait for chunk 1 as well)
+  WrAct X;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const float y[8] = {in[2 * ks].x, in[2 * ks].y, in[2 * ks].z, in[2 * ks].w, in[2 * ks + 1].x, in[2 * ks + 1].y, in[2 * ks + 1].z, in[2 * ks + 1].w};
+    wr_pack8(y, X.hi[ks], X.lo[ks]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  wr_dma(T2 + (size_t)(path ? kT2Kb[1][1] : kT2Kb[0][1]) * 1024, S1, 64, wave, lane);   // the wave's 8 most recent requests
+  __builtin_amdgcn_sched_barrier(0);
+  // barrier k closes interval k: every wave has finished reading slot (k - 1) & 1, and its share of chunk k (requested one
+  // interval earlier) has landed; then chunk k + 1 goes into the slot just released
+  // ABL == 6: cycle timeline - s_memtime at numbered points, every wave of workgroup (0, path), into emb_out as long long [path][wave][32]
+  int probe_n = 0;
+  auto probe = [&]() {
+    if (ABL == 6 && blockIdx.x == 0 && lane == 0 && probe_n < 32)
+      reinterpret_cast<long long*>(emb_out)[(path * 8 + wave) * 32 + probe_n] = (long long)__builtin_readcyclecounter();
+    ++probe_n;
+  };
+  probe();   // 0: prologue done (DMA requested, inputs converted)
+  auto sync = [&](int k) {
+    probe();
+    if (k == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // everything but chunk 1
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (not __syncthreads(): hipcc puts a vmcnt(0) in front of it while LDS-bound loads are in flight, which would wait for
+    // chunk 1 as well; the LDS writes of the parameters are drained by the lgkmcnt(0))
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    probe();
+    if (k >= 1 && k <= 4) wr_dma(T2 + (size_t)(path ? kT2Kb[1][k + 1] : kT2Kb[0][k + 1]) * 1024, ((k + 1) & 1) ? S1 : S0, (path == 1 && k == 4) ? 72 : 64, wave, lane);
+  };
+  sync(0);
+
+  f32x16 v[4];
+  // ---- layer 0: emb = proj(gru_out) ----
+  wr_lane_vec(L.par, half, v);
+  if (ABL != 2) wr_layer_mma<8, 4, false, false, ABL == 3>(S0, 0, X, v, lane);
+  probe();
+  if (TAPS && path == 0 && emb_out != nullptr && frame < F) {
+    const int b = frame / T, t = frame - b * T;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) emb_out[((size_t)b * NWS_HIDDEN + 32 * mt + frag_row(r, half)) * T + t] = v[mt][r];
+  }
+  wr_pack<ABL == 5>(v, X);
+  probe();
+  sync(1);
+
+  // ---- three hidden layers: X = LeakyReLU(LayerNorm(W X + b)) ----
+  float h128 = 0.0f;
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    const float* par = L.par + 128 + 384 * l;
+    const char* slot = (l & 1) ? S0 : S1;          // chunks 1, 2, 3 -> slots 1, 0, 1
+    wr_lane_vec(par, half, v);
+    if (ABL != 2) wr_layer_mma<8, 4, false, false, ABL == 3>(slot, 0, X, v, lane);
+    probe();
+    if (ABL != 1) wr_layer_norm(v, par + 128, par + 256, half);
+    if (l == 2 && path == 1) {
+      // band 128 of H: fp32 dot product of the frame's 128 activations with row 128 of the last layer
+      f32x16 w128[4];
+      wr_lane_vec(L.par + 1408, half, w128);
+      float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        d0 = fmaf(v[0][r], w128[0][r], d0);
+        d1 = fmaf(v[1][r], w128[1][r], d1);
+        d2 = fmaf(v[2][r], w128[2][r], d2);
+        d3 = fmaf(v[3][r], w128[3][r], d3);
+      }
+      float d = (d0 + d1) + (d2 + d3);
+      d += nws_swap_halves(d);
+      h128 = d + L.par[1536];
+    }
+    wr_pack<ABL == 5>(v, X);
+    probe();
+    sync(l + 2);
+  }
+
+  if (path == 0) {
+    // ---- film = last layer of newt.mlp, transposed: lane = channel, register = frame; chunk 4 (slot 0): tiles 0..3, chunk 5: 4..7
+    const __amdgpu_buffer_rsrc_t film_rs = __builtin_amdgcn_make_buffer_rsrc(film_out, 0, F * NWS_FILM_CH * 4, 0x00020000);
+    const int lane_off = ((f0 + 4 * half) * NWS_FILM_CH + col) * 4;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const char* slot = c ? S1 : S0;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {           // two tiles at a time: two accumulator chains
+        f32x16 acc[2];
+        if (ABL != 2) wr_layer_mma<8, 2, true, true, ABL == 3>(slot, 2 * pr, X, acc, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          wr_store_rows<NWS_FILM_CH, true>(film_rs, acc[j], lane_off, 4 * c + 2 * pr + j, L.par[1280 + 32 * (4 * c + 2 * pr + j) + col]);
+      }
+      probe();
+      if (c == 0) sync(5);
+    }
+  } else {
+    // ---- H = last layer of h_generator (bands 0..127 on the matrix pipe, band 128 from above) -> operand of the FIR design ----
+    wr_lane_vec(L.par + 1280, half, v);
+    if (ABL != 2) wr_layer_mma<8, 4, false, false, ABL == 3>(S0, 0, X, v, lane);
+    if (TAPS && H_out != nullptr && frame < F) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H_out[(size_t)frame * NWS_N_BANDS + 32 * mt + frag_row(r, half)] = v[mt][r];
+      if (half == 0) H_out[(size_t)frame * NWS_N_BANDS + 128] = h128;
+    }
+    wr_pack(v, X);
+    {
+      const float y[8] = {half == 0 ? h128 : 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // kperm_d(8, 0, 0) = 128
+      wr_pack8(y, X.hi[8], X.lo[8]);
+    }
+    sync(5);
+    // ---- fir = D[128..255] H, transposed; K = 9 steps (129 bands) ----
+    const __amdgpu_buffer_rsrc_t fir_rs = __builtin_amdgcn_make_buffer_rsrc(fir_out, 0, F * NWS_FIR_HALF * 4, 0x00020000);
+    const int lane_off = ((f0 + 4 * half) * NWS_FIR_HALF + col) * 4;
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      f32x16 acc[2];
+      if (ABL != 2) wr_layer_mma<9, 2, true, true, ABL == 3>(S1, 2 * pr, X, acc, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wr_store_rows<NWS_FIR_HALF, false>(fir_rs, acc[j], lane_off, 2 * pr + j, 0.0f);
+    }
+    probe();
+  }
+}
+
+// second fragment table: the layers in the contraction orders of frame_mlps_wr_kernel
+__global__ void mlp_frags2_kernel(NwsWeights w, const float* __restrict__ fir_design, f16x8* __restrict__ out) {
+  // chunks: 0 proj | 1-3 newt hidden | 4 newt out (8 M-tiles) | 5-7 hgen hidden | 8 hgen out rows 0..127 | 9 FIR design (9 K-steps)
+  constexpr int kPairs[10] = {2048, 2048, 2048, 2048, 4096, 2048, 2048, 2048, 2048, 2304};   // (hi, lo) pairs per chunk
+  constexpr int kKb[10] = {0, 64, 128, 192, 256, 384, 448, 512, 576, 640};
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  int id = 0;
+  while (id < 10 && e >= kPairs[id]) e -= kPairs[id++];
+  if (id >= 10) return;
+  const int KS = id == 9 ? 9 : 8;
+  const int li = e & 63, ks = (e >> 6) % KS, mt = (e >> 6) / KS;
+  const int row = 32 * mt + (li & 31), h = li >> 5;
+  const float* W;
+  int rows, ld, kmax;
+  if (id == 0) { W = w.proj_w; rows = 128; ld = 128; kmax = 128; }
+  else if (id <= 4) { W = w.newt_mlp_w[id - 1]; rows = id == 4 ? 256 : 128; ld = 128; kmax = 128; }
+  else if (id <= 8) { W = w.hgen_w[id - 5]; rows = 128; ld = 128; kmax = 128; }
+  else { W = fir_design + (size_t)NWS_FIR_HALF * kDK; rows = NWS_FIR_HALF; ld = kDK; kmax = NWS_N_BANDS; }
+  f16x8 hi, lo;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = id == 0 ? kperm_in(ks, h, i) : (ks < 8 ? kperm_d(ks, h, i) : 128 + 4 * h + i + (i >= 4 ? 4 : 0));
+    const float v = (row < rows && k < kmax) ? W[(size_t)row * ld + k] : 0.0f;
+    hi[i] = (_Float16)v;
+    lo[i] = (_Float16)(v - (float)hi[i]);
+  }
+  f16x8* dst = out + (size_t)kKb[id] * 64 + ((size_t)(mt * KS + ks) * 2) * 64 + li;
+  dst[0] = hi;
+  dst[64] = lo;
+}
+
 // one thread per fragment pair: 8 consecutive-k weights of one row, split into hi / lo
 __global__ void mlp_frags_kernel(NwsWeights w, const float* __restrict__ fir_design, f16x8* __restrict__ out) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -835,6 +1277,23 @@ int nws_mlp_frags(const NwsWeights* w, const float* fir_design, void* frags_out,
   mlp_frags_kernel<<<(kFragTotal / 2 + 255) / 256, 256, 0, (hipStream_t)stream>>>(*w, fir_design,
                                                                                    static_cast<f16x8*>(frags_out));
   NWS_CHECK_LAUNCH();
+  mlp_frags2_kernel<<<(kT2Bytes / 32 + 255) / 256, 256, 0, (hipStream_t)stream>>>(
+      *w, fir_design, reinterpret_cast<f16x8*>(static_cast<char*>(frags_out) + kT2Base));
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+// measurements / tests: 0 automatic (by frame count, NWS_MLP_KERNEL), 1 tile kernels (frame_mlps16 / 64), 2 wave-resident frames
+static int g_mlp_kernel_mode = 0, g_mlp_dbg = 0;
+static void* g_mlp_probe = nullptr;
+int nws_debug_frame_mlps_probe(void* buf) {
+  g_mlp_probe = buf;   // 2 x 8 x 32 long long: s_memtime timeline of workgroups (0, path), ablation 6
+  return NWS_OK;
+}
+int nws_debug_frame_mlps_kernel(int mode) {
+  if (mode < 0 || (mode & 15) > 2) return NWS_ERR_BAD_ARG;
+  g_mlp_kernel_mode = mode & 15;
+  g_mlp_dbg = mode >> 4;     // bits 8..10: timing ablation
   return NWS_OK;
 }
 
@@ -858,6 +1317,41 @@ int nws_frame_mlps(const NwsWeights* w, const float* gru_out, const float* fir_d
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_mlps16_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpLds16));
     if (e != hipSuccess) return (int)e;
+  }
+  // enough frames to give most CUs a 256-frame workgroup: wave-resident frames (NWS_MLP_KERNEL=tiles keeps the kernels below)
+  static const int env_mode = [] {
+    const char* e = getenv("NWS_MLP_KERNEL");
+    return e == nullptr ? 0 : strcmp(e, "tiles") == 0 ? 1 : strcmp(e, "frames") == 0 ? 2 : 0;
+  }();
+  const int mode = g_mlp_kernel_mode ? g_mlp_kernel_mode : env_mode;
+  const long long F = (long long)B * T;
+  // (from the point where the 64-frame tile kernel needs a second round of workgroups: 256 tiles)
+  const bool many = (long long)B * ((T + kFT2 - 1) / kFT2) > 256;
+  if (w->mlp_frags != nullptr && mode != 1 && (many || mode == 2) && F * NWS_FILM_CH < (1ll << 31)) {
+    static unsigned long long attr_wr = 0;
+    if (nws_first_use_on_device(attr_wr)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_mlps_wr_kernel<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WrLds));
+      if (e != hipSuccess) return (int)e;
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_mlps_wr_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)sizeof(WrLds));
+      if (e != hipSuccess) return (int)e;
+    }
+    const dim3 gridw((unsigned)((F + kWrFrames - 1) / kWrFrames), 2);
+    const int abl = g_mlp_dbg >> 4;
+    if (abl == 6 && g_mlp_probe) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(frame_mlps_wr_kernel<false, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WrLds));
+      frame_mlps_wr_kernel<false, 6><<<gridw, 512, sizeof(WrLds), (hipStream_t)stream>>>(*w, gru_out, (int)F, T, static_cast<float*>(g_mlp_probe), film_out, nullptr, fir_out);
+    } else if (abl == 1 || abl == 2 || abl == 3 || abl == 5) {
+      auto fn = abl == 1 ? frame_mlps_wr_kernel<false, 1> : abl == 2 ? frame_mlps_wr_kernel<false, 2> : abl == 3 ? frame_mlps_wr_kernel<false, 3> : frame_mlps_wr_kernel<false, 5>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WrLds));
+      fn<<<gridw, 512, sizeof(WrLds), (hipStream_t)stream>>>(*w, gru_out, (int)F, T, nullptr, film_out, nullptr, fir_out);
+    } else if (!emb_out && !H_out)
+      frame_mlps_wr_kernel<false><<<gridw, 512, sizeof(WrLds), (hipStream_t)stream>>>(*w, gru_out, (int)F, T, nullptr, film_out, nullptr, fir_out);
+    else
+      frame_mlps_wr_kernel<true><<<gridw, 512, sizeof(WrLds), (hipStream_t)stream>>>(*w, gru_out, (int)F, T, emb_out, film_out, H_out, fir_out);
+    NWS_CHECK_LAUNCH();
+    return NWS_OK;
   }
   // more than one 32-frame tile per utterance: 64-frame tiles.  NWS_MLP_TILE=32 keeps the 32-frame kernel for A/B timing
   // (same box, back to back at B=64, T=500: 66.4 us per call with 32-frame tiles, 62.5 with 64-frame tiles)

@@ -291,6 +291,36 @@ def test_build_guard_finds_swizzled_packed_forms():
     assert len(first) == 4 and all("pk_probe" in k for k, _ in found), found      # the 4 hazardous fp32 forms of probe 1
 
 
+def test_build_guard_finds_valu_writes_in_front_of_matrix_reads():
+    """Second ISA guard of build.py (round 4): a v_mfma must not read a VGPR that a vector instruction wrote less than two wait
+    states earlier.  hipcc keeps that distance for what it schedules but not for inline asm - the wave-resident frame-MLP kernel
+    returned wrong first products of every layer until its fp16 split stopped being inline asm.  Clean on every product object;
+    sees the pattern in a listing that has it (the sequence the first build of that kernel contained)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("nws_build", os.path.join(ROOT, "neural-waveshaping-synthesis_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    b.build(verbose=False)
+    for src in b.SOURCES:
+        assert b.check_valu_mfma_hazard(os.path.join(b.OBJ, src.replace(".hip", ".o"))) == [], src
+    listing = """
+0000000000001000 <bad_kernel>:
+\tv_fma_mixlo_f16 v127, v123, -1.0, v16 op_sel_hi:[1,0,0]    // 000000001000: D3A1007F
+\tv_fma_mixhi_f16 v127, v123, -1.0, v17 op_sel:[1,0,0] op_sel_hi:[1,0,0]// 000000001008: D3A2087F
+\ts_cmpk_gt_u32 s20, 0xff                                    // 000000001010: B51400FF
+\tv_mfma_f32_32x32x16_f16 v[0:15], v[18:21], v[124:127], v[0:15]// 000000001018: D3D50000
+0000000000002000 <good_kernel>:
+\tv_fma_mixhi_f16 v127, v123, -1.0, v17 op_sel:[1,0,0] op_sel_hi:[1,0,0]// 000000002008: D3A2087F
+\ts_nop 1                                                    // 000000002010: BF800001
+\tv_mfma_f32_32x32x16_f16 v[0:15], v[18:21], v[124:127], v[0:15]// 000000002018: D3D50000
+\tv_add_f32_e32 v40, v41, v42                                // 000000002020: 02505529
+\tv_mfma_f32_32x32x16_f16 v[0:15], v[18:21], v[124:127], v[0:15]// 000000002028: D3D50000
+"""
+    b.device_disassembly = lambda obj: listing
+    found = b.check_valu_mfma_hazard("unused")
+    assert [k for k, _, _ in found] == ["bad_kernel"] and "v_fma_mixhi_f16 v127" in found[0][1], found
+
+
 def test_precision_rule_is_a_worst_case_bound_from_the_weights():
     """Engine.exciter_opts' automatic choice (precision.hybrid_w_error_bound): host logic, no GPU.  The shipped checkpoint's bound
     is far above 1e-5 (-> every mixer product two-term); it scales linearly with ||ir||_1 and with the high-harmonic weights

@@ -172,6 +172,45 @@ def test_gru_and_frame_mlps(models, oracle, weights):
     assert maxabs(emb.cpu().numpy(), g["embedding"]) <= 1e-5
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_frame_mlp_kernels_against_the_stage_taps(models, oracle, mode):
+    """Both frame-MLP kernel families forced on the same inputs (nws_debug_frame_mlps_kernel: 1 = one M-tile per wave with the
+    activations in LDS, 2 = wave-resident frames, round 4): the reference's stage taps at T = 8 and T = 500 (two and 500 frames
+    of a 256-frame workgroup: partial waves, empty waves), and a batch whose 65 x 501 frames end inside a wave."""
+    from nws_amd import _lib
+    m, _ = models
+    L = _lib.lib()
+    assert L.nws_debug_frame_mlps_kernel(mode) == 0
+    try:
+        for name in ("g3_stages.npz", "g1_realistic.npz"):
+            g = load_npz(name)
+            d = g if "phase_u" in g else load_npz("g1_realistic.npz")
+            st = {}
+            oracle[0](g["f0"], g["control"], d["phase_u"], d["noise"], stages=st)
+            emb, film, H, fir = m._engine.frame_mlps(st["gru_out"].contiguous().cuda(), want_emb=True, want_H=True)
+            film2, fir2 = m._engine.frame_mlps(st["gru_out"].contiguous().cuda())[1::2]      # the forward's instantiation (no taps)
+            assert torch.equal(film, film2) and torch.equal(fir, fir2)
+            Ht = st["H"].transpose(1, 2)
+            h = torch.fft.irfft(torch.complex(Ht, torch.zeros_like(Ht))).roll(128, -1) * torch.hann_window(256).view(1, 1, -1)
+            errs = dict(emb=maxabs(emb.cpu().numpy(), st["embedding"].numpy()),
+                        film=maxabs(film.cpu().numpy(), st["film"].numpy().transpose(0, 2, 1)),
+                        H=maxabs(H.cpu().numpy(), st["H"].numpy().transpose(0, 2, 1)),
+                        fir=maxabs(fir.cpu().numpy(), h[..., 128:].numpy()))
+            record(f"frame_mlps_mode{mode}_{name[:2]}", **errs)
+            assert errs["emb"] <= 1e-5 and errs["film"] <= 5e-5 and errs["H"] <= 5e-5, errs
+            assert errs["fir"] <= 2e-6 * max(1.0, float(np.abs(st["H"].numpy()).max())), errs
+        gen = torch.Generator().manual_seed(7)
+        gru = torch.tanh(torch.randn(65, 501, 128, generator=gen))
+        _, film, _, fir = m._engine.frame_mlps(gru.cuda())
+        L.nws_debug_frame_mlps_kernel(1)
+        _, film_t, _, fir_t = m._engine.frame_mlps(gru.cuda())
+        e_film, e_fir = maxabs(film.cpu().numpy(), film_t.cpu().numpy()), maxabs(fir.cpu().numpy(), fir_t.cpu().numpy())
+        record(f"frame_mlps_mode{mode}_vs_tiles", film=e_film, fir=e_fir, film_max=float(film_t.abs().max()), fir_max=float(fir_t.abs().max()))
+        assert e_film <= 2e-5 and e_fir <= 2e-6 * max(1.0, float(fir_t.abs().max()) * 50), (e_film, e_fir)
+    finally:
+        L.nws_debug_frame_mlps_kernel(0)
+
+
 def test_forward_pipeline_matches_plain_forward(models, oracle):
     """ForwardPipeline (control half on side streams, batched GRU, ring of workspaces) must return what model() returns for
     the same inputs and draws, batch after batch, including a shape change in mid-stream; one batch is also held against
