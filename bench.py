@@ -476,16 +476,24 @@ def main():
         if peer is not None:
             peer.push_rows(y, i % nbuf, row0, n)
             return None
-        return dist.all_gather([full[i % nbuf][r * B + row0:r * B + row0 + n] for r in range(world)], y[row0:row0 + n], async_op=True)
+        return par.gather_row_block(full[i % nbuf], y, row0, n)
 
     def gather(i, y):
         """all-gather of this step's waveforms on the CURRENT stream; returns a work handle (or None)"""
         if blocks is not None:      # (compute skipped: the same sub-batch messages, back to back)
             works = [gather_rows(i, y, r0, n) for r0, n in blocks]
-            return peer.finish(i % nbuf)[1] if peer is not None else _Works(works)
+            return peer_finish(i) if peer is not None else _Works(works)
         if peer is not None:
-            return peer.gather(y, i % nbuf)[1]
-        return dist.all_gather_into_tensor(full[i % nbuf], y, async_op=True)
+            work = peer.gather(y, i % nbuf)[1]
+            peer.release(i % nbuf)
+            return work
+        return par.gather_full(full[i % nbuf], y)
+
+    def peer_finish(i):
+        """completion signal of a sub-batch exchange; the loop never reads the gathered rows, so the slot is released at once"""
+        work = peer.finish(i % nbuf)[1]
+        peer.release(i % nbuf)
+        return work
 
     def step(i, pending, do_gather=True, do_compute=True):
         if use_pipe:
@@ -510,7 +518,7 @@ def main():
 
                     pipe.submit(f0, control, phase_u=pu, noise=nz, row_blocks=blocks, on_block=on_block)
                     with torch.cuda.stream(au):
-                        return peer.finish(i % nbuf)[1] if peer is not None else _Works(works)
+                        return peer_finish(i) if peer is not None else _Works(works)
                 y = pipe.submit(f0, control, phase_u=pu, noise=nz)
             with torch.cuda.stream(au):                 # ordered after this batch's reverb
                 if pending is not None:
@@ -628,7 +636,7 @@ def main():
                     y = pipe.submit(f0, control, phase_u=pu_c, noise=nz_c, row_blocks=blocks, on_block=on_block_c)
                     ys.append(y)
                     with torch.cuda.stream(au):
-                        pend = peer.finish(i % nbuf)[1] if peer is not None else _Works(works)
+                        pend = peer_finish(i) if peer is not None else _Works(works)
                     continue
                 y = pipe.submit(f0, control, phase_u=pu_c, noise=nz_c)
                 ys.append(y)

@@ -415,6 +415,12 @@ class Engine:
         self.weights()
         return self._fir_design
 
+    def osc_sample_rate(self) -> float:
+        """The rate the oscillator divides by: HarmonicOscillator's own gin binding (generators.py:41,59), which a configuration
+        may set apart from NeuralWaveshaping.sample_rate - the reference's forward only ever uses the oscillator's."""
+        m = self._model_ref
+        return float(getattr(getattr(m, "osc", None), "sample_rate", m.sample_rate))
+
     def reverb_aux(self, n_samples: int):
         """(plan, tables, spectrum, plan tensor) for a forward of n_samples; the IR spectrum is rebuilt with the weights"""
         self._wd()
@@ -453,7 +459,7 @@ class Engine:
         w, _, dev, wdesc = self._wd()
         src = f0 if f0 is not None else f0_up
         same_device(dev, f0=src, carry=carry, phase_u=phase_u, film=film)
-        sr = float(self._model_ref.sample_rate)
+        sr = self.osc_sample_rate()
         o = ops()
         if o is not None:
             exc, out = o.exciter_newt(wdesc, f0, f0_up, carry, phase_u, self._w[1][-2], film, sr, want_exciter, want_newt)
@@ -622,9 +628,20 @@ class Engine:
         same_device(dev, f0=f0, phase_u=phase_u, noise=noise, workspace=ws, out=out)
         N = T * _lib.HOP
         plan, tables, spec, plan_t = self._reverb_aux(N)
-        sr = float(self._model_ref.sample_rate)
+        sr = self.osc_sample_rate()
         o = ops()
         if row_blocks is not None and len(row_blocks) > 1:
+            # the blocks must tile [0, B) with even sizes (two utterances share one transform; ForwardPipeline.row_blocks' rule):
+            # anything else would leave rows of `out` unwritten or pair the wrong utterances
+            nxt = 0
+            for row0, nrows in row_blocks:
+                if int(row0) != nxt or int(nrows) <= 0 or int(nrows) % 2:
+                    raise RuntimeError(f"row_blocks must tile [0, {B}) in order with even sizes, got {list(row_blocks)}")
+                nxt += int(nrows)
+            if nxt != B:
+                raise RuntimeError(f"row_blocks cover {nxt} of {B} rows: {list(row_blocks)}")
+            if wait_event is not None or record_event is not None:
+                raise RuntimeError("wait_event / record_event hook the single-call form; they cannot be combined with row_blocks")
             with torch.cuda.device(dev):
                 if out is None:
                     out = torch.empty((B, N), dtype=torch.float32, device=dev)
@@ -686,7 +703,7 @@ class Engine:
                 # is handed back to the caching allocator, which re-issues a block only in the stream order it was used in)
                 self._workspaces.pop(next(iter(self._workspaces)))
             self._workspaces[key] = ws
-        sr = float(self._model_ref.sample_rate)
+        sr = self.osc_sample_rate()
         o = ops()
         if o is not None:
             return o.forward(wdesc, f0, control, phase_u, self._w[1][-2], noise, self._fir_design, plan_t, tables, spec, ws, sr)

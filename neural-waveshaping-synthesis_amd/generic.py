@@ -218,7 +218,7 @@ class GenericEngine:
             if len(self._workspaces) >= 8:
                 self._workspaces.pop(next(iter(self._workspaces)))
             self._workspaces[key] = ws
-        sr = float(self._model_ref.sample_rate)
+        sr = float(getattr(getattr(self._model_ref, 'osc', None), 'sample_rate', self._model_ref.sample_rate))   # the oscillator's own binding (generators.py:41)
         o = ops()
         if o is not None:
             return o.forward_generic(gdesc, f0, control, phase_u, rp, noise, plan_t, tables, spec, ws[1], ws[0], sr)

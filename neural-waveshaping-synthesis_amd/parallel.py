@@ -80,6 +80,26 @@ def render_sharded(render_fn, f0, control, group=None, phase_u=None, noise=None,
     return (full, None) if async_op else full
 
 
+def gather_full(full: torch.Tensor, y: torch.Tensor, group=None, async_op: bool = True):
+    """Weak-scaling exchange of one step (bench.py --gpus N): every rank contributes its own (b, N) batch `y`; `full`
+    (world * b, N) receives rank r's rows at [r * b, (r + 1) * b).  One all_gather_into_tensor on the current stream."""
+    world = dist.get_world_size(group)
+    if full.shape != (world * y.shape[0], y.shape[1]):
+        raise ValueError(f"gather buffer {tuple(full.shape)} does not hold {world} shards of {tuple(y.shape)}")
+    return dist.all_gather_into_tensor(full, y, group=group, async_op=async_op)
+
+
+def gather_row_block(full: torch.Tensor, y: torch.Tensor, row0: int, n: int, group=None, async_op: bool = True):
+    """Sub-batch exchange (`--gather-chunks`): rows [row0, row0 + n) of every rank's batch, as soon as their reverb
+    is enqueued; rank r's block lands at rows [r * b + row0, r * b + row0 + n) of `full` - the same layout gather_full fills."""
+    world = dist.get_world_size(group)
+    b = y.shape[0]
+    if full.shape != (world * b, y.shape[1]) or row0 < 0 or n <= 0 or row0 + n > b:
+        raise ValueError(f"rows [{row0}, {row0 + n}) of {tuple(y.shape)} into {tuple(full.shape)}")
+    views = [full[r * b + row0:r * b + row0 + n] for r in range(world)]
+    return dist.all_gather(views, y[row0:row0 + n], group=group, async_op=async_op)
+
+
 class PeerCopyAllGather:
     """All-gather of the rendered waveforms WITHOUT collective kernels: every rank pushes its (b, N) shard straight into
     every peer's gather buffer with device-to-device copies (hipMemcpyAsync on peer-mapped memory = the SDMA copy
@@ -92,8 +112,11 @@ class PeerCopyAllGather:
     (4-byte all-reduce; on the "gloo" test backend a host barrier after a stream sync) whose completion on rank q implies
     that every rank's copies into q's buffer were complete when that rank joined it.  Returns (full_buffer, work).
 
-    The caller must not reuse slot s for a new gather before every rank has finished reading its full[s] (bench.py cycles
-    through `nbuf` slots and never reads them inside the loop; a consumer would put its own synchronisation there).
+    Slot reuse is guarded here, not left to the caller: `gather` / `finish` hand slot s out, the consumer calls `release(s)`
+    when the work it enqueued on full[s] is done with it (an event on its current stream), and
+      * a new gather into a slot that was handed out and not released raises (host-side bookkeeping);
+      * every rank makes its completion signal wait for its own release events, and every gather first waits for the previous
+        gather's completion signal - so a push into rank q's slot s is ordered after q's last read of it (nbuf >= 2).
     """
 
     def __init__(self, rows: int, n_samples: int, device, nbuf: int = 2, group=None, dtype=torch.float32):
@@ -122,11 +145,48 @@ class PeerCopyAllGather:
                 opened.append(t)
             self.remote.append(opened)
         self._flag = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._held = [False] * nbuf          # handed to the consumer, not yet released
+        self._released = [None] * nbuf       # event of the consumer's last use of the slot
+        self._last_work = None               # completion signal of the previous gather
         dist.barrier(group=group)   # nobody starts pushing before everybody has opened everything
+
+    def _claim(self, slot: int):
+        if self._held[slot]:
+            raise RuntimeError(f"PeerCopyAllGather: slot {slot} is still held by its consumer - call release({slot}) when the work "
+                               f"reading full[{slot}] has been enqueued (peers would overwrite rows that are being read)")
+        if self._last_work is not None:      # the previous exchange is complete on every rank before new rows travel
+            self._last_work.wait()
+            self._last_work = None
+
+    def release(self, slot: int):
+        """The consumer is done with full[slot]: everything it enqueued on the current stream so far may still read it, anything
+        later must not."""
+        if self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._released[slot] = ev
+        self._held[slot] = False
+
+    def _signal(self, slot: int):
+        st = torch.cuda.current_stream(self.device)
+        for s, ev in enumerate(self._released):      # this rank's reads of released slots precede its completion signal
+            if ev is not None:
+                st.wait_event(ev)
+                self._released[s] = None
+        self._held[slot] = True
+        if self.backend == "gloo":              # CPU-side test backend: no stream-ordered collectives
+            st.synchronize()
+            dist.barrier(group=self.group)
+            return self.full[slot], None
+        work = dist.all_reduce(self._flag, group=self.group, async_op=True)   # ordered after the copies on this stream
+        self._last_work = work
+        return self.full[slot], work
 
     def push_rows(self, y: torch.Tensor, slot: int, row0: int, nrows: int):
         """Sub-batch form: push rows [row0, row0 + nrows) of this rank's shard into every peer's buffer on the
         current stream; call `finish(slot)` after the last block."""
+        if row0 == 0:
+            self._claim(slot)
         lo = self.rank * self.rows + row0
         for k in range(self.world):
             p = (self.rank + k) % self.world
@@ -134,23 +194,14 @@ class PeerCopyAllGather:
 
     def finish(self, slot: int):
         """the completion signal of gather(), on its own (after push_rows of every block)"""
-        if self.backend == "gloo":
-            torch.cuda.current_stream(self.device).synchronize()
-            dist.barrier(group=self.group)
-            return self.full[slot], None
-        work = dist.all_reduce(self._flag, group=self.group, async_op=True)
-        return self.full[slot], work
+        return self._signal(slot)
 
     def gather(self, y: torch.Tensor, slot: int):
         if y.shape != (self.rows, self.n) or not y.is_contiguous():
             raise ValueError(f"expected a contiguous {(self.rows, self.n)} shard, got {tuple(y.shape)}")
+        self._claim(slot)
         lo = self.rank * self.rows
         for k in range(self.world):             # start with the right-hand neighbour: the ranks' pushes spread over the links
             p = (self.rank + k) % self.world
             self.remote[p][slot][lo:lo + self.rows].copy_(y, non_blocking=True)
-        if self.backend == "gloo":              # CPU-side test backend: no stream-ordered collectives
-            torch.cuda.current_stream(self.device).synchronize()
-            dist.barrier(group=self.group)
-            return self.full[slot], None
-        work = dist.all_reduce(self._flag, group=self.group, async_op=True)   # ordered after the copies on this stream
-        return self.full[slot], work
+        return self._signal(slot)

@@ -28,8 +28,9 @@ from . import _lib
 from .engine import _req, ops, stream_ptr
 
 HOP = _lib.HOP
-_MAX_CHUNK_FRAMES = 249   # (K+1) * 128 + 31999 <= 64000: the FFT reverb of a long chunk fits the L = 64000 plan
-_GRAPH_AFTER = 2          # steady-state pushes of one K before that hop is captured
+_MAX_CHUNK_FRAMES = 249   # 16 kHz: (K+1) * 128 + 31999 <= 64000, the FFT reverb of a long chunk inside the L = 64000 plan
+_RING = 65536             # kRing of csrc/stream.hip: reverb-input ring per utterance; the impulse response must fit half of it
+_GRAPH_AFTER = 2          # consecutive steady-state pushes of one (K, channels) before that hop is captured
 
 
 class NewtStream:
@@ -43,7 +44,17 @@ class NewtStream:
         w, _, dev = self.eng.weights()
         self.dev = dev
         self.B = int(batch_size)
-        self.max_frames = int(min(max(1, max_chunk_frames), _MAX_CHUNK_FRAMES))
+        self._ir_len = int(self.eng.ir().numel())
+        self.tail_len = self._ir_len + 1
+        if self._ir_len >= _RING // 2:
+            raise RuntimeError(f"stateful streaming keeps {_RING // 2 - 1} samples of reverb history per utterance; this model's impulse "
+                               f"response has {self._ir_len} taps ({self._ir_len / float(model.sample_rate):.2f} s at "
+                               f"{model.sample_rate} Hz) - render it with the one-shot forward")
+        # the FFT reverb of a long chunk is one direct transform of [ir_len samples of history | chunk]: the smallest standard
+        # length that holds twice the tail (64000 at 16 kHz, 32000 at 8 kHz) bounds the chunk
+        self._plan_n = next(n for n in (32000, 64000, 128000, 256000) if n >= 2 * self.tail_len)
+        fit = (self._plan_n - self._ir_len) // HOP - 1
+        self.max_frames = int(min(max(1, max_chunk_frames), fit))
         self.phase_u = _req((phase_u if phase_u is not None else torch.rand_like(model.osc.rand_phase)).reshape(-1),
                             "phase_u", _lib.N_HARMONICS)
         self._noise_all = _req(noise, "noise") if noise is not None else None    # parity mode: the reference's whole draw
@@ -51,18 +62,16 @@ class NewtStream:
         self.samples_emitted = 0
         self.finished = False
         self._nz_prev_start = 0
-        self._ir_len = int(self.eng.ir().numel())
-        self.tail_len = self._ir_len + 1
         self._need_fft = HOP * (self.max_frames + 1) > 2048
         L = _lib.lib()
-        plan = self.eng.reverb_aux(2 * self.tail_len)[0] if self._need_fft else None
+        plan = self.eng.reverb_aux(self._plan_n)[0] if self._need_fft else None
         nbytes = L.nws_stream_state_bytes(self.B, self.max_frames, self._ir_len, C.byref(plan) if plan is not None else None)
         with torch.cuda.device(dev):
             self._state = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             _lib.check(L.nws_stream_reset(self._state.data_ptr(), nbytes, stream_ptr(dev)), "nws_stream_reset")
         self._use_graph = bool(graph)
-        self._graphs = {}          # K -> (graph, f0_in, control_in, noise_new, out, pre)
-        self._steady_runs = {}     # K -> consecutive steady-state pushes seen
+        self._graphs = {}          # (K, channels) -> (graph, f0_in, control_in, noise_new, out, pre)
+        self._steady_runs = {}     # (K, channels) -> CONSECUTIVE steady-state pushes seen
         self._last_K = None
         self._last_pre = None
 
@@ -72,8 +81,8 @@ class NewtStream:
         w, keep, dev, wdesc = eng._wd()
         B, K = f0_2d.shape
         fft = self._need_fft
-        plan, tables, spec, plan_t = eng._reverb_aux(2 * self.tail_len) if fft else (None, None, None, None)
-        sr = float(self.model.sample_rate)
+        plan, tables, spec, plan_t = eng._reverb_aux(self._plan_n) if fft else (None, None, None, None)
+        sr = eng.osc_sample_rate()
         rp, ir = keep[-2], keep[-1]
         o = ops()
         if o is not None:
@@ -137,14 +146,20 @@ class NewtStream:
         steady = (not first) and (not final) and self._last_K == K and self.frames_seen >= K + 2
         f0_2d = f0[:, 0, :]
         self._check_weights()
+        key = (K, control.shape[1])
+        if not steady:
+            self._steady_runs.clear()      # the count is of CONSECUTIVE steady hops of one shape
         if steady and self._use_graph:
-            hit = self._graphs.get((K, control.shape[1]))
-            runs = self._steady_runs.get(K, 0) + 1
-            self._steady_runs[K] = runs
+            hit = self._graphs.get(key)
+            runs = self._steady_runs.get(key, 0) + 1
+            self._steady_runs = {key: runs}
             if hit is None and runs > _GRAPH_AFTER and not torch.cuda.is_current_stream_capturing():
                 try:
-                    hit = self._graphs[(K, control.shape[1])] = self._capture(K, control.shape[1])
-                except Exception:          # capture not possible here (e.g. foreign capture in progress): stay eager
+                    hit = self._graphs[key] = self._capture(K, control.shape[1])
+                except Exception as e:     # capture not possible here (e.g. foreign capture in progress): stay eager, and say so
+                    import warnings
+                    warnings.warn(f"NewtStream: hipGraph capture of the {K}-frame hop failed ({type(e).__name__}: {e}); this stream "
+                                  f"continues with eager pushes", RuntimeWarning, stacklevel=2)
                     self._use_graph = False
                     hit = None
             if hit is not None:
@@ -165,12 +180,21 @@ class NewtStream:
         self._last_pre = pre
         return out
 
+    def refresh(self):
+        """Pick up a weight update NOW: re-derive the engine's tables if any parameter changed and drop the captured hops that
+        point into the old ones.  Call it after an optimizer step / load_state_dict / in-place edit when the very next hop must
+        see the new weights; without it a captured hop (`graph=True`) keeps replaying the old tables for up to 250 ms (eager
+        pushes notice at once), see _check_weights."""
+        self.__dict__["_last_walk"] = 0.0
+        self._check_weights()
+
     def _check_weights(self):
         """A captured hop holds raw pointers into the engine's derived tables (fragment tables, LUT pairs, FIR design, IR
         spectrum).  If the engine has rebuilt them (somebody ran a forward after a weight update, `.to()`, `invalidate_cache`)
         the graphs are dropped and re-captured; in-place updates nobody has told the engine about are looked for at most every
         250 ms of wall-clock (a full fingerprint walk costs ~12 us of host time: too much for every 256-sample hop, nothing once
-        per sixteen 16 ms hops)."""
+        per sixteen 16 ms hops).  So for up to 250 ms after such an update graph=True and graph=False streams differ; `refresh()`
+        closes that window on demand."""
         eng = self.eng
         now = time.monotonic()
         if now - self.__dict__.get("_last_walk", 0.0) >= 0.25:
@@ -201,7 +225,7 @@ class NewtStream:
         buffer (overwritten by the next hop)."""
         self._check_weights()
         hit = self._graphs.get((K, channels))
-        if hit is None or self._last_K != K or self.finished:
+        if hit is None or self._last_K != K or self.finished or self.frames_seen < K + 2:
             raise RuntimeError("hop(): call static_io(K) first (again after a weight update), and do not interleave other chunk sizes")
         hit[0].replay()
         self._advance(K, HOP * K, False, False)
@@ -219,7 +243,7 @@ class NewtStream:
         """The remaining (B, 32000) reverb tail after the last chunk (what a linear reverb still rings out)."""
         eng = self.eng
         eng._wd()
-        plan, tables, spec, _ = eng._reverb_aux(2 * self.tail_len)
+        plan, tables, spec, _ = eng._reverb_aux(self._plan_n)
         L = _lib.lib()
         with torch.cuda.device(self.dev):
             tail = torch.empty((self.B, self.tail_len), dtype=torch.float32, device=self.dev)

@@ -19,6 +19,7 @@ Fixtures written:
   g7_fl.npz / g7_tpt.npz             B=1,T=125 (1 s) realistic vector per instrument: y_newt, y_fast, draws
   g8_small / g8_odd / g8_oddlen .npz three NON-default gin configurations (random init, recorded weights + gin text): inputs, draws,
                                      stage taps, y_newt, y_fast   (`... make_golden.py generic` regenerates only these)
+  g9_upsampling.npz   data/utils/upsampling.py: linear / cubic-spline / overlap-add interpolators (`... make_golden.py upsampling`)
 (`python tests/golden/make_golden.py instruments` regenerates only the fl / tpt four.)
 The RNG draws made inside forward are recorded by wrapping torch.rand / torch.rand_like.
 """
@@ -373,7 +374,29 @@ def generic_configs():
     gin.clear_config()
 
 
+def upsampling_vectors():
+    """g9_upsampling.npz: the three frame-rate -> sample-rate interpolators of data/utils/upsampling.py (the gin-selectable
+    `interpolate_fn` of the loudness / F0 features) on seeded inputs, with and without `original_length`."""
+    from neural_waveshaping_synthesis.data.utils import upsampling as ref_up
+    rng = np.random.default_rng(9)
+    out = {}
+    for i, (frames, win, hop, orig) in enumerate([(12, 256, 64, 0), (30, 512, 128, 3500), (7, 256, 64, 300), (33, 400, 100, 3111)]):
+        sig = rng.standard_normal(frames).cumsum()
+        out[f"c{i}_args"] = np.array([frames, win, hop, orig], dtype=np.int64)
+        out[f"c{i}_signal"] = sig
+        kw = dict(original_length=orig) if orig else {}
+        out[f"c{i}_linear"] = ref_up.linear_interpolation(sig, win, hop, **kw)
+        out[f"c{i}_cubic"] = ref_up.cubic_spline_interpolation(sig, win, hop, **kw)
+        out[f"c{i}_ola"] = ref_up.overlap_add_upsample(sig, win, hop, **kw)
+        out[f"c{i}_ola_tri3"] = ref_up.overlap_add_upsample(sig, win, hop, window_fn="triang", window_scale=3, **kw)
+    np.savez(os.path.join(HERE, "g9_upsampling.npz"), **out)
+    print("g9_upsampling.npz", {k: v.shape for k, v in out.items() if k.startswith("c1_")})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "upsampling":
+        upsampling_vectors()
+        sys.exit(0)
     if sys.argv[1:] == ["instruments"]:
         instruments()
     elif sys.argv[1:] == ["generic"]:

@@ -71,3 +71,77 @@ def test_two_rank_sharded_render_equals_unsharded(tmp_path, B):
         assert np.array_equal(r[0], r[2])               # gathered shards == un-sharded render, bit for bit
         assert np.array_equal(r[1], r[2])
     assert np.array_equal(r0, r1)
+
+
+def _worker8(rank, world, port, b, T, tmp):
+    """One rank of the weak-scaling job `bench.py --gpus 8` runs (BASELINE config 4: 64 utterances per rank, 512 in all): its
+    own batch, the shared draws from identically seeded generators, the whole-batch exchange and the sub-batch exchange - through
+    the functions bench.py itself calls (parallel.gather_full / gather_row_block, ForwardPipeline.row_blocks)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(1)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.newt_oracle import OracleNEWT
+        pipeline = importlib.import_module("neural-waveshaping-synthesis_amd.pipeline")
+        w = {k: v for k, v in load_npz("weights_vn.npz").items() if not k.startswith("__")}
+        oracle = OracleNEWT(w, fast=True, lut_python_loop=False)
+        N = 128 * T
+        g = torch.Generator().manual_seed(1000 + rank)            # this rank's own 64 utterances
+        f0 = 150 + 500 * torch.rand(b, 1, T, generator=g)
+        control = torch.randn(b, 2, T, generator=g)
+        gen = par.make_shared_generator(torch.device("cpu"), seed=4242)
+        outs = []
+        for step in range(2):                                       # two steps: the shared stream advances identically
+            pu, nz = par.shared_draws(101, N - 1, torch.device("cpu"), generator=gen)
+            y = oracle(f0 + step, control, pu, nz).contiguous()
+            full = torch.full((world * b, N), float("nan"))
+            par.gather_full(full, y).wait()
+            full_blocks = torch.full((world * b, N), float("nan"))
+            blocks = pipeline.ForwardPipeline.row_blocks(b, 4)
+            assert blocks == [(0, 16), (16, 16), (32, 16), (48, 16)]
+            works = [par.gather_row_block(full_blocks, y, r0, n) for r0, n in blocks]
+            for wk in works:
+                wk.wait()
+            assert torch.equal(full, full_blocks) and not torch.isnan(full).any()
+            assert torch.equal(full[rank * b:(rank + 1) * b], y)
+            outs.append(torch.cat([pu, nz, full.reshape(-1)]).numpy())
+        np.save(os.path.join(tmp, f"w{rank}.npy"), np.stack(outs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world8_weak_scaling_rehearsal(tmp_path):
+    """World size 8, 64 utterances per rank = the 512-utterance batch of BASELINE config 4 (T = 2: the reference's streaming
+    size), on gloo: every rank ends up with the same (512, N) buffer, and that buffer equals ONE un-sharded oracle forward of
+    the 512 utterances with the same draws - shard bounds, shared draws, all_gather_into_tensor layout and the sub-batch order
+    are what `bench.py --gpus 8` executes.  (RCCL over xGMI itself is for the driver's 8-GPU node: unmeasured here.)"""
+    world, b, T = 8, 64, 2
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker8, args=(world, port, b, T, str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(tmp_path / f"w{r}.npy") for r in range(world)]
+    for r in range(1, world):
+        assert np.array_equal(got[0], got[r]), r                 # draws and gathered batches identical on every rank
+    from oracle.newt_oracle import OracleNEWT
+    w = {k: v for k, v in load_npz("weights_vn.npz").items() if not k.startswith("__")}
+    oracle = OracleNEWT(w, fast=True, lut_python_loop=False)
+    N = 128 * T
+    f0s, cs = [], []
+    for r in range(world):
+        g = torch.Generator().manual_seed(1000 + r)
+        f0s.append(150 + 500 * torch.rand(b, 1, T, generator=g))
+        cs.append(torch.randn(b, 2, T, generator=g))
+    f0, control = torch.cat(f0s), torch.cat(cs)
+    assert [par.shard_bounds(world * b, world, r) for r in range(world)] == [(r * b, (r + 1) * b) for r in range(world)]
+    for step in range(2):
+        pu, nz = torch.from_numpy(got[0][step][:101]), torch.from_numpy(got[0][step][101:101 + N - 1])
+        ref = oracle(f0 + step, control, pu, nz).numpy()
+        full = got[0][step][101 + N - 1:].reshape(world * b, N)
+        # the sharded job == the un-sharded B = 512 forward: same rows in the same places (torch's CPU kernels block a 512-row
+        # batch differently from eight 64-row ones, so equality is to fp32 rounding, not bit for bit as in the two-rank test)
+        err = np.abs(full - ref).max(axis=1)
+        assert err.max() <= 2e-6 * max(1.0, np.abs(ref).max()), (step, err.max(), np.abs(ref).max())
+        wrong_place = np.abs(full - np.roll(ref, b, axis=0)).max(axis=1)
+        assert wrong_place.min() > 100 * err.max()                 # (a permuted layout would not pass the bound above)
+    assert not np.array_equal(got[0][0][:101], got[0][1][:101])

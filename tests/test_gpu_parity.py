@@ -1247,3 +1247,29 @@ def test_exciter_optional_table_fallbacks(models):
     assert torch.equal(a, run(w_r2))
     assert not torch.equal(a, ref)
     record("exciter_optional_tables", lut_two_gathers_vs_pairs_fma_max_abs=d, max_abs=scale)
+
+
+def test_forward_audio_validates_row_blocks(models):
+    """row blocks that do not tile the batch with even sizes (or come with the single-call event hooks) raise instead of
+    leaving rows of the output unwritten."""
+    _, m = models
+    eng = m._engine
+    B, T = 8, 4
+    f0 = torch.full((B, 1, T), 220.0).cuda()
+    c = torch.zeros(B, 2, T).cuda()
+    pu, nz = torch.rand(101).cuda(), torch.rand(128 * T - 1).cuda()
+    ws = eng.workspace(B, T) if hasattr(eng, "workspace") else None
+    if ws is None:
+        import ctypes as C
+        from nws_amd import _lib
+        plan = eng.reverb_aux(128 * T)[0]
+        ws = torch.empty(_lib.lib().nws_forward_workspace_bytes(C.byref(plan), B, T), dtype=torch.uint8, device="cuda")
+    eng.forward_control(f0, c, ws)
+    ref = eng.forward_audio(f0, B, T, pu, nz, ws)
+    ok = eng.forward_audio(f0, B, T, pu, nz, ws, row_blocks=[(0, 4), (4, 4)])
+    assert torch.equal(ok, ref)
+    for bad in ([(0, 4), (4, 2)], [(0, 3), (3, 5)], [(4, 4), (0, 4)], [(0, 4), (2, 6)]):
+        with pytest.raises(RuntimeError, match="row_blocks"):
+            eng.forward_audio(f0, B, T, pu, nz, ws, row_blocks=bad)
+    with pytest.raises(RuntimeError, match="row_blocks"):
+        eng.forward_audio(f0, B, T, pu, nz, ws, row_blocks=[(0, 4), (4, 4)], wait_event=torch.cuda.Event())

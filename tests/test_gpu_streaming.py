@@ -133,3 +133,69 @@ def test_stream_picks_up_weight_updates_and_recaptures(setup):
     # with a zero IR the output is the dry pre-reverb signal itself
     assert torch.equal(y, s._last_pre) and not torch.equal(outs[-1], outs[-2])
     assert not s._graphs or s._w_seen is m._engine._w
+
+
+def test_stream_geometry_follows_the_reverb_length():
+    """the stream's chunk limit and ring come from THIS model's reverb, not from the 16 kHz default.  An 8 kHz model
+    (2 s reverb = 15999 taps, FFT plan of 32000 points) takes chunks of at most (32000 - 15999) / 128 - 1 = 124 frames - one such
+    chunk equals the same frames pushed in pieces; a 22.05 kHz model (44099 taps) does not fit the 32767 samples of reverb history
+    a stream keeps and is refused at construction with the reason, instead of failing every push with NWS_ERR_BAD_ARG."""
+    import nws_amd as nws
+    nws.ensure_default_config()
+    try:
+        nws.gin.parse_config("NeuralWaveshaping.sample_rate = 8000\nHarmonicOscillator.sample_rate = 8000\nReverb.sr = 8000\n")
+        torch.manual_seed(11)
+        m = nws.NeuralWaveshaping().cuda().eval()
+        m.newt = nws.FastNEWT(m.newt)
+        assert m.reverb.ir.numel() == 15999 and m._engine.specialised()
+        g = torch.Generator().manual_seed(3)
+        F = 124
+        f0 = (150 + 300 * torch.rand(2, 1, 1, generator=g)) * torch.ones(2, 1, F)
+        control = torch.randn(2, 2, F, generator=g)
+        pu, nz = torch.rand(101, generator=g).cuda(), torch.rand(128 * F - 1, generator=g).cuda()
+        outs = []
+        for chunks in ([124], [60, 64], [3] * 40 + [4]):
+            s = m.stream(2, phase_u=pu, noise=nz)
+            assert s.max_frames == 124 and s._plan_n == 32000
+            k, ys = 0, []
+            for i, K in enumerate(chunks):
+                ys.append(s.push(f0[:, :, k:k + K].cuda(), control[:, :, k:k + K].cuda(), final=(i == len(chunks) - 1)))
+                k += K
+            outs.append(torch.cat(ys, dim=1).cpu().numpy())
+        assert outs[0].shape == (2, 128 * F) and np.isfinite(outs[0]).all() and rms(outs[0]) > 1e-5
+        for o in outs[1:]:
+            assert rms(o - outs[0]) <= 2e-6 * max(rms(outs[0]), 1e-3), rms(o - outs[0])
+        nws.gin.parse_config("NeuralWaveshaping.sample_rate = 22050\nHarmonicOscillator.sample_rate = 22050\nReverb.sr = 22050\n")
+        m22 = nws.NeuralWaveshaping().cuda().eval()
+        assert m22.reverb.ir.numel() == 44099
+        with pytest.raises(RuntimeError, match="reverb history"):
+            m22.stream(1)
+        y = m22(torch.full((1, 1, 8), 200.0).cuda(), torch.randn(1, 2, 8).cuda())      # the one-shot forward serves it
+        assert y.shape == (1, 1024) and torch.isfinite(y).all()
+    finally:
+        nws.gin.clear_config()
+        nws.gin.parse_config_file(nws.DEFAULT_GIN)
+
+
+def test_stream_refresh_picks_up_a_weight_update_at_once(setup):
+    """a captured hop replays the old tables for up to 250 ms after an in-place weight update; refresh() closes the
+    window - the very next hop of a graph=True stream equals an eager stream's."""
+    import copy
+    model = copy.deepcopy(setup[0])
+    g = torch.Generator().manual_seed(5)
+    K = 2
+    pu = torch.rand(101, generator=g).cuda()
+    nz = torch.rand(128 * 40, generator=g).cuda()
+    f0 = (200 + 100 * torch.rand(1, 1, 40, generator=g)).cuda()
+    c = torch.randn(1, 2, 40, generator=g).cuda()
+    a, b = model.stream(1, phase_u=pu, noise=nz, graph=True), model.stream(1, phase_u=pu, noise=nz, graph=False)
+    for i in range(6):
+        ya, yb = a.push(f0[:, :, 2 * i:2 * i + K], c[:, :, 2 * i:2 * i + K]), b.push(f0[:, :, 2 * i:2 * i + K], c[:, :, 2 * i:2 * i + K])
+    assert a._graphs and torch.equal(ya, yb)
+    with torch.no_grad():
+        model.newt.mixer[0].weight.mul_(0.5)           # in-place: nobody tells the engine
+    a.refresh()
+    b.refresh()
+    assert not a._graphs                                   # dropped, to be re-captured on the new tables
+    ya, yb = a.push(f0[:, :, 12:14], c[:, :, 12:14]), b.push(f0[:, :, 12:14], c[:, :, 12:14])
+    assert torch.equal(ya, yb)
