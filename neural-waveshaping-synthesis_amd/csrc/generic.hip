@@ -10,6 +10,8 @@
 // materialised in the caller's workspace (the oscillator bank (B, K, N) included), nothing is tuned.  No kernel here indexes
 // a private array with a runtime value (that would become scratch memory, which the build refuses): per-thread vectors of
 // runtime length live in LDS.
+#include <stdlib.h>
+
 #include "nws_common.h"
 
 namespace {
@@ -116,6 +118,86 @@ __global__ __launch_bounds__(256) void g_gru_kernel(const float* __restrict__ w_
     for (int j = threadIdx.x; j < H; j += blockDim.x) hT[(size_t)b * H + j] = hbuf[(size_t)cur * H + j];
 }
 
+// ---- the same recurrence with W_hh in registers (round 4; hidden sizes up to 128: 3 H^2 floats fit the registers of 4 H lanes) -----------------------------------------
+// g_gru_kernel re-reads the 3 H^2 weights from L2 every step (196 KB at H = 128: 2.8 ms per 500 steps).  Here four adjacent
+// lanes share a hidden unit: lane (j, q) keeps rows j, H + j, 2H + j of W_hh for k in [q KQ, (q + 1) KQ) in 3 KQ registers
+// (KQ = compile-time bucket 8 / 16 / 32 >= H / 4, zero padded), reads its quarter of h from LDS (broadcast across the
+// units), and the quarters meet in two DPP quad steps.  The input projection of gate g is computed by lane q = g (W_ih in LDS).
+// One barrier per step; h ping-pongs in LDS.
+template <int CTRL>
+__device__ __forceinline__ float g_quad_perm(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float g_quad_sum(float v) {
+  v += g_quad_perm<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+  v += g_quad_perm<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+  return v;
+}
+
+template <int KQ>
+__global__ __launch_bounds__(16 * KQ) void g_gru_q_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+                                                       const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                                       const float* __restrict__ control, int C_total, int C_in, int H, int T,
+                                                       const float* __restrict__ h0, float* __restrict__ out,
+                                                       float* __restrict__ hT) {
+  extern __shared__ float lds[];   // h[2][4 KQ] | x[2][C_in] | W_ih (3 H x C_in)
+  float* hbuf = lds;
+  float* xs = lds + 2 * 4 * KQ;
+  float* wih = xs + 2 * C_in;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int j = tid >> 2, q = tid & 3;
+  const bool unit = j < H;
+  float wr[KQ], wz[KQ], wn[KQ];
+#pragma unroll
+  for (int i = 0; i < KQ; ++i) {
+    const int k = q * KQ + i;
+    const bool in = unit && k < H;
+    wr[i] = in ? w_hh[(size_t)j * H + k] : 0.0f;
+    wz[i] = in ? w_hh[(size_t)(H + j) * H + k] : 0.0f;
+    wn[i] = in ? w_hh[(size_t)(2 * H + j) * H + k] : 0.0f;
+  }
+  for (int i = tid; i < 2 * 4 * KQ; i += blockDim.x) hbuf[i] = (i < H && h0) ? h0[(size_t)b * H + i] : 0.0f;
+  for (int i = tid; i < 3 * H * C_in; i += blockDim.x) wih[i] = w_ih[i];
+  if (tid < C_in) xs[tid] = control[((size_t)b * C_total + tid) * T];
+  // this lane's input-projection gate (q = 0, 1, 2: r, z, n) and the recurrent biases
+  const int grow = (q < 3 ? q : 0) * H + (unit ? j : 0);
+  const float bi = b_ih[grow];
+  const float bhr = unit ? b_hh[j] : 0.0f, bhz = unit ? b_hh[H + j] : 0.0f, bhn = unit ? b_hh[2 * H + j] : 0.0f;
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < T; ++t) {
+    const float* hp = hbuf + cur * 4 * KQ;
+    const float* xc = xs + (t & 1) * C_in;
+    if (tid < C_in && t + 1 < T) xs[((t + 1) & 1) * C_in + tid] = control[((size_t)b * C_total + tid) * T + t + 1];
+    float pr = 0.0f, pz = 0.0f, pn = 0.0f;
+#pragma unroll
+    for (int i4 = 0; i4 < KQ; i4 += 4) {
+      const float4 hv = *reinterpret_cast<const float4*>(hp + q * KQ + i4);
+      pr = fmaf(wr[i4], hv.x, pr); pz = fmaf(wz[i4], hv.x, pz); pn = fmaf(wn[i4], hv.x, pn);
+      pr = fmaf(wr[i4 + 1], hv.y, pr); pz = fmaf(wz[i4 + 1], hv.y, pz); pn = fmaf(wn[i4 + 1], hv.y, pn);
+      pr = fmaf(wr[i4 + 2], hv.z, pr); pz = fmaf(wz[i4 + 2], hv.z, pz); pn = fmaf(wn[i4 + 2], hv.z, pn);
+      pr = fmaf(wr[i4 + 3], hv.w, pr); pz = fmaf(wz[i4 + 3], hv.w, pz); pn = fmaf(wn[i4 + 3], hv.w, pn);
+    }
+    float ig = bi;                       // gate q of W_ih x + b_ih
+    for (int c = 0; c < C_in; ++c) ig = fmaf(wih[(size_t)grow * C_in + c], xc[c], ig);
+    pr += q == 0 ? ig : 0.0f;            // r and z: input and recurrent parts simply add
+    pz += q == 1 ? ig : 0.0f;
+    const float in_n = g_quad_perm<0xAA>(ig);     // quad_perm [2, 2, 2, 2]: the n gate's input part, kept apart
+    const float sr = g_quad_sum(pr) + bhr, sz = g_quad_sum(pz) + bhz, sn = g_quad_sum(pn) + bhn;
+    const float r = 1.0f / (1.0f + expf(-sr));
+    const float z = 1.0f / (1.0f + expf(-sz));
+    const float nn = tanhf(in_n + r * sn);
+    const float hv = (1.0f - z) * nn + z * hp[unit ? j : 0];
+    if (unit && q == 0) {
+      hbuf[(cur ^ 1) * 4 * KQ + j] = hv;
+      out[((size_t)b * T + t) * H + j] = hv;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (hT && unit && q == 0) hT[(size_t)b * H + j] = hbuf[cur * 4 * KQ + j];
+}
+
 // (B, T, H) -> (B, H, T) (the GRU writes frame-major, the Conv1d stacks read channel-major)
 __global__ void g_bth_to_bht_kernel(const float* __restrict__ x, int T, int H, float* __restrict__ y) {
   const int b = blockIdx.y;
@@ -184,7 +266,7 @@ __global__ __launch_bounds__(256) void g_oscillator_kernel(const float* __restri
   const float kf = (float)k;
   const float f0n = f0_up[(size_t)b * N + n];
   const float arg = kf * phase[(size_t)b * N + n] + shift;            // two roundings (-ffp-contract=off)
-  const float v = nws_sinf(arg);
+  const float v = nws_sinf_nocall(arg);
   out[((size_t)b * K + (k - 1)) * N + n] = (f0n * kf) < sample_rate * 0.5f ? v : 0.0f;
 }
 
@@ -243,18 +325,18 @@ struct GShaper {
 // ATen's order), torch.sin -> nws_sinf.
 __device__ __forceinline__ float g_exact_shaper(const GShaper& P, int s, float x, float* hb, int tid, int nthreads) {
   float a = P.in_scale[s] * x;
-  if (P.depth == 1) return nws_sinf(fmaf(P.w[0][s], a, P.b[0][s]));
+  if (P.depth == 1) return nws_sinf_nocall(fmaf(P.w[0][s], a, P.b[0][s]));
   const int W = P.width;
   float* cur = hb;
   float* nxt = hb + (size_t)W * nthreads;
-  for (int j = 0; j < W; ++j) cur[(size_t)j * nthreads + tid] = nws_sinf(fmaf(P.w[0][s * W + j], a, P.b[0][s * W + j]));
+  for (int j = 0; j < W; ++j) cur[(size_t)j * nthreads + tid] = nws_sinf_nocall(fmaf(P.w[0][s * W + j], a, P.b[0][s * W + j]));
   for (int layer = 1; layer < P.depth - 1; ++layer) {
     const float* wl = P.w[layer] + (size_t)s * W * W;
     const float* bl = P.b[layer] + (size_t)s * W;
     for (int i = 0; i < W; ++i) {
       float acc = bl[i];
       for (int j = 0; j < W; ++j) acc = fmaf(wl[i * W + j], cur[(size_t)j * nthreads + tid], acc);
-      nxt[(size_t)i * nthreads + tid] = nws_sinf(acc);
+      nxt[(size_t)i * nthreads + tid] = nws_sinf_nocall(acc);
     }
     float* t = cur;
     cur = nxt;
@@ -263,7 +345,7 @@ __device__ __forceinline__ float g_exact_shaper(const GShaper& P, int s, float x
   const float* wl = P.w[P.depth - 1] + (size_t)s * W;
   float acc = P.b[P.depth - 1][s];
   for (int j = 0; j < W; ++j) acc = fmaf(wl[j], cur[(size_t)j * nthreads + tid], acc);
-  return nws_sinf(acc);
+  return nws_sinf_nocall(acc);
 }
 
 // FastNEWT.shaping_fn (shaping.py:136-151), the reference's chain rounding for rounding (index scale `size`, clamped floor,
@@ -323,6 +405,100 @@ __global__ __launch_bounds__(128) void g_film_shaper_kernel(GShaper P, const flo
     const float x = g_i * exciter[((size_t)b * S + s) * N + n] + b_i;
     const float sh = P.lut ? g_lut_shaper(P, s, x) : g_exact_shaper(P, s, x, hb, threadIdx.x, 128);
     out[((size_t)b * S + s) * N + n] = g_n * sh + b_n;
+  }
+}
+
+// ---- oscillator bank + harmonic mixer + FiLM + shapers + NEWT mixer in ONE kernel (round 4) -----------------------------
+// The stage kernels above materialise the oscillator bank (B, K, N) (26 MB per 4 s utterance at 101 harmonics), the exciter
+// (B, S, N) and the shaped signal (B, S, N).  Inside a forward none of them is needed: thread = sample keeps the S mixer
+// accumulators in registers (S rounded up to the compile-time bucket SB: padded weight columns are zero), walks the harmonics
+// once (one sine per harmonic, the K x SB transposed mixer weights are wave-uniform: scalar loads), then runs the FiLM'ed
+// shapers channel by channel and folds them into the <= 4 NEWT output channels.  The FiLM rows of the workgroup's frames sit
+// in LDS.  Same summation orders and rounding chains as g_oscillator / g_conv1x1 / g_film_shaper (bit-identical results).
+__global__ void g_mixer_t_kernel(const float* __restrict__ w, int S, int K, int SB, float* __restrict__ wt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;     // wt[k][s], s < SB
+  if (i >= K * SB) return;
+  const int k = i / SB, sidx = i - k * SB;
+  wt[i] = sidx < S ? w[(size_t)sidx * K + k] : 0.0f;
+}
+
+// EXC_ONLY: stop at the exciter (B, S, N) = oscillator bank x mixer + bias; the sin-MLP shapers then run in g_film_shaper_kernel,
+// whose 128-thread workgroups keep many more waves per CU than this kernel's LDS allows (measured at B = 64, default sizes,
+// exact shapers: 43 ms with everything in here against 17.7 ms for the stage kernels)
+template <int SB, bool EXC_ONLY>
+__global__ __launch_bounds__(256) void g_exciter_newt_kernel(GShaper P, const float* __restrict__ f0_up, const float* __restrict__ phase,
+                                                             const float* __restrict__ phase_u, const float* __restrict__ rand_phase,
+                                                             const float* __restrict__ wt, const float* __restrict__ mixer_b,
+                                                             const float* __restrict__ film, const float* __restrict__ out_w,
+                                                             const float* __restrict__ out_b, int K, int T, int N, int hop, float scale,
+                                                             float sample_rate, int OC, int nf, float* __restrict__ out) {
+  extern __shared__ float lds[];     // shift[K] | film rows [4 S][nf]
+  float* shift = lds;
+  float* fl = lds + K;
+  const int S = P.S;
+  const int b = blockIdx.z, tid = threadIdx.x;
+  const int n0 = blockIdx.x * 256;
+  const int n = n0 + tid;
+  const bool live = n < N;
+  // frames the workgroup's samples interpolate between: [fa, fa + nf)
+  const GLerp first = g_lerp_coeff(n0, T, scale);
+  const int fa = first.i0;
+  for (int k = tid; k < K; k += 256) shift[k] = phase_u[k] * rand_phase[k] - kPiF;     // generators.py:54-56, two roundings
+  if (!EXC_ONLY) {
+    const float* fb = film + (size_t)b * 4 * S * T;
+    for (int i = tid; i < 4 * S * nf; i += 256) {
+      const int ch = i / nf, f = i - ch * nf;
+      fl[i] = fb[(size_t)ch * T + (fa + f < T ? fa + f : T - 1)];
+    }
+  }
+  __syncthreads();
+  const int nn = live ? n : N - 1;
+  const float f0n = f0_up[(size_t)b * N + nn], ph = phase[(size_t)b * N + nn];
+  float acc[SB];
+#pragma unroll
+  for (int c = 0; c < SB; ++c) acc[c] = 0.0f;
+  const float nyq = sample_rate * 0.5f;
+  for (int k = 1; k <= K; ++k) {
+    const float kf = (float)k;
+    const float arg = kf * ph + shift[k - 1];                       // two roundings (-ffp-contract=off)
+    const float v = (f0n * kf) < nyq ? nws_sinf_nocall(arg) : 0.0f;
+    const float* wr = wt + (size_t)(k - 1) * SB;
+#pragma unroll
+    for (int c = 0; c < SB; ++c) acc[c] = fmaf(wr[c], v, acc[c]);
+  }
+  if (EXC_ONLY) {
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < SB; ++c)
+        if (c < S) out[((size_t)b * S + c) * N + n] = acc[c] + mixer_b[c];
+    }
+    return;
+  }
+  const GLerp lc = g_lerp_coeff(nn, T, scale);
+  const int l0 = lc.i0 - fa, l1 = lc.i1 - fa;
+  // (table shapers only on this route - the launcher sends the sin-MLP shapers through EXC_ONLY: their body is far too large to
+  // unroll SB times, and a run-time channel index into the accumulators would be scratch memory)
+  float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
+#pragma unroll
+  for (int c = 0; c < SB; ++c) {
+    if (c < S) {
+      auto lerp = [&](int ch) { return fmaf(lc.w0, fl[ch * nf + l0], lc.w1 * fl[ch * nf + l1]); };
+      const float g_i = lerp(c), b_i = lerp(S + c), g_n = lerp(2 * S + c), b_n = lerp(3 * S + c);
+      const float e = acc[c] + mixer_b[c];
+      const float x = g_i * e + b_i;
+      const float v = g_n * g_lut_shaper(P, c, x) + b_n;
+      o0 = fmaf(out_w[c], v, o0);
+      if (OC > 1) o1 = fmaf(out_w[S + c], v, o1);
+      if (OC > 2) o2 = fmaf(out_w[2 * S + c], v, o2);
+      if (OC > 3) o3 = fmaf(out_w[3 * S + c], v, o3);
+    }
+  }
+  if (live) {
+    float* op = out + (size_t)b * OC * N + n;
+    op[0] = o0 + out_b[0];
+    if (OC > 1) op[(size_t)N] = o1 + out_b[1];
+    if (OC > 2) op[(size_t)2 * N] = o2 + out_b[2];
+    if (OC > 3) op[(size_t)3 * N] = o3 + out_b[3];
   }
 }
 
@@ -536,6 +712,21 @@ int nws_g_gru(const float* w_ih, const float* w_hh, const float* b_ih, const flo
   const size_t lds = ((size_t)2 * hidden + C_in) * sizeof(float);
   if (lds > 160 * 1024) return NWS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  if (hidden <= 128 && !getenv("NWS_G_GRU_L2")) {
+    // W_hh in registers: four lanes per hidden unit (whole waves: units rounded up to 16)
+    const int threads = 4 * ((hidden + 15) & ~15);
+    const int kq = hidden <= 32 ? 8 : hidden <= 64 ? 16 : 32;
+    const size_t qlds = ((size_t)2 * 4 * kq + 2 * C_in + (size_t)3 * hidden * C_in) * sizeof(float);
+    if (qlds <= 64 * 1024) {
+      switch (kq) {
+        case 8: g_gru_q_kernel<8><<<B, threads, qlds, st>>>(w_ih, w_hh, b_ih, b_hh, control, C_total, C_in, hidden, T, h0, out, hT); break;
+        case 16: g_gru_q_kernel<16><<<B, threads, qlds, st>>>(w_ih, w_hh, b_ih, b_hh, control, C_total, C_in, hidden, T, h0, out, hT); break;
+        default: g_gru_q_kernel<32><<<B, threads, qlds, st>>>(w_ih, w_hh, b_ih, b_hh, control, C_total, C_in, hidden, T, h0, out, hT); break;
+      }
+      NWS_CHECK_LAUNCH();
+      return NWS_OK;
+    }
+  }
   float* wt = static_cast<float*>(workspace);
   const int cells = 3 * hidden * hidden;
   g_transpose_kernel<<<(cells + 255) / 256, 256, 0, st>>>(w_hh, 3 * hidden, hidden, wt);
@@ -751,6 +942,53 @@ static GArena g_carve(const NwsGenericModel* m, int B, int T, void* ws, size_t b
   return a;
 }
 
+// launch of g_exciter_newt_kernel; NWS_ERR_UNSUPPORTED when the sizes do not fit it (the caller runs the stage kernels).
+// `scratch` >= K * 64 floats (the oscillator-bank region of the arena, unused on this route) receives the transposed mixer.
+static int g_exciter_newt_fused(const NwsGenericModel* m, const float* f0_up, const float* phase, const float* phase_u,
+                                const float* rand_phase, const float* film, int B, int T, int N, float sample_rate, float* scratch,
+                                float* newt_out, float* exciter_out, float* shaped, void* stream) {
+  const int S = m->n_shapers, K = m->n_harmonics, OC = m->out_channels;
+  if (S > 64 || OC > 4 || B > 65535 || getenv("NWS_G_STAGES")) return NWS_ERR_UNSUPPORTED;
+  const bool exc_only = m->shaper.lut == nullptr;     // sin-MLP shapers: see EXC_ONLY
+  const int SB = S <= 8 ? 8 : S <= 16 ? 16 : S <= 32 ? 32 : 64;
+  const int nf = 256 / m->hop + 3;                  // frames 256 consecutive samples can touch (+ the clamped right neighbour)
+  const NwsShaperDesc* d = &m->shaper;
+  const size_t lds = exc_only ? (size_t)K * sizeof(float) : ((size_t)K + (size_t)4 * S * nf) * sizeof(float);
+  if (lds > 160 * 1024) return NWS_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  g_mixer_t_kernel<<<(K * SB + 255) / 256, 256, 0, st>>>(m->mixer_w, S, K, SB, scratch);
+  NWS_CHECK_LAUNCH();
+  const dim3 grid((N + 255) / 256, 1, B);
+  const float scale = (float)T / (float)N;
+  const GShaper P = to_dev(d);
+#define NWS_G_EN(SBV)                                                                                                              \
+  {                                                                                                                                \
+    static unsigned long long attr = 0;                                                                                            \
+    if (int rc = ensure_lds(reinterpret_cast<const void*>(g_exciter_newt_kernel<SBV, false>), attr)) return rc;                    \
+    if (exc_only)                                                                                                                  \
+      g_exciter_newt_kernel<SBV, true><<<grid, 256, lds, st>>>(P, f0_up, phase, phase_u, rand_phase, scratch, m->mixer_b, film,    \
+                                                                 m->newt_out_w, m->newt_out_b, K, T, N, m->hop, scale, sample_rate, \
+                                                                 OC, nf, exciter_out);                                             \
+    else                                                                                                                           \
+      g_exciter_newt_kernel<SBV, false><<<grid, 256, lds, st>>>(P, f0_up, phase, phase_u, rand_phase, scratch, m->mixer_b, film,   \
+                                                                  m->newt_out_w, m->newt_out_b, K, T, N, m->hop, scale,            \
+                                                                  sample_rate, OC, nf, newt_out);                                  \
+  }
+  if (SB == 8) NWS_G_EN(8)
+  else if (SB == 16) NWS_G_EN(16)
+  else if (SB == 32) NWS_G_EN(32)
+  else NWS_G_EN(64)
+#undef NWS_G_EN
+  NWS_CHECK_LAUNCH();
+  if (exc_only) {
+    // (`shaped` may alias the scratch: the transposed mixer is dead once the exciter kernel above has run)
+    int rc = nws_g_film_shaper(&m->shaper, exciter_out, film, B, T, m->hop, shaped, stream);
+    if (rc != NWS_OK) return rc;
+    return nws_g_conv1x1(shaped, m->newt_out_w, m->newt_out_b, B, S, OC, N, newt_out, stream);
+  }
+  return NWS_OK;
+}
+
 size_t nws_forward_generic_workspace_bytes(const NwsGenericModel* m, int B, int T) {
   if (!m || B <= 0 || T <= 0 || m->hop <= 0) return 0;
   const size_t N = (size_t)T * m->hop;
@@ -798,11 +1036,18 @@ int nws_forward_generic(const NwsGenericModel* m, const float* f0, const float* 
                m->ln_eps, m->leaky_slope, a.H, stream));
   // exciter (neural_waveshaping.py:75-76, :64-67)
   G(nws_g_phase(f0, nullptr, B, T, m->hop, sample_rate, a.f0_up, a.phase, stream));
-  G(nws_g_oscillator(a.f0_up, a.phase, phase_u, rand_phase, K, B, N, sample_rate, a.osc, stream));
-  G(nws_g_conv1x1(a.osc, m->mixer_w, m->mixer_b, B, K, S, N, a.exciter, stream));
-  // NEWT (shaping.py:67-79)
-  G(nws_g_film_shaper(&m->shaper, a.exciter, a.film, B, T, m->hop, a.shaped, stream));
-  G(nws_g_conv1x1(a.shaped, m->newt_out_w, m->newt_out_b, B, S, m->out_channels, N, a.newt, stream));
+  // oscillator bank -> harmonic mixer -> FiLM / shapers -> NEWT mixer (generators.py:58-66, neural_waveshaping.py:64-67,
+  // shaping.py:67-79): one kernel that keeps everything between the phase and the NEWT output in registers when the sizes allow
+  // (<= 64 shapers, <= 4 output channels), the stage kernels otherwise
+  rc = g_exciter_newt_fused(m, a.f0_up, a.phase, phase_u, rand_phase, a.film, B, T, N, sample_rate, a.osc, a.newt, a.exciter, a.shaped, stream);
+  if (rc == NWS_ERR_UNSUPPORTED) {
+    G(nws_g_oscillator(a.f0_up, a.phase, phase_u, rand_phase, K, B, N, sample_rate, a.osc, stream));
+    G(nws_g_conv1x1(a.osc, m->mixer_w, m->mixer_b, B, K, S, N, a.exciter, stream));
+    G(nws_g_film_shaper(&m->shaper, a.exciter, a.film, B, T, m->hop, a.shaped, stream));
+    G(nws_g_conv1x1(a.shaped, m->newt_out_w, m->newt_out_b, B, S, m->out_channels, N, a.newt, stream));
+  } else if (rc != NWS_OK) {
+    return rc;
+  }
   // noise branch + branch sum (generators.py:21-35, neural_waveshaping.py:82-86)
   G(nws_g_fir_design(a.H, m->noise_window, m->fir_len, B, T, a.fir, stream));
   G(nws_g_fir_noise(a.fir, noise, m->fir_len, m->hop, B, T, a.newt, m->out_channels, a.pre, stream));

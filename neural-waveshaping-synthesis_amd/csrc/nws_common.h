@@ -132,6 +132,26 @@ __device__ __forceinline__ float nws_sin_wide(float x) {
   return __builtin_amdgcn_sinf((float)t);
 }
 
+// nws_sinf without a device function call on any path (a call inside a kernel that keeps dozens of accumulators live spills
+// them around the call): the polynomial form up to 6e6, the inline fp64 reduction + v_sin_f32 beyond
+__device__ __forceinline__ float nws_sinf_nocall(float x) {
+  if (__builtin_expect(fabsf(x) > 6.0e6f, 0)) return nws_sin_wide(x);
+  const float fq = rintf(x * 0.6366197723675814f);
+  float r = fmaf(fq, -1.5707963705062866f, x);
+  r = fmaf(fq, 4.371138828673793e-08f, r);
+  int q = (int)fq;
+  if (fabsf(x) > 32768.0f) {
+    const float fq2 = rintf(r * 0.6366197723675814f);
+    r = fmaf(fq2, -1.5707963705062866f, r);
+    r = fmaf(fq2, 4.371138828673793e-08f, r);
+    q += (int)fq2;
+  }
+  const float sv = nws_sin_poly(r);
+  const float cv = nws_cos_poly(r);
+  const float v = (q & 1) ? cv : sv;
+  return (q & 2) ? -v : v;
+}
+
 __device__ __forceinline__ float nws_sin_turns_checked(float x) {
   return __builtin_expect(fabsf(x) > 6.0e6f, 0) ? nws_sin_wide(x) : nws_sin_turns(x);
 }

@@ -16,18 +16,26 @@ struct MlpArgs {
   const float* ln_b[kMaxDepth];
 };
 
-// One workgroup = one utterance x 32 frames; activations in LDS as X[channel][frame] (stride 33); thread (cg, f) owns frame f
-// and channels cg, cg + 8, ...  Layer i: Conv1d(k=1) -> [LayerNorm over channels (biased variance) -> LeakyReLU] except last.
+// One workgroup (4 waves) = one utterance x 32 frames; activations in LDS as X[channel][frame] (stride 33).  Layer i:
+// Conv1d(k=1) -> [LayerNorm over channels (biased variance) -> LeakyReLU] except last.  The contraction of a layer runs on the
+// matrix cores in exact fp32 (v_mfma_f32_32x32x2_f32: wave w takes the 32-channel output tiles w, w + 4, ...; lane half h of a
+// 32-wide K chunk contracts k0 + 16 h .. k0 + 16 h + 15, the order of a sum being free, so every lane reads 16 consecutive
+// weights of its row) - round 4: the per-thread FMA loop it replaces read every weight through the vector cache once per
+// frame group (0.46 ms per call at 64 x 500 frames of the default sizes; runtime sizes, guards instead of padding).
+__device__ __forceinline__ int td_frag_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
 __global__ __launch_bounds__(256) void td_mlp_kernel(MlpArgs a, const float* __restrict__ x, int in_size, int hidden,
                                                      int out_size, int depth, int T, float eps, float slope,
                                                      float* __restrict__ y) {
   extern __shared__ float lds[];
-  const int maxw = in_size > hidden ? in_size : hidden;
+  int maxw = in_size > hidden ? in_size : hidden;
+  maxw = maxw > out_size ? maxw : out_size;
   float* bufA = lds;                       // [maxw][33]
   float* bufB = lds + (size_t)maxw * 33;   // [maxw][33]
   float* red = bufB + (size_t)maxw * 33;   // [2][8][32]
   const int b = blockIdx.y, t0 = blockIdx.x * kFT;
   const int f = threadIdx.x & 31, cg = threadIdx.x >> 5;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
   const int t = t0 + f;
   const bool live = t < T;
   for (int c = cg; c < in_size; c += 8) bufA[c * 33 + f] = live ? x[((size_t)b * in_size + c) * T + t] : 0.0f;
@@ -40,20 +48,54 @@ __global__ __launch_bounds__(256) void td_mlp_kernel(MlpArgs a, const float* __r
     const float* __restrict__ W = a.w[layer];
     const float* __restrict__ bias = a.b[layer];
     const bool last = layer == depth - 1;
-    float s1 = 0.0f;
-    for (int c = cg; c < cout; c += 8) {
-      float acc = bias[c];
-      const float* wr = W + (size_t)c * cin;
-      for (int k = 0; k < cin; ++k) acc = fmaf(wr[k], cur[k * 33 + f], acc);
-      if (last) {
-        if (live) y[((size_t)b * out_size + c) * T + t] = acc;
-      } else {
-        nxt[c * 33 + f] = acc;
-        s1 += acc;
+    const bool vec = (cin & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
+    for (int mt = wave; 32 * mt < cout; mt += 4) {
+      const int row = 32 * mt + col;
+      const float* wr = W + (size_t)(row < cout ? row : cout - 1) * cin;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      for (int k0 = 0; k0 < cin; k0 += 32) {
+        const int kb = k0 + 16 * half;
+        float av[16];
+        if (vec && kb + 16 <= cin) {
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const float4 v4 = *reinterpret_cast<const float4*>(wr + kb + 4 * q4);
+            av[4 * q4] = v4.x;
+            av[4 * q4 + 1] = v4.y;
+            av[4 * q4 + 2] = v4.z;
+            av[4 * q4 + 3] = v4.w;
+          }
+        } else {
+#pragma unroll
+          for (int s2 = 0; s2 < 16; ++s2) av[s2] = kb + s2 < cin ? wr[kb + s2] : 0.0f;
+        }
+        if (row >= cout) {
+#pragma unroll
+          for (int s2 = 0; s2 < 16; ++s2) av[s2] = 0.0f;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+          const float bv = kb + s2 < cin ? cur[(kb + s2) * 33 + col] : 0.0f;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv, acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = 32 * mt + td_frag_row(r, half);
+        if (c < cout) nxt[c * 33 + col] = acc[r] + bias[c];
       }
     }
-    if (last) break;
+    __syncthreads();
+    if (last) {
+      for (int c = cg; c < cout; c += 8)
+        if (live) y[((size_t)b * out_size + c) * T + t] = nxt[c * 33 + f];
+      break;
+    }
     // LayerNorm over the `hidden` channels of frame f: mean, then variance about the mean (two passes, like ATen)
+    float s1 = 0.0f;
+    for (int c = cg; c < cout; c += 8) s1 += nxt[c * 33 + f];
     red[cg * 32 + f] = s1;
     __syncthreads();
     float mean = 0.0f;
@@ -155,7 +197,8 @@ int nws_td_mlp(const float* x, int B, int in_size, int hidden, int out_size, int
       a.ln_b[i] = ln_b[i];
     }
   }
-  const int maxw = in_size > hidden ? in_size : hidden;
+  int maxw = in_size > hidden ? in_size : hidden;
+  maxw = maxw > out_size ? maxw : out_size;
   const size_t lds = ((size_t)2 * maxw * 33 + 512) * sizeof(float);
   if (lds > 160 * 1024) return NWS_ERR_UNSUPPORTED;   // layer widths up to ~600
   static unsigned long long attr_devices = 0;
