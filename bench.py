@@ -295,7 +295,8 @@ def hbm_algorithmic_bytes(B, T):
         # f0 frames + FiLM rows (B,T,256) in, carries (B, N/32) f64 in, fragment + pair tables (28 KB + 2 MB, shared), out (B,N)
         "exciter_newt_kernel": 4 * B * T + 1024 * B * T + 8 * B * N // 32 + 28672 + 2 * 64 * 4096 * 4 + 4 * B * N,
         "control_gru_kernel": 8 * B * T + 512 * B * T + 384 * 131 * 4,                 # control in, gru_out (B,T,128) out, weights
-        "frame_mlps64_kernel": 512 * B * T + 745472 + 1024 * B * T + 4 * B * T * FIR_ROW_FLOATS,   # gru_out in, frags, film + noise-filter rows out
+        # gru_out in (read by both path workgroups: the second read hits L2), the 712 KB fragment table, film + noise-filter rows out
+        "frame_mlps_wr_kernel": 512 * B * T + 729088 + 1024 * B * T + 4 * B * T * FIR_ROW_FLOATS,
         "fir_noise_mfma_kernel": 4 * B * T * FIR_ROW_FLOATS + 4 * N + 2 * 4 * B * N,  # filter rows in, noise, add_in in + out
         # four-step FFT, two utterances per complex transform: x read by the forward column pass and again for the dry add, the
         # (re, im) planes of B/2 transforms written once, read + written by the row pass, read by the inverse column pass, y out
@@ -307,7 +308,9 @@ def kernel_roofline(name, pmc, ms, algo_flop=None, mfma_flop=None, hbm_note=None
     """One roofline entry: what bounds the kernel and how close it runs to that bound."""
     e = {"kernel": name, "kernel_ms": ms}
     ks = (pmc or {}).get("kernels", {})
-    k = ks.get(name) or (ks.get("frame_mlps16_kernel") if name == "frame_mlps64_kernel" else None)
+    k = ks.get(name)
+    if k is None and name == "frame_mlps_wr_kernel":      # smaller batches run the tile kernels (csrc/frame_mlps.hip)
+        k = ks.get("frame_mlps64_kernel") or ks.get("frame_mlps16_kernel")
     if algo_flop is not None and ms:
         e["algorithmic_tflops"] = algo_flop / (ms * 1e-3) / 1e12
     if mfma_flop is not None and ms:
@@ -825,6 +828,7 @@ def main():
         if a.pmc in ("auto", "live") and world == 1 and st:
             stage_ns = {"exciter_newt_kernel": st.get("exciter_newt", 0) * 1e6, "control_gru_kernel": st.get("control_gru", 0) * 1e6,
                         "frame_mlps16_kernel": st.get("frame_mlps", 0) * 1e6, "frame_mlps64_kernel": st.get("frame_mlps", 0) * 1e6,
+                        "frame_mlps_wr_kernel": st.get("frame_mlps", 0) * 1e6,
                         "fir_noise_mfma_kernel": st.get("fir_noise", 0) * 1e6}
             try:
                 pmc, pmc_src = collect_pmc_live(a, stage_ns)
@@ -879,8 +883,9 @@ def main():
                 kernel_roofline("control_gru_kernel", pmc, st.get("control_gru"), algo_flop=FLOP_PER_STEP_GRU * B * T,
                                 hbm_note="sequential recurrence, one workgroup per utterance: bound by the per-step latency chain "
                                          "(B of 256 CUs busy); fp32 VALU peak of those CUs = B/256 x 157.3 TFLOP/s"),
-                kernel_roofline("frame_mlps64_kernel", pmc, st.get("frame_mlps"), algo_flop=FLOP_PER_FRAME_MLPS * B * T,
-                                mfma_flop=3 * FLOP_PER_FRAME_MLPS * B * T),
+                # (executed: the three products of the two-term split, and proj in both path workgroups)
+                kernel_roofline("frame_mlps_wr_kernel", pmc, st.get("frame_mlps"), algo_flop=FLOP_PER_FRAME_MLPS * B * T,
+                                mfma_flop=3 * (FLOP_PER_FRAME_MLPS + 2 * 128 * 128) * B * T),
                 kernel_roofline("fir_noise_mfma_kernel", pmc, st.get("fir_noise"), algo_flop=FLOP_PER_FRAME_NOISE * B * T,
                                 mfma_flop=3 * FLOP_PER_FRAME_NOISE * B * T),
                 kernel_roofline("reverb (col125_fwd + row + col125_inv)", pmc, st.get("reverb"),

@@ -109,6 +109,9 @@ typedef struct NwsWeights {
                                    weight energy in the shipped checkpoints), one term for harmonics 16..101 */
 #define NWS_EXCITER_HYBRID_W 8  /* NWS_EXCITER_HYBRID plus: the mixer WEIGHTS of harmonics 16..101 as one fp16 term as well
                                    (one MFMA per product there instead of two) */
+#define NWS_EXCITER_BANK_NOFRACT 16 /* exact sin-MLP shapers (shaping.py:36-37): the hidden and output layers' pre-activations are
+                                   provably inside v_sin_f32's own +-256-turn domain (sum |W| + |b| per row, checked by the caller
+                                   from the weights), so their sines skip the v_fract: 24 of an evaluation's 25 */
 
 int nws_abi_version(void);
 /* sizeof of the C structs above as this library was compiled (0 NwsWeights, 1 NwsReverbPlan, 2 NwsForwardAux, 3 NwsShaperDesc, 4 NwsGenericModel): lets a

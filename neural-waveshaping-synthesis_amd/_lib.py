@@ -16,6 +16,7 @@ EXCITER_VALU_FILM = 1    # NwsWeights.exciter_opts bits (include/nws_hip.h)
 EXCITER_ONE_TERM = 2
 EXCITER_HYBRID = 4
 EXCITER_HYBRID_W = 8
+EXCITER_BANK_NOFRACT = 16
 N_HARMONICS = 101
 N_SHAPERS = 64
 HIDDEN = 128

@@ -15,6 +15,7 @@
 // indistinguishable from the exact-fp32 MFMA it replaced, at 1/5 of its matrix-pipe time, and unlike
 // the fp32 MFMA it overlaps with the VALU work.  The 64x32 accumulator tile then goes straight through
 // FiLM -> LUT (or sin-MLP) -> FiLM -> 64->1 mix in registers; one coalesced 128 B store per wave.
+#include <cstdlib>
 #include <type_traits>
 
 #include "nws_common.h"
@@ -40,7 +41,9 @@ enum Opt {
   kOptHybridW = 16      // with kOptHybrid: the mixer WEIGHTS of harmonics 16..101 as one fp16 term too (1 MFMA per product)
 };
 static_assert((kOptScalarSines ^ kOptFilmMfma ^ kOptOneTerm ^ kOptHybrid ^ kOptHybridW) == 31, "Opt bits must be distinct");
-enum Mode { kModeLut = 0, kModeExact = 1, kModeExciterOnly = 2, kModeLutPairs = 3, kModeLutPairsDiv6 = 4, kModeExactBank = 5 };
+enum Mode { kModeLut = 0, kModeExact = 1, kModeExciterOnly = 2, kModeLutPairs = 3, kModeLutPairsDiv6 = 4, kModeExactBank = 5,
+            kModeExactBankNF = 6 };   // NF: no v_fract in front of the sines of the hidden and output layers (NWS_EXCITER_BANK_NOFRACT)
+__host__ __device__ constexpr bool is_bank(int mode) { return mode == kModeExactBank || mode == kModeExactBankNF; }
 __host__ __device__ constexpr bool is_lut(int mode) {
   return mode == kModeLut || mode == kModeLutPairs || mode == kModeLutPairsDiv6;
 }
@@ -180,6 +183,14 @@ struct BankLds {
   float red[4][kTile];
 };
 
+// FRACT = false: the pre-activation goes to v_sin_f32 as it is (in turns).  The instruction reduces arguments inside +-256 turns
+// by itself; hidden and output layers of a sin-MLP see |pre| <= sum |W| + |b| (their inputs are sines), which the host checks
+// against that domain once per weights version (engine.py: bank_nofract_safe; 0.6 turns for the shipped checkpoints).  One
+// quarter-rate instruction per sine instead of two: 24 of the 25 sines of an evaluation.
+template <bool FRACT>
+__device__ __forceinline__ float bank_sin(float t) { return FRACT ? sin_of_turns(t) : __builtin_amdgcn_sinf(t); }
+
+template <bool FRACT>
 __device__ __forceinline__ void bank_layer8(const float* __restrict__ wt, const float* __restrict__ bias,
                                             const float (&h)[8], float (&out)[8]) {
   f32x2 acc[4] = {{bias[0], bias[1]}, {bias[2], bias[3]}, {bias[4], bias[5]}, {bias[6], bias[7]}};
@@ -191,25 +202,30 @@ __device__ __forceinline__ void bank_layer8(const float* __restrict__ wt, const 
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    out[2 * q] = sin_of_turns(acc[q].x);
-    out[2 * q + 1] = sin_of_turns(acc[q].y);
+    out[2 * q] = bank_sin<FRACT>(acc[q].x);
+    out[2 * q + 1] = bank_sin<FRACT>(acc[q].y);
   }
 }
 
 // W: wave-uniform pointer to the shaper's table row (scalar loads).  Every sine keeps its v_fract: a variant without it for
 // shapers whose hidden pre-activations provably stay inside v_sin_f32's +-256-turn domain was measured SLOWER (1.69 vs
 // 1.56 ms at B=64: two copies of the loop body, one uniform branch per shaper).
+// (Round 4, measured and dropped: the two 8 x 8 hidden layers as 2 x 16 v_mfma_f32_4x4x1_16B_f32 per evaluation - lane 4 blk + j
+// holds sample j's activation as B and its four output rows as the accumulator, the wave-uniform weight column comes from lane
+// 4 blk + i; layout probed in tools/ubench/mfma4x4x1_layout.hip.  Same results, 1.71 against 1.49 ms per B = 64 launch: eight
+// dependent two-pass MFMAs per accumulator with only four chains in flight, plus 32 per-lane weight loads per shaper.)
+template <bool FRACT>
 __device__ __forceinline__ float bank_shaper(const float* __restrict__ W, float x) {
   const float a = W[169] * x;
   float h1[8], h2[8];
 #pragma unroll
-  for (int o = 0; o < 8; ++o) h1[o] = sin_of_turns(fmaf(W[o], a, W[8 + o]));
-  bank_layer8(W + 16, W + 80, h1, h2);
-  bank_layer8(W + 88, W + 152, h2, h1);
+  for (int o = 0; o < 8; ++o) h1[o] = sin_of_turns(fmaf(W[o], a, W[8 + o]));    // the first layer's argument is unbounded: always reduced
+  bank_layer8<FRACT>(W + 16, W + 80, h1, h2);
+  bank_layer8<FRACT>(W + 88, W + 152, h2, h1);
   float acc = W[168];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc = fmaf(W[160 + i], h1[i], acc);
-  return sin_of_turns(acc);
+  return bank_sin<FRACT>(acc);
 }
 
 __global__ void shaper_turns_kernel(NwsWeights w, float* __restrict__ out) {
@@ -488,7 +504,7 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 // (0.328 ms).  (Wrong results seen with that build under two overlapping audio streams were first blamed on the scratch;
 // the multi-stream problem turned out to be independent of it, see pipeline.py.  The build still rejects scratch.)
 template <int MODE, int DBG = 0, int HPB = 1, int OPT = 0>
-__global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeExactBank ? 3 : ((OPT & kOptFilmMfma) ? 5 : ((OPT & kOptScalarSines) ? 6 : (HPB == 2 ? 7 : 5))))) void exciter_newt_kernel(NwsWeights w, const float* __restrict__ f0,
+__global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) ? 3 : ((OPT & kOptFilmMfma) ? 5 : ((OPT & kOptScalarSines) ? 6 : (HPB == 2 ? 7 : 5))))) void exciter_newt_kernel(NwsWeights w, const float* __restrict__ f0,
                                                            const float* __restrict__ f0_up,
                                                            const double* __restrict__ carry,
                                                            const float* __restrict__ phase_u,
@@ -971,7 +987,7 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
         const f32x2 g_n = fma2(w1_2, NWS_PAIR(fd[2]), NWS_PAIR(fa[2]));  // already times newt.mixer.weight
         const f32x2 xi = fma2(g_i, x2, b_i);  // FiLM (models/modules/dynamic.py:8)
         f32x2 sh;
-        if (MODE == kModeExactBank) {
+        if (is_bank(MODE)) {
           BankLds& BK = *reinterpret_cast<BankLds*>(&SH);
           BK.xi[s4 + 2 * h2][32 * w4 + col] = xi.x;
           BK.xi[s4 + 2 * h2 + 1][32 * w4 + col] = xi.y;
@@ -993,7 +1009,7 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  if (MODE == kModeExactBank) {
+  if (is_bank(MODE)) {
     BankLds& BK = *reinterpret_cast<BankLds*>(&SH);
     __syncthreads();
     // wave v: shapers 16v .. 16v+15; lane: samples `lane` and 64 + `lane` of the hop (frame pairs (j-1, j) and (j, j+1))
@@ -1006,8 +1022,8 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (MODE == kModeE
     for (int k = 0; k < 16; ++k) {
       const int sh_idx = sv + k;
       const float* __restrict__ W = bank + (size_t)sh_idx * kBankRow;   // a __restrict__ kernel argument: scalar loads
-      const float ya = bank_shaper(W, BK.xi[sh_idx][lane]);
-      const float yb = bank_shaper(W, BK.xi[sh_idx][64 + lane]);
+      const float ya = bank_shaper<MODE == kModeExactBank>(W, BK.xi[sh_idx][lane]);
+      const float yb = bank_shaper<MODE == kModeExactBank>(W, BK.xi[sh_idx][64 + lane]);
       pa = fmaf(fmaf(la.w1, L.fd[qa][2][sh_idx], L.fa[qa][2][sh_idx]), ya, pa);   // normalising FiLM gain x newt.mixer weight
       pb = fmaf(fmaf(lb.w1, L.fd[qb][2][sh_idx], L.fa[qb][2][sh_idx]), yb, pb);
     }
@@ -1354,7 +1370,10 @@ int nws_exciter_newt(const NwsWeights* w, const float* f0, const float* f0_up, c
                                                                sample_rate, exciter_out, newt_out);
     } else {
       if (!w->shaper_w0 || !w->shaper_w2 || !w->shaper_w4 || !w->shaper_w6) return NWS_ERR_BAD_ARG;
-      if (w->shaper_turns != nullptr)
+      if (w->shaper_turns != nullptr && (w->exciter_opts & NWS_EXCITER_BANK_NOFRACT))
+        exciter_newt_kernel<kModeExactBankNF><<<grid, 256, base + sizeof(BankLds), st>>>(
+            *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out, w->shaper_turns);
+      else if (w->shaper_turns != nullptr)
         exciter_newt_kernel<kModeExactBank><<<grid, 256, base + sizeof(BankLds), st>>>(
             *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out, w->shaper_turns);
       else

@@ -325,6 +325,8 @@ class Engine:
                 w.lut_pairs = None
                 w.lut_size, w.lut_min, w.lut_max = 0, 0.0, 0.0
             w.exciter_opts = self.exciter_opts()
+            if getattr(m.newt, "lookup_table", None) is None and self.bank_nofract_safe():
+                w.exciter_opts |= _lib.EXCITER_BANK_NOFRACT
             w.newt_out_w = P(m.newt.mixer[0].weight, "newt.mixer.0.weight", 64)
             w.newt_out_b = P(m.newt.mixer[0].bias, "newt.mixer.0.bias", 1)
             w.noise_window = P(m.noise_synth.window, "noise_synth.window", 256)
@@ -369,6 +371,23 @@ class Engine:
             return int(v)
         b = self.hybrid_w_bound()
         return _lib.EXCITER_HYBRID_W if (b is not None and b["bound"] <= self.HYBRID_W_BOUND) else 0
+
+    def bank_nofract_safe(self, limit_turns: float = 128.0) -> bool:
+        """Exact sin-MLP shapers: may the sines of the hidden and output layers go to v_sin_f32 without a v_fract in front?
+        Their inputs are sines, so a row's pre-activation is bounded by sum |W| + |b| whatever the signal; v_sin_f32 reduces
+        arguments inside +-256 turns itself.  One-time host check from the weights (the shipped checkpoints: 0.6 turns; the bound
+        is held to half the domain).  NWS_BANK_FRACT=1 keeps the v_fract for A/B timing."""
+        if os.environ.get("NWS_BANK_FRACT"):
+            return False
+        sh = self._model_ref.newt._modules.get("shaping_fn")
+        if sh is None or getattr(sh, "depth", 0) != 4:
+            return False
+        with torch.no_grad():
+            worst = 0.0
+            for i in (2, 4, 6):
+                wt, b = sh.net[i].weight.detach(), sh.net[i].bias.detach()
+                worst = max(worst, float((wt.abs().flatten(1).sum(1) + b.abs()).max()) / (2.0 * math.pi))
+        return math.isfinite(worst) and worst < limit_turns
 
     def hybrid_w_bound(self):
         """precision.hybrid_w_error_bound for this model (None for exact shapers: the option only exists on the LUT path)"""

@@ -1152,6 +1152,8 @@ def test_exact_shaper_bank_large_output_layer():
         m.newt.shaping_fn.net[6].weight.mul_(3000.0)      # 8 x ~0.2 x 3000 rad ~ 700 turns
     weights = {k: v.detach().clone().numpy() for k, v in m.state_dict().items()}
     m = m.cuda().eval()
+    # (round 4: such a model must NOT get the kernel variant that feeds v_sin_f32 without the v_fract)
+    assert not m._engine.bank_nofract_safe() and not (m._engine.weights()[0].exciter_opts & 16)
     g = torch.Generator().manual_seed(4)
     T = 24
     f0 = 100 + 500 * torch.rand(2, 1, T, generator=g)
@@ -1195,6 +1197,37 @@ def test_exact_shaper_lds_fallback_matches_bank(models, oracle):
     scale = float(bank.abs().max())
     record("exact_tail_bank_vs_lds_fallback", max_abs_diff=d, max_abs=scale)
     assert scale > 0 and d <= 2e-6 * max(1.0, scale), (d, scale)
+
+
+def test_exact_shaper_bank_without_fract_matches_the_reduced_form(models):
+    """Round 4: the shipped sin-MLP shapers' hidden / output pre-activations are bounded by 0.6 turns (sum |W| + |b| per row), so
+    the engine selects the bank kernel whose 24 inner sines go to v_sin_f32 unreduced (NWS_EXCITER_BANK_NOFRACT).  Same values as
+    the v_fract form to rounding; the end-to-end exact vectors (test_e2e_*) run this variant against the reference."""
+    import ctypes as C
+    import nws_amd
+    _lib = nws_amd._lib
+    m, _ = models
+    eng = m._engine
+    w, _, dev = eng.weights()
+    assert eng.bank_nofract_safe() and (w.exciter_opts & _lib.EXCITER_BANK_NOFRACT)
+    w2 = _lib.NwsWeights.from_buffer_copy(w)
+    w2.exciter_opts = w.exciter_opts & ~_lib.EXCITER_BANK_NOFRACT
+    g = torch.Generator().manual_seed(78)
+    B, T = 3, 21
+    f0 = (120 + 500 * torch.rand(B, 1, T, generator=g)).cuda()
+    control = torch.randn(B, 2, T, generator=g).cuda()
+    pu = torch.rand(101, generator=g).cuda()
+    _, film, _, _ = eng.frame_mlps(eng.control_gru(control))
+    carry = eng.phase_carry(f0=f0[:, 0].contiguous())
+    _, nf = eng.exciter_newt(f0[:, 0].contiguous(), None, carry, pu, film)
+    fr = torch.empty_like(nf)
+    _lib.check(_lib.lib().nws_exciter_newt(C.byref(w2), _lib.ptr(f0[:, 0].contiguous()), None, _lib.ptr(carry), _lib.ptr(pu),
+                                           _lib.ptr(eng.rand_phase()), _lib.ptr(film), B, T, float(m.sample_rate), None,
+                                           _lib.ptr(fr), _lib.stream_ptr()), "nws_exciter_newt (v_fract form)")
+    torch.cuda.synchronize()
+    d, scale = float((nf - fr).abs().max()), float(fr.abs().max())
+    record("exact_bank_nofract_vs_fract", max_abs_diff=d, max_abs=scale)
+    assert scale > 0 and d <= 1e-6 * max(1.0, scale), (d, scale)
 
 
 def test_exciter_optional_table_fallbacks(models):
