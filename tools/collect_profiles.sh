@@ -5,7 +5,7 @@
 #   gpurun_out/prof_<round>/pmc_*           counter passes (separate runs: SQ has 8 slots, FETCH_SIZE and WRITE_SIZE do not
 #                                           fit one pass; never combined with sys/hip/hsa traces)
 # then tools/pmc_digest.py condenses them; copy the digest files into profiles/<round>/ and commit.
-R=${1:-r03}
+R=${1:-r04}
 OUT=gpurun_out/prof_$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp
