@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void row_kernel(PlanDev d, float* __restrict__
 // the same transform (SPECTRUM_ONLY) - and the inverse runs the three passes backwards with conjugate twiddles, so neither
 // direction reorders anything.  No workgroup barrier anywhere (a wave's LDS traffic is ordered by itself); the 256-thread
 // Stockham form above needed ten per row and ran at 1.9 TB/s (17.3 us for 32.8 MB at B = 64).  Scalar fp32 butterflies: the
-// "times -i" of a packed complex type is exactly the operand swizzle the build refuses.
+// "times -i" of a packed complex type is exactly the operand swizzle the build refuses (LABBOOK.md "5.2").
 // ---------------------------------------------------------------------------------------------
 struct C8 {
   float re[8], im[8];

@@ -2,7 +2,7 @@
 // one call = K new control frames of B parallel streams in, 128 K audio samples out, ALL state device-resident behind fixed
 // pointers, so that a steady-state hop is a fixed sequence of eight launches that a hipGraph replays.
 //
-// What is carried: the GRU state h; the previous chunk's last frame (F0, FiLM row, FIR half-taps) so
+// What is carried (LABBOOK.md "7"): the GRU state h; the previous chunk's last frame (F0, FiLM row, FIR half-taps) so
 // that every kernel of the one-shot forward runs unchanged on the window [previous frame | K new frames]; the float64 phase
 // sum through the last emitted sample (spliced exactly into the window's carries); 64 samples of noise-branch residue (the
 // noise branch runs half a hop ahead of the oscillator branch); the last 384 samples of the noise stream; and, for the
