@@ -447,6 +447,9 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   return v;
 }
 
+// (Round 4, measured and dropped: mask-and-subtract instead - hi = bits & 0xFFFFE000, lo = v - hi, two v_cvt_pk - is two
+// instructions more per pair in cheaper classes and times the same (0.2605 against 0.2598 ms); LABBOOK.md.  Pitfall met on the
+// way: hipcc 7.2 reads element 0 for __builtin_bit_cast(unsigned, v.y) of an ext_vector - tools/ubench/split_probe.hip.)
 // lo = fp16(v - hi) for a packed pair, hi given as fp16: v_fma_mix{lo,hi}_f16 read the fp16 operand directly and round the
 // (exact) difference to fp16 on the way out: 2 instructions per pair instead of 2 cvt + 1 pk_add + 1 cvt_pk.
 // (hipcc folds fma(x,-1,y) to a subtraction before it can select the mixed-precision form, hence the asm.)
