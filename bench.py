@@ -86,7 +86,7 @@ def parse():
                     help="audio streams of the pipeline (or, with --pipeline 0, streams that whole forwards are issued on "
                          "round-robin).  Two overlap the tail of batch i with the head of batch i+1 (~7 %%); this is the "
                          "configuration that exposed the packed-fp32 / MFMA co-execution hazard the build now guards against "
-                         "(DESIGN.md 5.3, LABBOOK.md "5.2") - the self-check below compares it with the plain forward bit for bit")
+                         "(DESIGN.md 5.3, LABBOOK.md '5.2') - the self-check below compares it with the plain forward bit for bit")
     ap.add_argument("--depth", type=int, default=0, help="workspaces in flight (0: streams + 2)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="1: ForwardPipeline (control half = carries + GRU of batch i+1 on a side stream under the audio "

@@ -129,8 +129,12 @@ class PeerCopyAllGather:
         self.device = torch.device(device)
         self.backend = dist.get_backend(group)
         self.full = [torch.empty((self.world * self.rows, self.n), dtype=dtype, device=self.device) for _ in range(nbuf)]
-        # export: one IPC handle per buffer (the same mechanism torch.multiprocessing uses to share CUDA tensors)
-        mine = [(t.untyped_storage()._share_cuda_(), t.storage_offset(), tuple(t.shape), tuple(t.stride())) for t in self.full]
+        # export / import through torch.multiprocessing's own CUDA-tensor sharing (the documented route by which a producer process
+        # hands device tensors to a consumer: reduce_tensor -> (rebuild function, picklable IPC descriptor); dmabuf IPC handles
+        # underneath).  The producer keeps `self.full` alive for the lifetime of this object, as that protocol requires.
+        from torch.multiprocessing.reductions import reduce_tensor
+
+        mine = [reduce_tensor(t) for t in self.full]
         everybody = [None] * self.world
         dist.all_gather_object(everybody, mine, group=group)
         self.remote = []        # remote[p][slot] = rank p's gather buffer, opened in this process
@@ -139,9 +143,10 @@ class PeerCopyAllGather:
                 self.remote.append(self.full)
                 continue
             opened = []
-            for h, off, shape, stride in handles:
-                storage = torch.UntypedStorage._new_shared_cuda(*h)
-                t = torch.empty(0, dtype=dtype, device=storage.device).set_(storage, off, shape, stride)
+            for rebuild, args in handles:
+                t = rebuild(*args)
+                if tuple(t.shape) != (self.world * self.rows, self.n) or t.dtype != dtype:
+                    raise RuntimeError(f"rank {p} exported a gather buffer of {tuple(t.shape)} {t.dtype}")
                 opened.append(t)
             self.remote.append(opened)
         self._flag = torch.zeros(1, dtype=torch.float32, device=self.device)

@@ -21,7 +21,7 @@ overlap: 0.392 -> 0.364 ms per batch on one GPU; next to RCCL's own streams it w
 
 Audio streams.  `audio_streams=2` alternates the audio halves over two streams (another ~6 %: the tail of batch i - noise,
 reverb - overlaps the head of batch i+1).  That configuration exposed a hardware hazard on MI355X which the build now guards
-against (LABBOOK.md "5.2", csrc/coexec_probe.hip): a packed fp32 instruction whose low lane reads the high half of its
+against (LABBOOK.md '5.2', csrc/coexec_probe.hip): a packed fp32 instruction whose low lane reads the high half of its
 second operand (v_pk_{add,mul,fma}_f32 with op_sel[1] = 1 - what a complex "times -i" butterfly compiles to) returns wrong
 values while ANOTHER kernel executes K=16/32 f16 MFMAs on the same compute unit.  The reverb's FFT kernels of batch i, running
 beside the frame-MLP / noise kernels of batch i+1, came out wrong in pairs of rows (~1e-2) in up to half of the batches.  No

@@ -274,7 +274,7 @@ extract_perceptual_loudness.hop_length = %control_hop
 
 
 def test_build_guard_finds_swizzled_packed_forms():
-    """The ISA guard of build.py (co-execution hazard, DESIGN.md 5.3, LABBOOK.md "5.2"): clean on every product object, and it does see
+    """The ISA guard of build.py (co-execution hazard, DESIGN.md 5.3, LABBOOK.md '5.2'): clean on every product object, and it does see
     the forms when they are there (the probe kernel contains them on purpose)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("nws_build", os.path.join(ROOT, "neural-waveshaping-synthesis_amd", "build.py"))

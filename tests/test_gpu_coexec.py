@@ -1,4 +1,4 @@
-"""The MI355X co-execution hazard (csrc/coexec_probe.hip, DESIGN.md 5.3, LABBOOK.md "5.2") and the product's immunity to it.
+"""The MI355X co-execution hazard (csrc/coexec_probe.hip, DESIGN.md 5.3, LABBOOK.md '5.2') and the product's immunity to it.
 
 A v_pk_{add,mul,fma}_f32 whose low lane reads the high half of src1 returns wrong values while another kernel runs
 K=16/32 f16 MFMAs on the same CU.  The build keeps that form out of every product kernel; these tests check
@@ -29,7 +29,7 @@ def test_probe_forms_and_safe_forms_beside_mfma():
         assert counts[:4] == [0, 0, 0, 0], (load, counts)      # the forms the build lets through
     hazard = {k: v[4:] for k, v in wrong.items() if any(v[4:])}
     print("swizzled-src1 forms wrong beside:", hazard or "nothing on this box")
-    # DESIGN.md 5.3, LABBOOK.md "5.2" as falsifiable statements, with the whole matrix left in gpurun_out/parity_report.json either way:
+    # DESIGN.md 5.3, LABBOOK.md '5.2' as falsifiable statements, with the whole matrix left in gpurun_out/parity_report.json either way:
     #   (i) the swizzled-src1 forms are exact beside the MFMAs that predate gfx950 (32x32x8 f16, 32x32x2 f32) and beside nothing;
     #  (ii) IF a swizzled form fails on this box at all, it fails beside a K=16 / K=32 half-precision MFMA (the claim is about
     #       those instructions: a failure anywhere else would be a different hazard the build guard does not describe).

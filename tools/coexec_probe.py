@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Print the MI355X co-execution hazard matrix (csrc/coexec_probe.hip, DESIGN.md 5.3, LABBOOK.md "5.2").
+"""Print the MI355X co-execution hazard matrix (csrc/coexec_probe.hip, DESIGN.md 5.3, LABBOOK.md '5.2').
 
 A probe kernel evaluates eight packed-fp32 instruction forms against scalar arithmetic while, on a second stream, either
 nothing, a bare MFMA loop of one flavour, or one of the product's own MFMA kernels runs.  Columns = wrong results per form
