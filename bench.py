@@ -292,12 +292,13 @@ def collect_pmc_live(a, stage_ns):
 def hbm_algorithmic_bytes(B, T):
     N = 128 * T
     return {
-        # f0 frames + FiLM rows (B,T,256) in, carries (B, N/32) f64 in, fragment + pair tables (28 KB + 2 MB, shared), out (B,N)
-        "exciter_newt_kernel": 4 * B * T + 1024 * B * T + 8 * B * N // 32 + 28672 + 2 * 64 * 4096 * 4 + 4 * B * N,
+        # f0 frames + FiLM rows (B,T,256) in, carries (B, N/32) f64 in, fragment + pair tables (28 KB + 2 MB, shared), the noise
+        # branch (B,N) in, newt + noise (B,N) out
+        "exciter_newt_kernel": 4 * B * T + 1024 * B * T + 8 * B * N // 32 + 28672 + 2 * 64 * 4096 * 4 + 2 * 4 * B * N,
         "control_gru_kernel": 8 * B * T + 512 * B * T + 384 * 131 * 4,                 # control in, gru_out (B,T,128) out, weights
         # gru_out in (read by both path workgroups: the second read hits L2), the 712 KB fragment table, film + noise-filter rows out
         "frame_mlps_wr_kernel": 512 * B * T + 729088 + 1024 * B * T + 4 * B * T * FIR_ROW_FLOATS,
-        "fir_noise_mfma_kernel": 4 * B * T * FIR_ROW_FLOATS + 4 * N + 2 * 4 * B * N,  # filter rows in, noise, add_in in + out
+        "fir_noise_mfma_kernel": 4 * B * T * FIR_ROW_FLOATS + 4 * N + 4 * B * N,      # filter rows in, noise in, noise branch out
         # four-step FFT, two utterances per complex transform: x read by the forward column pass and again for the dry add, the
         # (re, im) planes of B/2 transforms written once, read + written by the row pass, read by the inverse column pass, y out
         "reverb": 7 * 4 * B * N,

@@ -150,6 +150,11 @@ int nws_phase_carry(const float* f0, const float* f0_up, int B, int T, double* c
 int nws_exciter_newt(const NwsWeights* w, const float* f0, const float* f0_up, const double* carry,
                      const float* phase_u, const float* rand_phase, const float* film, int B, int T,
                      float sample_rate, float* exciter_out, float* newt_out, void* stream);
+/* same with newt_out = add_in + NEWT sum; add_in (B, N) or NULL (the noise branch of neural_waveshaping.py:81 when the
+ * FIR-noise kernel ran first); add_in may not alias newt_out */
+int nws_exciter_newt_add(const NwsWeights* w, const float* f0, const float* f0_up, const double* carry,
+                         const float* phase_u, const float* rand_phase, const float* film, const float* add_in, int B,
+                         int T, float sample_rate, float* exciter_out, float* newt_out, void* stream);
 
 /*
  * Control encoder: GRU(2->128, h0=0) over T frames of control[:, 0:2]

@@ -97,6 +97,8 @@ _PROTOTYPES = {
     "nws_phase_carry": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp, _fp]),
     "nws_exciter_newt": (C.c_int, [C.POINTER(NwsWeights), _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_float,
                                    _fp, _fp, _fp]),
+    "nws_exciter_newt_add": (C.c_int, [C.POINTER(NwsWeights), _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_float,
+                                       _fp, _fp, _fp]),
     "nws_control_gru": (C.c_int, [C.POINTER(NwsWeights), _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "nws_control_gru_state": (C.c_int, [C.POINTER(NwsWeights), _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
     "nws_control_gru_carry": (C.c_int, [C.POINTER(NwsWeights), _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),

@@ -515,7 +515,8 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
                                                            const float* __restrict__ film, int T, float sample_rate,
                                                            float* __restrict__ exciter_out,
                                                            float* __restrict__ newt_out,
-                                                           const float* __restrict__ bank = nullptr) {
+                                                           const float* __restrict__ bank = nullptr,
+                                                           const float* __restrict__ add_in = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   ExcLds& L = *reinterpret_cast<ExcLds*>(smem_raw);
   ShaperLds& SH = *reinterpret_cast<ShaperLds*>(smem_raw + ((sizeof(ExcLds) + 15) & ~size_t(15)));
@@ -961,7 +962,7 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
     }
     const float bias_n = fmaf(lc.w1, L.bsum[q0 + 1] - L.bsum[q0], L.bsum[q0]);
     const float total = part + nws_swap_halves(part) + (bias_n + w.newt_out_b[0]);
-    if (half == 0) newt_out[(size_t)b * N + n] = total;
+    if (half == 0) newt_out[(size_t)b * N + n] = add_in != nullptr ? add_in[(size_t)b * N + n] + total : total;
     return;
   }
   const f32x2 w1_2 = splat2(lc.w1);
@@ -1039,7 +1040,8 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
       const int qo = lo.i0 - (jb - 1);
       const float sum = (BK.red[0][tid] + BK.red[1][tid]) + (BK.red[2][tid] + BK.red[3][tid]);
       const float bias_o = fmaf(lo.w1, L.bsum[qo + 1] - L.bsum[qo], L.bsum[qo]);
-      newt_out[(size_t)b * N + n_o] = sum + (bias_o + w.newt_out_b[0]);
+      const float tot_o = sum + (bias_o + w.newt_out_b[0]);
+      newt_out[(size_t)b * N + n_o] = add_in != nullptr ? add_in[(size_t)b * N + n_o] + tot_o : tot_o;
     }
     return;
   }
@@ -1047,7 +1049,7 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
   // the normalising FiLM biases went through the mixer per FRAME: interpolate their sum like any other parameter
   const float bias_n = fmaf(lc.w1, L.bsum[q0 + 1] - L.bsum[q0], L.bsum[q0]);
   const float total = partial + nws_swap_halves(partial) + (bias_n + w.newt_out_b[0]);
-  if (half == 0) newt_out[(size_t)b * N + n] = total;
+  if (half == 0) newt_out[(size_t)b * N + n] = add_in != nullptr ? add_in[(size_t)b * N + n] + total : total;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1338,8 +1340,15 @@ int nws_phase_carry(const float* f0, const float* f0_up, int B, int T, double* c
 int nws_exciter_newt(const NwsWeights* w, const float* f0, const float* f0_up, const double* carry,
                      const float* phase_u, const float* rand_phase, const float* film, int B, int T,
                      float sample_rate, float* exciter_out, float* newt_out, void* stream) {
+  return nws_exciter_newt_add(w, f0, f0_up, carry, phase_u, rand_phase, film, nullptr, B, T, sample_rate, exciter_out, newt_out, stream);
+}
+
+int nws_exciter_newt_add(const NwsWeights* w, const float* f0, const float* f0_up, const double* carry,
+                         const float* phase_u, const float* rand_phase, const float* film, const float* add_in, int B, int T,
+                         float sample_rate, float* exciter_out, float* newt_out, void* stream) {
   if (!weights_ok(w) || (!f0 && !f0_up) || !carry || !phase_u || !rand_phase || B <= 0 || T <= 0) return NWS_ERR_BAD_ARG;
   if (!exciter_out && !newt_out) return NWS_ERR_BAD_ARG;
+  if (add_in && !newt_out) return NWS_ERR_BAD_ARG;
   if (B > 65535) return NWS_ERR_UNSUPPORTED;
   const dim3 grid(T, B);
   const size_t base = (sizeof(ExcLds) + 15) & ~size_t(15);
@@ -1358,7 +1367,7 @@ int nws_exciter_newt(const NwsWeights* w, const float* f0, const float* f0_up, c
         const dim3 g2((T + 1) / 2, B);
         const int opts = w->exciter_opts;
 #define NWS_HOT(O) exciter_newt_kernel<kModeLutPairsDiv6, 0, 2, O><<<g2, 512, base, st>>>( \
-            *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out)
+            *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out, nullptr, add_in)
         if (opts & NWS_EXCITER_VALU_FILM) NWS_HOT(0);
         else if (opts & NWS_EXCITER_ONE_TERM) NWS_HOT(kOptFilmMfma | kOptOneTerm);
         else if (opts & NWS_EXCITER_HYBRID_W) NWS_HOT(kOptFilmMfma | kOptHybrid | kOptHybridW);
@@ -1367,21 +1376,21 @@ int nws_exciter_newt(const NwsWeights* w, const float* f0, const float* f0_up, c
 #undef NWS_HOT
       } else if (w->lut_pairs != nullptr)
         exciter_newt_kernel<kModeLutPairs><<<grid, 256, base, st>>>(*w, f0, f0_up, carry, phase_u, rand_phase, film,
-                                                                    T, sample_rate, exciter_out, newt_out);
+                                                                    T, sample_rate, exciter_out, newt_out, nullptr, add_in);
       else
         exciter_newt_kernel<kModeLut><<<grid, 256, base, st>>>(*w, f0, f0_up, carry, phase_u, rand_phase, film, T,
-                                                               sample_rate, exciter_out, newt_out);
+                                                               sample_rate, exciter_out, newt_out, nullptr, add_in);
     } else {
       if (!w->shaper_w0 || !w->shaper_w2 || !w->shaper_w4 || !w->shaper_w6) return NWS_ERR_BAD_ARG;
       if (w->shaper_turns != nullptr && (w->exciter_opts & NWS_EXCITER_BANK_NOFRACT))
         exciter_newt_kernel<kModeExactBankNF><<<grid, 256, base + sizeof(BankLds), st>>>(
-            *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out, w->shaper_turns);
+            *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out, w->shaper_turns, add_in);
       else if (w->shaper_turns != nullptr)
         exciter_newt_kernel<kModeExactBank><<<grid, 256, base + sizeof(BankLds), st>>>(
-            *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out, w->shaper_turns);
+            *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out, w->shaper_turns, add_in);
       else
         exciter_newt_kernel<kModeExact><<<grid, 256, base + sizeof(ShaperLds), st>>>(
-            *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out);
+            *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out, nullptr, add_in);
     }
   }
   NWS_CHECK_LAUNCH();

@@ -53,7 +53,7 @@ size_t nws_forward_workspace_bytes(const NwsReverbPlan* plan, int B, int T) {
   total += aligned((size_t)B * T * NWS_HIDDEN * sizeof(float));     // gru_out
   total += aligned((size_t)B * T * NWS_FILM_CH * sizeof(float));    // film
   total += aligned((size_t)B * T * NWS_FIR_HALF * sizeof(float));   // fir (upper half-taps)
-  total += aligned((size_t)B * N * sizeof(float));                  // newt_out
+  total += aligned((size_t)B * N * sizeof(float));                  // noise branch (B, N)
   total += aligned((size_t)B * N * sizeof(float));                  // pre-reverb
   total += aligned(nws_reverb_workspace_bytes(plan, B));
   return total;
@@ -65,7 +65,7 @@ namespace {
 
 struct Arena {
   double* carry;
-  float *gru_out, *film, *fir, *newt_out, *pre;
+  float *gru_out, *film, *fir, *noise_out, *pre;
   void* rv_ws;
   size_t rv_bytes;
   bool ok;
@@ -82,7 +82,7 @@ Arena carve_arena(const NwsReverbPlan* plan, void* workspace, size_t bytes, int 
   if (!head_only) {
     a.film = static_cast<float*>(cv.take((size_t)B * T * NWS_FILM_CH * sizeof(float)));
     a.fir = static_cast<float*>(cv.take((size_t)B * T * NWS_FIR_HALF * sizeof(float)));
-    a.newt_out = static_cast<float*>(cv.take((size_t)B * N * sizeof(float)));
+    a.noise_out = static_cast<float*>(cv.take((size_t)B * N * sizeof(float)));
     a.pre = static_cast<float*>(cv.take((size_t)B * N * sizeof(float)));
     a.rv_bytes = nws_reverb_workspace_bytes(plan, B);
     a.rv_ws = cv.take(a.rv_bytes);
@@ -123,16 +123,19 @@ int audio_half(const NwsWeights* w, const NwsForwardAux* aux, const float* f0, i
   int rc = NWS_OK;
   const size_t N = (size_t)T * NWS_HOP;
   NWS_STAGE(2, nws_frame_mlps(w, a.gru_out, aux->fir_design, B, T, nullptr, a.film, nullptr, a.fir, stream));
+  // the noise branch first (its output starts the NEWT sum), then the oscillator kernel adds its own sum on top and leaves
+  // pre = newt + noise (models/neural_waveshaping.py:77-81; a + b in either order is the same fp32 sum): the FIR-noise kernel
+  // neither reads the other branch nor waits for the chain of exciter events
+  NWS_STAGE(4, nws_fir_noise(a.fir, noise, nullptr, B, T, a.noise_out, stream));
   if (wait_before_exciter != nullptr) {
     const hipError_t e = hipStreamWaitEvent(st, (hipEvent_t)wait_before_exciter, 0);
     if (e != hipSuccess) return (int)e;
   }
-  NWS_STAGE(3, nws_exciter_newt(w, f0, nullptr, a.carry, phase_u, rand_phase, a.film, B, T, sample_rate, nullptr, a.newt_out, stream));
+  NWS_STAGE(3, nws_exciter_newt_add(w, f0, nullptr, a.carry, phase_u, rand_phase, a.film, a.noise_out, B, T, sample_rate, nullptr, a.pre, stream));
   if (record_after_exciter != nullptr) {
     const hipError_t e = hipEventRecord((hipEvent_t)record_after_exciter, st);
     if (e != hipSuccess) return (int)e;
   }
-  NWS_STAGE(4, nws_fir_noise(a.fir, noise, a.newt_out, B, T, a.pre, stream));
   if (with_reverb)
     NWS_STAGE(5, nws_reverb(aux->plan, aux->reverb_tables, aux->reverb_spectrum, a.pre, B, (int)N, out, a.rv_ws, a.rv_bytes, stream));
   if (g_prof.ev != nullptr && g_prof.used < g_prof.slots) ++g_prof.used;
