@@ -11,6 +11,7 @@
 // a private array with a runtime value (that would become scratch memory, which the build refuses): per-thread vectors of
 // runtime length live in LDS.
 #include <stdlib.h>
+#include <string.h>
 
 #include "nws_common.h"
 
@@ -159,6 +160,8 @@ __global__ __launch_bounds__(16 * KQ) void g_gru_q_kernel(const float* __restric
   for (int i = tid; i < 2 * 4 * KQ; i += blockDim.x) hbuf[i] = (i < H && h0) ? h0[(size_t)b * H + i] : 0.0f;
   for (int i = tid; i < 3 * H * C_in; i += blockDim.x) wih[i] = w_ih[i];
   if (tid < C_in) xs[tid] = control[((size_t)b * C_total + tid) * T];
+  // frame t + 2 travels from memory while step t runs and reaches LDS during step t + 1: no load latency inside a step
+  float xnext = (tid < C_in && T > 1) ? control[((size_t)b * C_total + tid) * T + 1] : 0.0f;
   // this lane's input-projection gate (q = 0, 1, 2: r, z, n) and the recurrent biases
   const int grow = (q < 3 ? q : 0) * H + (unit ? j : 0);
   const float bi = b_ih[grow];
@@ -168,7 +171,10 @@ __global__ __launch_bounds__(16 * KQ) void g_gru_q_kernel(const float* __restric
   for (int t = 0; t < T; ++t) {
     const float* hp = hbuf + cur * 4 * KQ;
     const float* xc = xs + (t & 1) * C_in;
-    if (tid < C_in && t + 1 < T) xs[((t + 1) & 1) * C_in + tid] = control[((size_t)b * C_total + tid) * T + t + 1];
+    if (tid < C_in && t + 1 < T) {
+      xs[((t + 1) & 1) * C_in + tid] = xnext;
+      if (t + 2 < T) xnext = control[((size_t)b * C_total + tid) * T + t + 2];
+    }
     float pr = 0.0f, pz = 0.0f, pn = 0.0f;
 #pragma unroll
     for (int i4 = 0; i4 < KQ; i4 += 4) {
@@ -184,15 +190,21 @@ __global__ __launch_bounds__(16 * KQ) void g_gru_q_kernel(const float* __restric
     pz += q == 1 ? ig : 0.0f;
     const float in_n = g_quad_perm<0xAA>(ig);     // quad_perm [2, 2, 2, 2]: the n gate's input part, kept apart
     const float sr = g_quad_sum(pr) + bhr, sz = g_quad_sum(pz) + bhz, sn = g_quad_sum(pn) + bhn;
-    const float r = 1.0f / (1.0f + expf(-sr));
-    const float z = 1.0f / (1.0f + expf(-sz));
-    const float nn = tanhf(in_n + r * sn);
-    const float hv = (1.0f - z) * nn + z * hp[unit ? j : 0];
+    // sigmoid(x) = 1 / (1 + 2^(-x log2 e)); tanh(x) = 1 - 2 / (1 + 2^(2 x log2 e)) on v_exp_f32 / v_rcp_f32 (~1 ulp each, the
+    // error class of the libm forms inside torch's CPU GRU); h' = [z h + (1 - z)] - 2 (1 - z) / (1 + 2^..): n is never rounded
+    // at magnitude 1 (control_gru.hip: 1.9e-5 against a float64 GRU over 500 steps where "(1 - z) n + z h" gave 5.3e-5)
+    const float kL2E = 1.4426950408889634f;
+    const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kL2E * sr));
+    const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kL2E * sz));
+    const float omz = 1.0f - z;
+    const float base = fmaf(z, hp[unit ? j : 0], omz);
+    const float hv = fmaf(-2.0f * omz, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.0f * kL2E * (in_n + r * sn))), base);
     if (unit && q == 0) {
       hbuf[(cur ^ 1) * 4 * KQ + j] = hv;
       out[((size_t)b * T + t) * H + j] = hv;
     }
-    __syncthreads();
+    // LDS-only barrier: the store of h and the load of frame t + 2 stay in flight across it
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     cur ^= 1;
   }
   if (hT && unit && q == 0) hT[(size_t)b * H + j] = hbuf[cur * 4 * KQ + j];
@@ -389,8 +401,43 @@ __global__ __launch_bounds__(128) void g_shaper_table_kernel(GShaper P, int size
   if (i < size) table[(size_t)s * size + i] = v;
 }
 
+// the sin-MLP of one (sample, shaper) with the hidden activations in registers: compile-time width W (4 / 8 / 16), run-time
+// depth; the shaper index is workgroup-uniform, so every weight is a scalar operand.  Sines through the v_sin_f32 reduction of
+// nws_sin_turns (2.4e-7 absolute, against 1.5e-7 for the polynomial nws_sinf that the table construction keeps).
+template <int W>
+__device__ __forceinline__ float g_exact_shaper_reg(const GShaper& P, int s, float x) {
+  const float a = P.in_scale[s] * x;
+  float h[W], g[W];
+  {
+    const float* w0 = P.w[0] + (size_t)s * W;
+    const float* b0 = P.b[0] + (size_t)s * W;
+#pragma unroll
+    for (int j = 0; j < W; ++j) h[j] = nws_sinf_fast(fmaf(w0[j], a, b0[j]));
+  }
+  for (int layer = 1; layer < P.depth - 1; ++layer) {
+    const float* wl = P.w[layer] + (size_t)s * W * W;
+    const float* bl = P.b[layer] + (size_t)s * W;
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+      float acc = bl[i];
+#pragma unroll
+      for (int j = 0; j < W; ++j) acc = fmaf(wl[i * W + j], h[j], acc);
+      g[i] = nws_sinf_fast(acc);
+    }
+#pragma unroll
+    for (int i = 0; i < W; ++i) h[i] = g[i];
+  }
+  const float* wl = P.w[P.depth - 1] + (size_t)s * W;
+  float acc = P.b[P.depth - 1][s];
+#pragma unroll
+  for (int j = 0; j < W; ++j) acc = fmaf(wl[j], h[j], acc);
+  return nws_sinf_fast(acc);
+}
+
 // NEWT.forward up to the mixer (shaping.py:68-76): film (B, 4S, T) channel-major, upsampled xhop on the fly;
 // v[b][s][n] = g_norm * shaper_s(g_idx * e + b_idx) + b_norm   (FiLM: multiply then add, two roundings, dynamic.py:8)
+// W = the sin-MLP's width when it is 4 / 8 / 16 and depth >= 2 (registers), 0 = any width (LDS columns) or table shapers
+template <int W>
 __global__ __launch_bounds__(128) void g_film_shaper_kernel(GShaper P, const float* __restrict__ exciter,
                                                             const float* __restrict__ film, int T, int N, float scale,
                                                             float* __restrict__ out) {
@@ -403,7 +450,9 @@ __global__ __launch_bounds__(128) void g_film_shaper_kernel(GShaper P, const flo
     auto lerp = [&](int ch) { return fmaf(lc.w0, fb[(size_t)ch * T + lc.i0], lc.w1 * fb[(size_t)ch * T + lc.i1]); };
     const float g_i = lerp(s), b_i = lerp(S + s), g_n = lerp(2 * S + s), b_n = lerp(3 * S + s);
     const float x = g_i * exciter[((size_t)b * S + s) * N + n] + b_i;
-    const float sh = P.lut ? g_lut_shaper(P, s, x) : g_exact_shaper(P, s, x, hb, threadIdx.x, 128);
+    float sh;
+    if (W > 0) sh = g_exact_shaper_reg<(W > 0 ? W : 4)>(P, s, x);
+    else sh = P.lut ? g_lut_shaper(P, s, x) : g_exact_shaper(P, s, x, hb, threadIdx.x, 128);
     out[((size_t)b * S + s) * N + n] = g_n * sh + b_n;
   }
 }
@@ -502,6 +551,249 @@ __global__ __launch_bounds__(256) void g_exciter_newt_kernel(GShaper P, const fl
   }
 }
 
+// The same with the harmonic mixer on the matrix pipe (v_mfma_f32_32x32x2_f32: fp32 products and sums, any K / S <= 64): rows =
+// 32 shapers (A = mixer weights, K-major in LDS, zero padded), columns = 32 samples (B = the oscillator bank: every lane
+// computes ONE sine per MFMA - harmonic 2 s + lane / 32 + 1 of sample lane % 32 - so the bank is evaluated exactly once).  The
+// accumulators come out lane = sample, register = shaper: FiLM, table shapers and the NEWT mixer run on them in place, the two
+// lane halves (16 MT shapers each) meet in one cross-half add per output channel.  A wave walks `tpw` tiles of 32 samples; the
+// 6464 FMAs per sample of the thread-per-sample kernel above are what this removes (1.17 -> see LABBOOK at B = 64, defaults).
+typedef float gfloat16 __attribute__((ext_vector_type(16)));
+
+// table (S, size) -> pairs (SBM, size): (v[i], v[min(i + 1, size - 1)] - v[i]) - the two gathers and the difference of
+// FastNEWT.shaping_fn's interpolation (shaping.py:147-151) as one 8-byte load; rows beyond S are zero
+__global__ void g_lut_pairs_kernel(const float* __restrict__ lut, int S, int size, int SBM, float2* __restrict__ pairs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= SBM * size) return;
+  const int c = i / size, j = i - c * size;
+  float2 v{0.0f, 0.0f};
+  if (c < S) {
+    const float lo = lut[(size_t)c * size + j], up = lut[(size_t)c * size + (j + 1 < size ? j + 1 : size - 1)];
+    v = float2{lo, up - lo};
+  }
+  pairs[i] = v;
+}
+
+typedef _Float16 gf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 gf16x2 __attribute__((ext_vector_type(2)));
+
+// Mixer weights (S, K) -> A fragments of v_mfma_f32_32x32x16_f16 as two fp16 terms (hi + lo = 22 bits), scaled by a power of
+// two that brings max |w| into [1, 2) (any weight magnitude stays inside fp16's range; the kernel multiplies the sums by the
+// exact inverse).  Layout [step][mt][hi | lo][lane] x 16 B: lane l holds row 32 mt + l % 32, harmonics 16 step + 8 (l / 32)
+// + 0..7; zero beyond S / K.  scl[0] = scale, scl[1] = 1 / scale.  One workgroup (the table is 28 KB at the default sizes).
+__global__ __launch_bounds__(256) void g_mixer_frag_kernel(const float* __restrict__ w, int S, int K, int MT, gf16x8* __restrict__ frag,
+                                                           float* __restrict__ scl) {
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  float mx = 0.0f;
+  for (int i = tid; i < S * K; i += 256) {
+    const float a = fabsf(w[i]);
+    mx = (a <= 3.0e38f && a > mx) ? a : mx;          // finite maximum (NaN / inf weights give NaN / inf sums whatever the scale)
+  }
+  red[tid] = mx;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) red[tid] = fmaxf(red[tid], red[tid + off]);
+    __syncthreads();
+  }
+  mx = red[0];
+  int e = 1;
+  if (mx > 0.0f) (void)frexpf(mx, &e);               // mx = f 2^e, f in [0.5, 1)
+  const float scale = ldexpf(1.0f, 1 - e), inv = ldexpf(1.0f, e - 1);
+  if (tid == 0) {
+    scl[0] = scale;
+    scl[1] = inv;
+  }
+  const int K16 = (K + 15) / 16;
+  for (int idx = tid; idx < K16 * MT * 64; idx += 256) {
+    const int lane = idx & 63, mt = (idx >> 6) % MT, st = idx / (64 * MT);
+    const int row = 32 * mt + (lane & 31), k0 = 16 * st + 8 * (lane >> 5);
+    gf16x8 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float v = (row < S && k0 + i < K) ? w[(size_t)row * K + k0 + i] * scale : 0.0f;
+      const _Float16 h = (_Float16)v;
+      hi[i] = h;
+      lo[i] = (_Float16)(v - (float)h);
+    }
+    frag[((st * MT + mt) * 2 + 0) * 64 + lane] = hi;
+    frag[((st * MT + mt) * 2 + 1) * 64 + lane] = lo;
+  }
+}
+
+// fp32 pair -> fp16 (hi, lo) pairs: hi = the value cut to 11 significant bits (exact in fp16), lo = the rest rounded to fp16
+__device__ __forceinline__ void g_split2(float a, float b, gf16x2& hi, gf16x2& lo) {
+  const float ha = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & 0xFFFFE000u);
+  const float hb = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) & 0xFFFFE000u);
+  hi = __builtin_convertvector(f32x2{ha, hb}, gf16x2);
+  lo = __builtin_convertvector(f32x2{a - ha, b - hb}, gf16x2);
+}
+
+// one tile's mixer: acc (rows = shapers, columns = samples) += W x bank on v_mfma_f32_32x32x16_f16, both operands as two fp16
+// terms (hi hi + hi lo + lo hi: 22 bits, fp32 accumulation).  Every lane evaluates the 8 harmonics 16 step + 8 (lane / 32) +
+// 1..8 of its sample per step - the bank is computed exactly once.  WIDE = some lane's phase is beyond the v_sin_f32 reduction's
+// range (minutes of audio).  (Harmonics beyond K meet zero weights.)
+template <int MT, bool WIDE>
+__device__ __forceinline__ void g_mix_tile(gfloat16 (&acc)[MT], const gf16x8* fr, const float* sp, int K16, int half, float f0n,
+                                           float ph, float nyq) {
+  for (int st = 0; st < K16; ++st) {
+    const float4 sa = *reinterpret_cast<const float4*>(sp + 16 * st), sb = *reinterpret_cast<const float4*>(sp + 16 * st + 4);
+    const float sh[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+    const float kf0 = (float)(16 * st + 8 * half + 1);
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float kf = kf0 + (float)i;
+      const float arg = kf * ph + sh[i];                              // two roundings (-ffp-contract=off)
+      const float sv = WIDE ? nws_sin_wide(arg) : nws_sin_turns(arg);
+      v[i] = (f0n * kf) < nyq ? sv : 0.0f;
+    }
+    gf16x2 h0, l0, h1, l1, h2, l2, h3, l3;
+    g_split2(v[0], v[1], h0, l0);
+    g_split2(v[2], v[3], h1, l1);
+    g_split2(v[4], v[5], h2, l2);
+    g_split2(v[6], v[7], h3, l3);
+    const gf16x8 bhi = {h0.x, h0.y, h1.x, h1.y, h2.x, h2.y, h3.x, h3.y};
+    const gf16x8 blo = {l0.x, l0.y, l1.x, l1.y, l2.x, l2.y, l3.x, l3.y};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const gf16x8 ahi = fr[((st * MT + mt) * 2 + 0) * 64], alo = fr[((st * MT + mt) * 2 + 1) * 64];
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc[mt], 0, 0, 0);
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc[mt], 0, 0, 0);
+      acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc[mt], 0, 0, 0);
+    }
+  }
+}
+
+// OCT = NEWT output channels rounded up to 1 / 2 / 4 (0: stop at the exciter (B, S, N), the sin-MLP shapers follow in
+// g_film_shaper_kernel).  rdiv = fl(1 / (lut_max - lut_min)): the table index t / (max - min) as q0 = t * rdiv, one residual
+// and one correction FMA (Markstein's sequence: the correctly rounded quotient whenever rdiv is the correctly rounded
+// reciprocal - three instructions instead of the v_div_scale / v_div_fmas / v_div_fixup chain).  FiLM rows sit in LDS as
+// (x[f], x[f + 1] - x[f]) so that an interpolated parameter is one FMA (within an ulp of upsample_linear1d's w0 x0 + w1 x1).
+template <int MT, int OCT>
+__global__ __launch_bounds__(256, 2) void g_exciter_newt_mfma_kernel(GShaper P, const float* __restrict__ f0_up,
+                                                                     const float* __restrict__ phase, const float* __restrict__ phase_u,
+                                                                     const float* __restrict__ rand_phase, const gf16x8* __restrict__ frag,
+                                                                     const float* __restrict__ scl,
+                                                                     const float* __restrict__ mixer_b, const float* __restrict__ film,
+                                                                     const float* __restrict__ out_w, const float* __restrict__ out_b,
+                                                                     const float2* __restrict__ pairs, int K, int T, int N, float scale,
+                                                                     float sample_rate, int OC, int nf, int tpw, float rdiv,
+                                                                     float* __restrict__ out) {
+  constexpr int SBM = 32 * MT;
+  constexpr bool EXC_ONLY = OCT == 0;
+  extern __shared__ float lds[];
+  const int K16 = (K + 15) / 16;
+  gf16x8* wl = reinterpret_cast<gf16x8*>(lds);            // [K16][MT][hi | lo][64] mixer fragments
+  float* shift = lds + K16 * MT * 2 * 64 * 4;             // [16 K16]
+  float* mb = shift + 16 * K16;     // [SBM] mixer bias x scale
+  float* ow = mb + SBM;             // [4][SBM] NEWT mixer (zero rows / columns beyond OC / S)
+  float2* fl = reinterpret_cast<float2*>(ow + 4 * SBM);   // [nf][4][SBM] FiLM rows of the workgroup's frames (zero beyond S)
+  const int S = P.S;
+  const int b = blockIdx.z, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, col = lane & 31, half = lane >> 5;
+  const int n0 = blockIdx.x * (128 * tpw);
+  const int fa = g_lerp_coeff(n0, T, scale).i0;
+  for (int i = tid; i < K16 * MT * 2 * 64; i += 256) wl[i] = frag[i];
+  for (int k = tid; k < 16 * K16; k += 256) shift[k] = k < K ? phase_u[k] * rand_phase[k] - kPiF : 0.0f;     // generators.py:54-56
+  const float wscale = scl[0], winv = scl[1];
+  for (int c = tid; c < SBM; c += 256) mb[c] = c < S ? mixer_b[c] * wscale : 0.0f;
+  if (!EXC_ONLY) {
+    for (int i = tid; i < 4 * SBM; i += 256) {
+      const int j = i / SBM, c = i - j * SBM;
+      ow[i] = (j < OC && c < S) ? out_w[j * S + c] : 0.0f;
+    }
+    const float* fb = film + (size_t)b * 4 * S * T;
+    for (int i = tid; i < nf * 4 * SBM; i += 256) {
+      const int f = i / (4 * SBM), rc = i - f * (4 * SBM), row = rc / SBM, c = rc - row * SBM;
+      float2 v{0.0f, 0.0f};
+      if (c < S) {
+        const float* src = fb + (size_t)(row * S + c) * T;
+        const int t0 = fa + f < T ? fa + f : T - 1, t1 = t0 + 1 < T ? t0 + 1 : T - 1;
+        const float x0 = src[t0];
+        v = float2{x0, src[t1] - x0};
+      }
+      fl[i] = v;
+    }
+  }
+  __syncthreads();
+  const float nyq = sample_rate * 0.5f;
+  const float lsize = (float)P.lut_size, ltop = (float)(P.lut_size - 1), ldiv = P.lut_max - P.lut_min;
+  for (int tile = 0; tile < tpw; ++tile) {
+    const int nt = n0 + (wave * tpw + tile) * 32;
+    if (nt >= N) break;
+    const int n = nt + col;
+    const bool live = n < N;
+    const int nn = live ? n : N - 1;
+    const float f0n = f0_up[(size_t)b * N + nn], ph = phase[(size_t)b * N + nn];
+    // the lane's shapers: 32 mt + (r & 3) + 8 (r >> 2) + 4 half.  hsel is opaque so that the per-shaper addresses are NOT
+    // hoisted out of the tile loop as loop invariants (4 x 32 of them: registers); they are base + immediate instead
+    int hsel = 4 * half;
+    asm volatile("" : "+v"(hsel));
+    const float* mbp = mb + hsel;
+    gfloat16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][r] = mbp[32 * mt + (r & 3) + 8 * (r >> 2)];      // the mixer bias starts the sum
+    const bool wide = __any(fabsf(ph) * (float)(16 * K16 + 1) + 8.0f > 6.0e6f);
+    if (__builtin_expect(wide, 0))
+      g_mix_tile<MT, true>(acc, wl + lane, shift + 8 * half, K16, half, f0n, ph, nyq);
+    else
+      g_mix_tile<MT, false>(acc, wl + lane, shift + 8 * half, K16, half, f0n, ph, nyq);
+    if (EXC_ONLY) {
+      if (live) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = 32 * mt + (r & 3) + 8 * (r >> 2) + hsel;
+            if (c < S) out[((size_t)b * S + c) * N + n] = acc[mt][r] * winv;
+          }
+      }
+      continue;
+    }
+    const GLerp lc = g_lerp_coeff(nn, T, scale);
+    // (i1 == i0 only at the clamped last frame, where the staged difference is zero as well)
+    const float2* fp = fl + (lc.i0 - fa) * (4 * SBM) + hsel;
+    const float* owp = ow + hsel;
+    const unsigned hrow = (unsigned)hsel * (unsigned)P.lut_size;
+    float o[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        // (no branch on shaper < S: padded shapers have zero FiLM rows, zero table rows and zero NEWT-mixer weights, so a
+        // tile's table gathers stay in one basic block, in flight together)
+        const int cb = 32 * mt + (r & 3) + 8 * (r >> 2);
+        auto lerp = [&](int row) {
+          const float2 q = fp[row * SBM + cb];
+          return fmaf(lc.w1, q.y, q.x);
+        };
+        const float g_i = lerp(0), b_i = lerp(1), g_n = lerp(2), b_n = lerp(3);
+        const float x = g_i * (acc[mt][r] * winv) + b_i;
+        // FastNEWT.shaping_fn (shaping.py:136-151), g_lut_shaper's chain with the quotient as above
+        const float t = lsize * (x - P.lut_min);
+        const float q0 = t * rdiv;
+        const float idx = fmaf(fmaf(-ldiv, q0, t), rdiv, q0);
+        const float fi = __builtin_amdgcn_fmed3f(floorf(idx), 0.0f, ltop);
+        const float2 pr = (pairs + (size_t)cb * P.lut_size)[hrow + (unsigned)(int)fi];
+        const float sh = pr.y * (idx - fi) + pr.x;
+        const float v = g_n * sh + b_n;
+#pragma unroll
+        for (int j = 0; j < OCT; ++j) o[j] = fmaf(owp[j * SBM + cb], v, o[j]);
+        if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);     // eight shapers' gathers in flight at a time (registers)
+      }
+#pragma unroll
+    for (int j = 0; j < OCT; ++j) o[j] += __shfl_xor(o[j], 32);
+    if (live && half == 0) {
+      float* op = out + (size_t)b * OC * N + n;
+#pragma unroll
+      for (int j = 0; j < OCT; ++j)
+        if (j < OC) op[(size_t)j * N] = o[j] + out_b[j];
+    }
+  }
+}
+
 // ---- FIR noise (generators.py:21-35) for any ir_length L / hop --------------------------------------------------------
 // zero-phase FIR design: fir[b][t][n] = window[n] * roll(irfft(H[b, :, t]), L/2)[n]; irfft of a real half-spectrum as a
 // cosine sum (cos table of L entries in LDS, built in double)
@@ -564,6 +856,94 @@ __global__ __launch_bounds__(256) void g_fir_noise_kernel(const float* __restric
   if (add_in)
     for (int o = 0; o < O; ++o) v += add_in[((size_t)b * O + o) * N + n];
   out[(size_t)b * N + n] = v;
+}
+
+// The same on the matrix pipe.  Every utterance is filtered against the SAME noise frames (generators.py:30), so for an output
+// hop block h the sum over its covering frames t and taps k is one GEMM: rows = 32 utterances (A = taps[b][t][k]), columns =
+// 32 samples of the block (B = circulant of frame t: frame_t[(j - k) mod L], read from a doubled, reversed copy of the frame in
+// LDS so that consecutive k are consecutive addresses), accumulated over (t, k) in fp32 (v_mfma_f32_32x32x2_f32: products and
+// sums at fp32, any L / hop).  One workgroup per (hop block, 32 utterances); its four waves take the block's 32-sample column
+// tiles.  Columns of a frame past its L samples (L not a multiple of hop) are masked.
+constexpr int kFirTilesPerWave = 4;     // hop <= 4 waves x 4 tiles x 32 columns
+__global__ __launch_bounds__(256) void g_fir_noise_mfma_kernel(const float* __restrict__ fir, const float* __restrict__ noise,
+                                                               int M, int L, int hop, int T, int B,
+                                                               const float* __restrict__ add_in, int O, int N,
+                                                               float* __restrict__ out) {
+  extern __shared__ float lds[];        // taps[32][L + 1] | rv[2 L]: rv[i] = frame[(-i) mod L]
+  float* taps = lds;
+  float* rv = lds + 32 * (L + 1);
+  const int h = blockIdx.x, b0 = blockIdx.y * 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int ntile = (hop + 31) >> 5;
+  gfloat16 acc[kFirTilesPerWave];
+#pragma unroll
+  for (int i = 0; i < kFirTilesPerWave; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+  for (int t = h; t >= 0 && hop * t + L > hop * h; --t) {
+    __syncthreads();                    // the previous frame's operands are no longer read
+    for (int r = wave; r < 32; r += 4) {
+      const int b = b0 + r;
+      const float* src = fir + ((size_t)(b < B ? b : B - 1) * T + t) * L;
+      for (int k = lane; k < L; k += 64) taps[r * (L + 1) + k] = b < B ? src[k] : 0.0f;
+    }
+    const int base = hop * t - L / 2;   // frame_t[i] = noise[reflect(base + i)]
+    for (int i = threadIdx.x; i < L; i += 256) {
+      int p = base + i;
+      if (p < 0) p = -p;
+      if (p >= M) p = 2 * (M - 1) - p;
+      const float v = noise[p];
+      const int q = i == 0 ? 0 : L - i;
+      rv[q] = v;
+      rv[q + L] = v;
+    }
+    __syncthreads();
+    const int joff = hop * (h - t);     // position of the block's first sample inside frame t
+    const float* ap = taps + col * (L + 1) + half;
+#pragma unroll
+    for (int i = 0; i < kFirTilesPerWave; ++i) {
+      const int tile = wave + 4 * i;
+      if (tile < ntile) {
+        const int j = joff + tile * 32 + col;
+        if (joff + tile * 32 < L) {     // wave-uniform: the tile has at least one live column
+          const bool live = j < L;
+          const float* bp = rv + (L - (live ? j : L - 1)) + half;       // rv[k - j + L], k = 2 s + half
+          gfloat16 a = acc[i];
+#pragma unroll 8
+          for (int s = 0; s < L / 2; ++s) {
+            const float av = ap[2 * s];
+            float bv = bp[2 * s];
+            bv = live ? bv : 0.0f;
+            a = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, a, 0, 0, 0);
+          }
+          acc[i] = a;
+        }
+      }
+    }
+  }
+  // epilogue: divide by the number of covering frames, add the other branch's channels, store (lane = sample, register = row)
+#pragma unroll
+  for (int i = 0; i < kFirTilesPerWave; ++i) {
+    const int tile = wave + 4 * i;
+    const int jj = tile * 32 + col;
+    if (tile < ntile && jj < hop) {
+      const int n = hop * h + jj;
+      int count = 0;
+      for (int t = h; t >= 0 && hop * t + L > n; --t) ++count;
+      const float inv = (float)count;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int b = b0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (b < B) {
+          float v = acc[i][r] / inv;
+          if (add_in)
+            for (int o = 0; o < O; ++o) v += add_in[((size_t)b * O + o) * N + n];
+          out[(size_t)b * N + n] = v;
+        }
+      }
+    }
+  }
 }
 
 // ---- reverb, time-domain form for lengths the four-step FFT plan does not factor (shaping.py:161-173) -------------------
@@ -817,12 +1197,21 @@ int nws_g_film_shaper(const NwsShaperDesc* d, const float* exciter, const float*
   if (B > 65535 || d->n_shapers > 65535) return NWS_ERR_UNSUPPORTED;
   const size_t lds = shaper_lds(d);
   if (lds > 160 * 1024) return NWS_ERR_UNSUPPORTED;
-  static unsigned long long attr = 0;
-  if (int rc = ensure_lds(reinterpret_cast<const void*>(g_film_shaper_kernel), attr)) return rc;
   const int N = T * hop;
   const int gx = (N + 127) / 128 < 2048 ? (N + 127) / 128 : 2048;
-  g_film_shaper_kernel<<<dim3(gx, d->n_shapers, B), 128, lds, (hipStream_t)stream>>>(to_dev(d), exciter, film, T, N,
-                                                                                     (float)T / (float)N, out);
+  const dim3 grid(gx, d->n_shapers, B);
+  const int w = (!d->lut && d->depth >= 2) ? d->width : 0;
+  if (w == 4)
+    g_film_shaper_kernel<4><<<grid, 128, 0, (hipStream_t)stream>>>(to_dev(d), exciter, film, T, N, (float)T / (float)N, out);
+  else if (w == 8)
+    g_film_shaper_kernel<8><<<grid, 128, 0, (hipStream_t)stream>>>(to_dev(d), exciter, film, T, N, (float)T / (float)N, out);
+  else if (w == 16)
+    g_film_shaper_kernel<16><<<grid, 128, 0, (hipStream_t)stream>>>(to_dev(d), exciter, film, T, N, (float)T / (float)N, out);
+  else {
+    static unsigned long long attr = 0;
+    if (int rc = ensure_lds(reinterpret_cast<const void*>(g_film_shaper_kernel<0>), attr)) return rc;
+    g_film_shaper_kernel<0><<<grid, 128, lds, (hipStream_t)stream>>>(to_dev(d), exciter, film, T, N, (float)T / (float)N, out);
+  }
   NWS_CHECK_LAUNCH();
   return NWS_OK;
 }
@@ -847,6 +1236,18 @@ int nws_g_fir_noise(const float* fir, const float* noise, int fir_len, int hop, 
   // fir_len / 2 < hop*T - 1
   const long long N = (long long)T * hop;
   if (fir_len < hop || fir_len / 2 >= N - 1 || B > 65535) return NWS_ERR_UNSUPPORTED;
+  // matrix-pipe form (rows = utterances, shared noise circulant) when the tap tile fits LDS and a wave's column tiles its
+  // registers; NWS_G_FIR=valu keeps the per-sample kernel
+  static const bool valu_only = [] { const char* e = getenv("NWS_G_FIR"); return e && !strcmp(e, "valu"); }();
+  const size_t lds = ((size_t)32 * (fir_len + 1) + 2 * (size_t)fir_len) * sizeof(float);
+  if (!valu_only && lds <= 160 * 1024 && hop <= 128 * kFirTilesPerWave) {
+    static unsigned long long attr = 0;
+    if (int rc = ensure_lds(reinterpret_cast<const void*>(g_fir_noise_mfma_kernel), attr)) return rc;
+    g_fir_noise_mfma_kernel<<<dim3(T, (B + 31) / 32), 256, lds, (hipStream_t)stream>>>(fir, noise, (int)N - 1, fir_len, hop, T, B,
+                                                                                       add_in, add_channels, (int)N, out);
+    NWS_CHECK_LAUNCH();
+    return NWS_OK;
+  }
   g_fir_noise_kernel<<<dim3((unsigned)((N + 255) / 256), B), 256, 0, (hipStream_t)stream>>>(fir, noise, (int)N - 1, fir_len, hop,
                                                                                             T, add_in, add_channels, (int)N, out);
   NWS_CHECK_LAUNCH();
@@ -897,8 +1298,13 @@ static bool model_ok(const NwsGenericModel* m) {
   return shaper_ok(&m->shaper) && m->shaper.n_shapers == m->n_shapers;
 }
 
+// mixer fragments or transposed mixer (<= (K + 16) x 64) + scale + table pairs (64 x lut_size x 2) of g_exciter_newt_fused
+static size_t g_tab_floats(const NwsGenericModel* m) {
+  return ((size_t)m->n_harmonics + 16) * 64 + 4 + (m->shaper.lut ? (size_t)128 * m->shaper.lut_size : 0);
+}
+
 struct GArena {
-  float *gru_bth, *gru_bht, *emb, *film, *H, *fir, *f0_up, *phase, *osc, *exciter, *shaped, *newt, *pre;
+  float *gru_bth, *gru_bht, *emb, *film, *H, *fir, *f0_up, *phase, *osc, *exciter, *shaped, *newt, *pre, *tab;
   void* gru_ws;
   size_t gru_ws_bytes;
   bool ok;
@@ -938,29 +1344,75 @@ static GArena g_carve(const NwsGenericModel* m, int B, int T, void* ws, size_t b
   if (m->n_shapers > m->n_harmonics) a.shaped = fl((size_t)B * m->n_shapers * N);
   a.newt = fl((size_t)B * m->out_channels * N);
   a.pre = fl((size_t)B * N);
+  a.tab = fl(g_tab_floats(m));
   a.ok = ok;
   return a;
 }
 
 // launch of g_exciter_newt_kernel; NWS_ERR_UNSUPPORTED when the sizes do not fit it (the caller runs the stage kernels).
-// `scratch` >= K * 64 floats (the oscillator-bank region of the arena, unused on this route) receives the transposed mixer.
+// `scratch` (g_tab_floats: its own region of the arena) receives the transposed mixer and the table pairs.
 static int g_exciter_newt_fused(const NwsGenericModel* m, const float* f0_up, const float* phase, const float* phase_u,
                                 const float* rand_phase, const float* film, int B, int T, int N, float sample_rate, float* scratch,
                                 float* newt_out, float* exciter_out, float* shaped, void* stream) {
   const int S = m->n_shapers, K = m->n_harmonics, OC = m->out_channels;
   if (S > 64 || OC > 4 || B > 65535 || getenv("NWS_G_STAGES")) return NWS_ERR_UNSUPPORTED;
   const bool exc_only = m->shaper.lut == nullptr;     // sin-MLP shapers: see EXC_ONLY
+  hipStream_t st = (hipStream_t)stream;
+  const float scale = (float)T / (float)N;
+  const NwsShaperDesc* d = &m->shaper;
+  const GShaper P = to_dev(d);
+  static const bool valu_mixer = [] { const char* e = getenv("NWS_G_EXCITER"); return e && !strcmp(e, "valu"); }();
+  if (!valu_mixer) {
+    // matrix-pipe mixer: tiles of 32 samples, `tpw` per wave as long as the launch keeps >= 1024 workgroups
+    const int MT = S <= 32 ? 1 : 2, SBM = 32 * MT, K16 = (K + 15) / 16;
+    int tpw = 4;
+    while (tpw > 1 && (long long)((N + 128 * tpw - 1) / (128 * tpw)) * B < 1024) tpw >>= 1;
+    const int nf = 128 * tpw / m->hop + 3;
+    const size_t lds = ((size_t)K16 * MT * 512 + 16 * K16 + 5 * (size_t)SBM + (exc_only ? 0 : (size_t)8 * SBM * nf)) * sizeof(float);
+    if (lds <= 160 * 1024) {
+      // scratch: [fragments K16 x MT x 512 floats | scale, 1 / scale, pad | table pairs]
+      gf16x8* frag = reinterpret_cast<gf16x8*>(scratch);
+      float* scl = scratch + (size_t)K16 * MT * 512;
+      g_mixer_frag_kernel<<<1, 256, 0, st>>>(m->mixer_w, S, K, MT, frag, scl);
+      NWS_CHECK_LAUNCH();
+      float2* pairs = reinterpret_cast<float2*>(scl + 4);
+      if (!exc_only) {
+        g_lut_pairs_kernel<<<(SBM * P.lut_size + 255) / 256, 256, 0, st>>>(P.lut, S, P.lut_size, SBM, pairs);
+        NWS_CHECK_LAUNCH();
+      }
+      const dim3 grid((N + 128 * tpw - 1) / (128 * tpw), 1, B);
+#define NWS_G_EM(MTV, OCTV)                                                                                                        \
+  {                                                                                                                                \
+    static unsigned long long attr = 0;                                                                                            \
+    if (int rc = ensure_lds(reinterpret_cast<const void*>(g_exciter_newt_mfma_kernel<MTV, OCTV>), attr)) return rc;                \
+    g_exciter_newt_mfma_kernel<MTV, OCTV><<<grid, 256, lds, st>>>(P, f0_up, phase, phase_u, rand_phase, frag, scl, m->mixer_b, film, \
+                                                                  m->newt_out_w, m->newt_out_b, pairs, K, T, N, scale,             \
+                                                                  sample_rate, OC, nf, tpw, rdiv, OCTV == 0 ? exciter_out : newt_out); \
+  }
+      const int oct = exc_only ? 0 : OC == 1 ? 1 : OC == 2 ? 2 : 4;
+      const float rdiv = exc_only ? 0.0f : (float)(1.0 / (double)(P.lut_max - P.lut_min));
+      if (MT == 1) {
+        if (oct == 0) NWS_G_EM(1, 0) else if (oct == 1) NWS_G_EM(1, 1) else if (oct == 2) NWS_G_EM(1, 2) else NWS_G_EM(1, 4)
+      } else {
+        if (oct == 0) NWS_G_EM(2, 0) else if (oct == 1) NWS_G_EM(2, 1) else if (oct == 2) NWS_G_EM(2, 2) else NWS_G_EM(2, 4)
+      }
+#undef NWS_G_EM
+      NWS_CHECK_LAUNCH();
+      if (exc_only) {
+        int rc = nws_g_film_shaper(&m->shaper, exciter_out, film, B, T, m->hop, shaped, stream);
+        if (rc != NWS_OK) return rc;
+        return nws_g_conv1x1(shaped, m->newt_out_w, m->newt_out_b, B, S, OC, N, newt_out, stream);
+      }
+      return NWS_OK;
+    }
+  }
   const int SB = S <= 8 ? 8 : S <= 16 ? 16 : S <= 32 ? 32 : 64;
   const int nf = 256 / m->hop + 3;                  // frames 256 consecutive samples can touch (+ the clamped right neighbour)
-  const NwsShaperDesc* d = &m->shaper;
   const size_t lds = exc_only ? (size_t)K * sizeof(float) : ((size_t)K + (size_t)4 * S * nf) * sizeof(float);
   if (lds > 160 * 1024) return NWS_ERR_UNSUPPORTED;
-  hipStream_t st = (hipStream_t)stream;
   g_mixer_t_kernel<<<(K * SB + 255) / 256, 256, 0, st>>>(m->mixer_w, S, K, SB, scratch);
   NWS_CHECK_LAUNCH();
   const dim3 grid((N + 255) / 256, 1, B);
-  const float scale = (float)T / (float)N;
-  const GShaper P = to_dev(d);
 #define NWS_G_EN(SBV)                                                                                                              \
   {                                                                                                                                \
     static unsigned long long attr = 0;                                                                                            \
@@ -998,7 +1450,7 @@ size_t nws_forward_generic_workspace_bytes(const NwsGenericModel* m, int B, int 
   t += fb((size_t)B * T * (m->fir_len / 2 + 1)) + fb((size_t)B * T * m->fir_len) + 2 * fb((size_t)B * N);
   t += fb((size_t)B * m->n_harmonics * N) + fb((size_t)B * m->n_shapers * N);
   if (m->n_shapers > m->n_harmonics) t += fb((size_t)B * m->n_shapers * N);
-  t += fb((size_t)B * m->out_channels * N) + fb((size_t)B * N);
+  t += fb((size_t)B * m->out_channels * N) + fb((size_t)B * N) + fb(g_tab_floats(m));
   return t;
 }
 
@@ -1039,7 +1491,7 @@ int nws_forward_generic(const NwsGenericModel* m, const float* f0, const float* 
   // oscillator bank -> harmonic mixer -> FiLM / shapers -> NEWT mixer (generators.py:58-66, neural_waveshaping.py:64-67,
   // shaping.py:67-79): one kernel that keeps everything between the phase and the NEWT output in registers when the sizes allow
   // (<= 64 shapers, <= 4 output channels), the stage kernels otherwise
-  rc = g_exciter_newt_fused(m, a.f0_up, a.phase, phase_u, rand_phase, a.film, B, T, N, sample_rate, a.osc, a.newt, a.exciter, a.shaped, stream);
+  rc = g_exciter_newt_fused(m, a.f0_up, a.phase, phase_u, rand_phase, a.film, B, T, N, sample_rate, a.tab, a.newt, a.exciter, a.shaped, stream);
   if (rc == NWS_ERR_UNSUPPORTED) {
     G(nws_g_oscillator(a.f0_up, a.phase, phase_u, rand_phase, K, B, N, sample_rate, a.osc, stream));
     G(nws_g_conv1x1(a.osc, m->mixer_w, m->mixer_b, B, K, S, N, a.exciter, stream));

@@ -273,3 +273,47 @@ def test_random_gin_configurations_match_the_oracle(seed):
     finally:
         nws.gin.clear_config()
         nws.gin.parse_config_file(nws.DEFAULT_GIN)
+
+
+def _fir_noise_f64(fir, noise, hop):
+    """generators.py:24-35 for given taps, in float64: rectangular-window frames of the reflect-padded noise, L-point circular
+    convolution per frame, overlap-add divided by the number of covering frames, first hop*T samples."""
+    B, T, L = fir.shape
+    N = hop * T
+    pad = np.pad(noise.astype(np.float64), (L // 2, L // 2), mode="reflect")
+    acc = np.zeros((B, N + L))
+    cnt = np.zeros(N + L)
+    for t in range(T):
+        frame = pad[hop * t:hop * t + L]
+        y = np.fft.irfft(np.fft.rfft(fir[:, t].astype(np.float64), axis=-1) * np.fft.rfft(frame)[None], n=L, axis=-1)
+        acc[:, hop * t:hop * t + L] += y
+        cnt[hop * t:hop * t + L] += 1
+    return acc[:, :N] / cnt[:N]
+
+
+@pytest.mark.parametrize("L,hop,B,T", [(256, 128, 64, 9), (256, 128, 1, 5), (192, 128, 33, 6), (130, 40, 3, 11), (64, 64, 2, 7),
+                                       (1024, 160, 5, 4), (320, 100, 35, 5), (2048, 512, 2, 5), (600, 520, 2, 3)])
+def test_runtime_size_fir_noise_on_the_matrix_pipe(L, hop, B, T):
+    """nws_g_fir_noise: the fp32-MFMA form (rows = utterances against the shared noise circulant) over tap lengths that are /
+    are not multiples of the hop, hops that are not multiples of the 32-column tile, partial utterance tiles, the largest tap
+    tile LDS takes (L = 1024) and the two fall-backs to the per-sample kernel (L = 2048: LDS; hop = 520: registers) - against
+    the float64 overlap-add of the same taps, with and without the other branch's channels added."""
+    import nws_amd as nws
+    lib = nws._lib.lib()
+    g = torch.Generator().manual_seed(L + hop + B)
+    fir = (torch.rand(B, T, L, generator=g) - 0.5) * 0.1
+    noise = torch.rand(hop * T - 1, generator=g) * 2 - 1
+    add = torch.randn(B, 2, hop * T, generator=g)
+    ref = _fir_noise_f64(fir.numpy(), noise.numpy(), hop)
+    st = torch.cuda.current_stream().cuda_stream
+    fp = lambda t: t.data_ptr()    # noqa: E731  (device pointers travel as integers, _lib.py)
+    for with_add in (False, True):
+        d_fir, d_nz, d_add = fir.cuda(), noise.cuda(), add.cuda()
+        out = torch.full((B, hop * T), float("nan"), device="cuda")
+        rc = lib.nws_g_fir_noise(fp(d_fir), fp(d_nz), L, hop, B, T, fp(d_add) if with_add else None, 2 if with_add else 0, fp(out), st)
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        want = ref + (add.numpy().astype(np.float64).sum(1) if with_add else 0.0)
+        got = out.cpu().numpy()
+        assert np.isfinite(got).all()
+        assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max()), (with_add, np.abs(got - want).max())
