@@ -15,6 +15,8 @@
 
 #include "nws_common.h"
 
+typedef float gfloat16 __attribute__((ext_vector_type(16)));   // one 32x32 MFMA accumulator tile
+
 namespace {
 
 constexpr float kTauF = 6.283185307179586f;  // fl32(math.tau)
@@ -557,7 +559,6 @@ __global__ __launch_bounds__(256) void g_exciter_newt_kernel(GShaper P, const fl
 // accumulators come out lane = sample, register = shaper: FiLM, table shapers and the NEWT mixer run on them in place, the two
 // lane halves (16 MT shapers each) meet in one cross-half add per output channel.  A wave walks `tpw` tiles of 32 samples; the
 // 6464 FMAs per sample of the thread-per-sample kernel above are what this removes (1.17 -> see LABBOOK at B = 64, defaults).
-typedef float gfloat16 __attribute__((ext_vector_type(16)));
 
 // table (S, size) -> pairs (SBM, size): (v[i], v[min(i + 1, size - 1)] - v[i]) - the two gathers and the difference of
 // FastNEWT.shaping_fn's interpolation (shaping.py:147-151) as one 8-byte load; rows beyond S are zero
@@ -820,6 +821,59 @@ __global__ __launch_bounds__(256) void g_fir_design_kernel(const float* __restri
     float v = hs[0] + 2.0f * acc;
     v += (m & 1) ? -hs[L / 2] : hs[L / 2];
     fir[((size_t)b * T + t) * L + n] = window[n] * (v * inv);
+  }
+}
+
+// The same as ONE GEMM on the matrix pipe: fir (B T x L) = H^T (B T x L/2+1) x D, D[k][n] = window[n] c_k cos(2 pi k m(n) / L) / L
+// (c_0 = c_{L/2} = 1, else 2; m(n) = (n - L/2) mod L), built per call in double and rounded once.  v_mfma_f32_32x32x2_f32:
+// rows = 32 frames of one utterance (A = the H tile, staged channel-major in LDS), columns = 32 taps (B = D rows from L2), each
+// wave walks the K loop once for TWO column tiles; the accumulators leave as full 128 B segments of the frame-major tap rows.
+__global__ void g_fir_dmat_kernel(const float* __restrict__ window, int L, float* __restrict__ D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nb = L / 2 + 1;
+  if (i >= nb * L) return;
+  const int k = i / L, n = i - k * L;
+  const int m = (n + L - L / 2) % L;
+  const long long idx = ((long long)k * m) % L;
+  const double c = (k == 0 || k == L / 2) ? 1.0 : 2.0;
+  D[i] = (float)((double)window[n] * c * cospi(2.0 * (double)idx / (double)L) / (double)L);
+}
+
+__global__ __launch_bounds__(256) void g_fir_design_mfma_kernel(const float* __restrict__ H, const float* __restrict__ D, int L,
+                                                                int T, float* __restrict__ fir) {
+  extern __shared__ float hs[];          // [nb + 1][33]: hs[k][frame], one zero row of padding for odd nb
+  const int nb = L / 2 + 1, nbp = (nb + 1) & ~1;
+  const int b = blockIdx.y, t0 = blockIdx.x * 32;
+  const int f = threadIdx.x & 31, cg = threadIdx.x >> 5;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
+  for (int k = cg; k < nbp; k += 8) hs[k * 33 + f] = (k < nb && t0 + f < T) ? H[((size_t)b * nb + k) * T + t0 + f] : 0.0f;
+  __syncthreads();
+  const int ntile = (L + 31) / 32;
+  for (int nt = 2 * wave; nt < ntile; nt += 8) {
+    const int n0 = nt * 32 + col, n1 = n0 + 32;
+    const bool two = nt + 1 < ntile;
+    const float* d0 = D + (n0 < L ? n0 : L - 1);
+    const float* d1 = D + (n1 < L ? n1 : L - 1);
+    gfloat16 a0, a1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a0[r] = a1[r] = 0.0f;
+#pragma unroll 4
+    for (int k2 = 0; k2 < nbp; k2 += 2) {
+      const int k = k2 + half;
+      const int kc = k < nb ? k : nb - 1;                 // (the padded row of hs is zero)
+      const float hv = hs[k * 33 + col];
+      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(hv, d0[(size_t)kc * L], a0, 0, 0, 0);
+      if (two) a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(hv, d1[(size_t)kc * L], a1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (t < T) {
+        float* row = fir + ((size_t)b * T + t) * L;
+        if (n0 < L) row[n0] = a0[r];
+        if (two && n1 < L) row[n1] = a1[r];
+      }
+    }
   }
 }
 
@@ -1216,16 +1270,39 @@ int nws_g_film_shaper(const NwsShaperDesc* d, const float* exciter, const float*
   return NWS_OK;
 }
 
-int nws_g_fir_design(const float* H, const float* window, int fir_len, int B, int T, float* fir_out, void* stream) {
+// dmat: (fir_len / 2 + 1) x fir_len floats of scratch for the design matrix (NULL: stream-ordered allocation)
+static int g_fir_design_impl(const float* H, const float* window, int fir_len, int B, int T, float* fir_out, float* dmat,
+                             void* stream) {
   if (!H || !window || !fir_out || B <= 0 || T <= 0 || fir_len < 2 || (fir_len & 1)) return NWS_ERR_BAD_ARG;
   if (B > 65535) return NWS_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  static const bool valu_only = [] { const char* e = getenv("NWS_G_FIR"); return e && !strcmp(e, "valu"); }();
+  const int nb = fir_len / 2 + 1;
+  const size_t lds_mfma = (size_t)(nb + 1) * 33 * sizeof(float);
+  if (!valu_only && lds_mfma <= 160 * 1024) {
+    float* D = dmat;
+    if (!D && (hipMallocAsync(reinterpret_cast<void**>(&D), (size_t)nb * fir_len * sizeof(float), st) != hipSuccess || !D))
+      return NWS_ERR_WORKSPACE;
+    g_fir_dmat_kernel<<<(nb * fir_len + 255) / 256, 256, 0, st>>>(window, fir_len, D);
+    static unsigned long long attr = 0;
+    int rc = ensure_lds(reinterpret_cast<const void*>(g_fir_design_mfma_kernel), attr);
+    if (rc == NWS_OK) g_fir_design_mfma_kernel<<<dim3((T + 31) / 32, B), 256, lds_mfma, st>>>(H, D, fir_len, T, fir_out);
+    const hipError_t e = hipGetLastError();
+    if (!dmat) (void)hipFreeAsync(D, st);
+    if (rc != NWS_OK) return rc;
+    return e == hipSuccess ? NWS_OK : (int)e;
+  }
   const size_t lds = ((size_t)fir_len + fir_len / 2 + 1) * sizeof(float);
   if (lds > 160 * 1024) return NWS_ERR_UNSUPPORTED;
   static unsigned long long attr = 0;
   if (int rc = ensure_lds(reinterpret_cast<const void*>(g_fir_design_kernel), attr)) return rc;
-  g_fir_design_kernel<<<dim3(T, B), 256, lds, (hipStream_t)stream>>>(H, window, fir_len, T, fir_out);
+  g_fir_design_kernel<<<dim3(T, B), 256, lds, st>>>(H, window, fir_len, T, fir_out);
   NWS_CHECK_LAUNCH();
   return NWS_OK;
+}
+
+int nws_g_fir_design(const float* H, const float* window, int fir_len, int B, int T, float* fir_out, void* stream) {
+  return g_fir_design_impl(H, window, fir_len, B, T, fir_out, nullptr, stream);
 }
 
 int nws_g_fir_noise(const float* fir, const float* noise, int fir_len, int hop, int B, int T, const float* add_in,
@@ -1304,7 +1381,7 @@ static size_t g_tab_floats(const NwsGenericModel* m) {
 }
 
 struct GArena {
-  float *gru_bth, *gru_bht, *emb, *film, *H, *fir, *f0_up, *phase, *osc, *exciter, *shaped, *newt, *pre, *tab;
+  float *gru_bth, *gru_bht, *emb, *film, *H, *fir, *f0_up, *phase, *osc, *exciter, *shaped, *newt, *pre, *tab, *dmat;
   void* gru_ws;
   size_t gru_ws_bytes;
   bool ok;
@@ -1345,6 +1422,7 @@ static GArena g_carve(const NwsGenericModel* m, int B, int T, void* ws, size_t b
   a.newt = fl((size_t)B * m->out_channels * N);
   a.pre = fl((size_t)B * N);
   a.tab = fl(g_tab_floats(m));
+  a.dmat = fl((size_t)(m->fir_len / 2 + 1) * m->fir_len);
   a.ok = ok;
   return a;
 }
@@ -1451,6 +1529,7 @@ size_t nws_forward_generic_workspace_bytes(const NwsGenericModel* m, int B, int 
   t += fb((size_t)B * m->n_harmonics * N) + fb((size_t)B * m->n_shapers * N);
   if (m->n_shapers > m->n_harmonics) t += fb((size_t)B * m->n_shapers * N);
   t += fb((size_t)B * m->out_channels * N) + fb((size_t)B * N) + fb(g_tab_floats(m));
+  t += fb((size_t)(m->fir_len / 2 + 1) * m->fir_len);
   return t;
 }
 
@@ -1501,7 +1580,7 @@ int nws_forward_generic(const NwsGenericModel* m, const float* f0, const float* 
     return rc;
   }
   // noise branch + branch sum (generators.py:21-35, neural_waveshaping.py:82-86)
-  G(nws_g_fir_design(a.H, m->noise_window, m->fir_len, B, T, a.fir, stream));
+  G(g_fir_design_impl(a.H, m->noise_window, m->fir_len, B, T, a.fir, a.dmat, stream));
   G(nws_g_fir_noise(a.fir, noise, m->fir_len, m->hop, B, T, a.newt, m->out_channels, a.pre, stream));
   // reverb (shaping.py:161-173): four-step FFT when the circular length factors, time-domain form otherwise
   if (plan && reverb_tables && reverb_spectrum && reverb_workspace) {
