@@ -258,6 +258,81 @@ __global__ __launch_bounds__(1024) void g_phase_kernel(const float* __restrict__
   }
 }
 
+// The same for long rows in two parallel passes (the kernel above is one serial chain of N / 1024 double additions per
+// thread, twice, on ONE compute unit per utterance: 88 us at 4 s whatever the batch): workgroups of 4096 samples - their sums,
+// then per workgroup the sum of the partials before it + a block scan of 256 x 16 consecutive samples.  Same double sums.
+constexpr int kPhChunk = 4096, kPhPer = 16;
+__device__ __forceinline__ float g_f0_value(const float* __restrict__ x, const float* __restrict__ up, int n, int T, float scale) {
+  if (up) return up[n];
+  const GLerp L = g_lerp_coeff(n, T, scale);
+  return fmaf(L.w0, x[L.i0], L.w1 * x[L.i1]);
+}
+__device__ __forceinline__ double g_block_sum(double v, double* red) {      // 256 threads; the total in every thread
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double t = (red[0] + red[1]) + (red[2] + red[3]);
+  __syncthreads();
+  return t;
+}
+__global__ __launch_bounds__(256) void g_phase_sum_kernel(const float* __restrict__ f0, const float* __restrict__ f0_up_in, int T,
+                                                          int N, float scale, double* __restrict__ partial) {
+  __shared__ double red[4];
+  const int b = blockIdx.y, n0 = blockIdx.x * kPhChunk;
+  const float* x = f0 ? f0 + (size_t)b * T : nullptr;
+  const float* up = f0_up_in ? f0_up_in + (size_t)b * N : nullptr;
+  double s = 0.0;
+#pragma unroll 4
+  for (int i = 0; i < kPhPer; ++i) {
+    const int n = n0 + i * 256 + threadIdx.x;
+    if (n < N) s += (double)g_f0_value(x, up, n, T, scale);
+  }
+  s = g_block_sum(s, red);
+  if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void g_phase_scan_kernel(const float* __restrict__ f0, const float* __restrict__ f0_up_in, int T,
+                                                           int N, float scale, float sample_rate, const double* __restrict__ partial,
+                                                           float* __restrict__ f0_up_out, float* __restrict__ phase_out) {
+  __shared__ double red[4];
+  __shared__ double wtot[4];
+  const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+  const float* x = f0 ? f0 + (size_t)b * T : nullptr;
+  const float* up = f0_up_in ? f0_up_in + (size_t)b * N : nullptr;
+  double base = 0.0;
+  for (int j = tid; j < g; j += 256) base += partial[(size_t)b * gridDim.x + j];
+  base = g_block_sum(base, red);
+  const int n0 = g * kPhChunk + tid * kPhPer;
+  float v[kPhPer];
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < kPhPer; ++i) {
+    v[i] = n0 + i < N ? g_f0_value(x, up, n0 + i, T, scale) : 0.0f;
+    s += (double)v[i];
+  }
+  // exclusive scan of the 256 thread sums: inclusive scan inside each wave, wave totals through LDS
+  double inc = s;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double o = __shfl_up(inc, off);
+    if ((tid & 63) >= off) inc += o;
+  }
+  if ((tid & 63) == 63) wtot[tid >> 6] = inc;
+  __syncthreads();
+  double run = base + (inc - s);
+  for (int w = 0; w < (tid >> 6); ++w) run += wtot[w];
+#pragma unroll
+  for (int i = 0; i < kPhPer; ++i) {
+    if (n0 + i < N) {
+      run += (double)v[i];
+      const float c = (float)run;                         // torch's CPU cumsum: accumulate in double, round per element
+      const float tc = kTauF * c;                         // math.tau * cumsum      (one rounding)
+      phase_out[(size_t)b * N + n0 + i] = __fdiv_rn(tc, sample_rate);   // ... / sample_rate (true division)
+      if (f0_up_out) f0_up_out[(size_t)b * N + n0 + i] = v[i];
+    }
+  }
+}
+
 // ---- F.upsample(x, T*hop, mode="linear") on (rows, T) -> (rows, T*hop) (neural_waveshaping.py:75, shaping.py:69) -----------
 __global__ __launch_bounds__(256) void g_upsample_kernel(const float* __restrict__ x, int T, int N, float scale, float* __restrict__ y) {
   const size_t row = blockIdx.y;
@@ -1180,15 +1255,34 @@ int nws_g_bth_to_bht(const float* x, int B, int T, int H, float* y, void* stream
   return NWS_OK;
 }
 
-int nws_g_phase(const float* f0, const float* f0_up, int B, int T, int hop, float sample_rate, float* f0_up_out,
-                float* phase_out, void* stream) {
+// partial: B x ceil(N / 4096) doubles of scratch for the two-pass form (NULL: stream-ordered allocation)
+static size_t g_phase_partials(int B, long long N) { return (size_t)B * (size_t)((N + kPhChunk - 1) / kPhChunk); }
+static int g_phase_impl(const float* f0, const float* f0_up, int B, int T, int hop, float sample_rate, float* f0_up_out,
+                        float* phase_out, double* partial, void* stream) {
   if ((!f0) == (!f0_up) || !phase_out || B <= 0 || T <= 0 || hop <= 0 || !(sample_rate > 0.0f)) return NWS_ERR_BAD_ARG;
   const long long N = (long long)T * hop;     // f0_up given: T = N, hop = 1
   if (N > (1ll << 30)) return NWS_ERR_UNSUPPORTED;
   const float scale = (float)T / (float)N;
-  g_phase_kernel<<<B, 1024, 0, (hipStream_t)stream>>>(f0, f0_up, T, (int)N, scale, sample_rate, f0_up_out, phase_out);
-  NWS_CHECK_LAUNCH();
-  return NWS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const long long G = (N + kPhChunk - 1) / kPhChunk;
+  if (G < 2 || G > 65535 || B > 65535 || getenv("NWS_G_PHASE_SERIAL")) {      // short rows: one workgroup per utterance, one launch
+    g_phase_kernel<<<B, 1024, 0, st>>>(f0, f0_up, T, (int)N, scale, sample_rate, f0_up_out, phase_out);
+    NWS_CHECK_LAUNCH();
+    return NWS_OK;
+  }
+  double* P = partial;
+  if (!P && (hipMallocAsync(reinterpret_cast<void**>(&P), g_phase_partials(B, N) * sizeof(double), st) != hipSuccess || !P))
+    return NWS_ERR_WORKSPACE;
+  g_phase_sum_kernel<<<dim3((unsigned)G, B), 256, 0, st>>>(f0, f0_up, T, (int)N, scale, P);
+  g_phase_scan_kernel<<<dim3((unsigned)G, B), 256, 0, st>>>(f0, f0_up, T, (int)N, scale, sample_rate, P, f0_up_out, phase_out);
+  const hipError_t e = hipGetLastError();
+  if (!partial) (void)hipFreeAsync(P, st);
+  return e == hipSuccess ? NWS_OK : (int)e;
+}
+
+int nws_g_phase(const float* f0, const float* f0_up, int B, int T, int hop, float sample_rate, float* f0_up_out,
+                float* phase_out, void* stream) {
+  return g_phase_impl(f0, f0_up, B, T, hop, sample_rate, f0_up_out, phase_out, nullptr, stream);
 }
 
 int nws_g_upsample(const float* x, int64_t rows, int T, int hop, float* y, void* stream) {
@@ -1382,6 +1476,7 @@ static size_t g_tab_floats(const NwsGenericModel* m) {
 
 struct GArena {
   float *gru_bth, *gru_bht, *emb, *film, *H, *fir, *f0_up, *phase, *osc, *exciter, *shaped, *newt, *pre, *tab, *dmat;
+  double* partial;
   void* gru_ws;
   size_t gru_ws_bytes;
   bool ok;
@@ -1423,6 +1518,7 @@ static GArena g_carve(const NwsGenericModel* m, int B, int T, void* ws, size_t b
   a.pre = fl((size_t)B * N);
   a.tab = fl(g_tab_floats(m));
   a.dmat = fl((size_t)(m->fir_len / 2 + 1) * m->fir_len);
+  a.partial = static_cast<double*>(take(g_phase_partials(B, (long long)N) * sizeof(double)));
   a.ok = ok;
   return a;
 }
@@ -1529,7 +1625,7 @@ size_t nws_forward_generic_workspace_bytes(const NwsGenericModel* m, int B, int 
   t += fb((size_t)B * m->n_harmonics * N) + fb((size_t)B * m->n_shapers * N);
   if (m->n_shapers > m->n_harmonics) t += fb((size_t)B * m->n_shapers * N);
   t += fb((size_t)B * m->out_channels * N) + fb((size_t)B * N) + fb(g_tab_floats(m));
-  t += fb((size_t)(m->fir_len / 2 + 1) * m->fir_len);
+  t += fb((size_t)(m->fir_len / 2 + 1) * m->fir_len) + al(g_phase_partials(B, (long long)N) * sizeof(double));
   return t;
 }
 
@@ -1566,7 +1662,7 @@ int nws_forward_generic(const NwsGenericModel* m, const float* f0, const float* 
   G(nws_td_mlp(a.emb, B, m->embedding, m->hgen_hidden, nb, m->hgen_depth, T, m->hgen_w, m->hgen_b, m->hgen_ln_g, m->hgen_ln_b,
                m->ln_eps, m->leaky_slope, a.H, stream));
   // exciter (neural_waveshaping.py:75-76, :64-67)
-  G(nws_g_phase(f0, nullptr, B, T, m->hop, sample_rate, a.f0_up, a.phase, stream));
+  G(g_phase_impl(f0, nullptr, B, T, m->hop, sample_rate, a.f0_up, a.phase, a.partial, stream));
   // oscillator bank -> harmonic mixer -> FiLM / shapers -> NEWT mixer (generators.py:58-66, neural_waveshaping.py:64-67,
   // shaping.py:67-79): one kernel that keeps everything between the phase and the NEWT output in registers when the sizes allow
   // (<= 64 shapers, <= 4 output channels), the stage kernels otherwise

@@ -317,3 +317,40 @@ def test_runtime_size_fir_noise_on_the_matrix_pipe(L, hop, B, T):
         got = out.cpu().numpy()
         assert np.isfinite(got).all()
         assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max()), (with_add, np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("B,T,hop", [(3, 77, 128), (2, 500, 128), (1, 131, 100)])
+def test_two_pass_phase_equals_the_serial_kernel(B, T, hop):
+    """nws_g_phase: rows of more than 8192 samples take two parallel passes (chunk sums, then a block scan on top of the sums
+    before the chunk); sums of fp32 values in double are exact at these sizes, so the result must equal the one-workgroup
+    kernel's bit for bit - and both the float64 restatement of generators.py:59 (cumsum in double, rounded per element,
+    times tau, divided by the sample rate)."""
+    import os
+    import nws_amd as nws
+    lib = nws._lib.lib()
+    g = torch.Generator().manual_seed(B * T)
+    f0 = (60.0 + 700.0 * torch.rand(B, T, generator=g)).cuda()
+    N = T * hop
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for serial in (False, True):
+        if serial:
+            os.environ["NWS_G_PHASE_SERIAL"] = "1"
+        try:
+            up = torch.full((B, N), float("nan"), device="cuda")
+            ph = torch.full((B, N), float("nan"), device="cuda")
+            assert lib.nws_g_phase(f0.data_ptr(), None, B, T, hop, 16000.0, up.data_ptr(), ph.data_ptr(), st) == 0
+            torch.cuda.synchronize()
+            ph2 = torch.full((B, N), float("nan"), device="cuda")          # the f0_up entry (T = N, hop = 1)
+            assert lib.nws_g_phase(None, up.data_ptr(), B, N, 1, 16000.0, None, ph2.data_ptr(), st) == 0
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("NWS_G_PHASE_SERIAL", None)
+        assert torch.equal(ph, ph2)
+        outs.append((up.cpu(), ph.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    up_ref = torch.nn.functional.interpolate(f0.cpu()[:, None], size=N, mode="linear")[:, 0]
+    assert torch.equal(outs[0][0], up_ref)
+    c = torch.cumsum(up_ref.double(), 1).float()
+    want = (np.float32(2 * np.pi) * c.numpy()) / np.float32(16000.0)
+    assert np.array_equal(outs[0][1].numpy(), want.astype(np.float32))
