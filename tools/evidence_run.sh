@@ -25,6 +25,7 @@ python tools/reverb_lengths.py > gpurun_out/ev/reverb_lengths.txt 2>&1
 MODES=1,2,258,514,770,1282 python tools/mlp_variants.py 64 500 48 500 32 500 128 500 > gpurun_out/ev/mlp_variants.txt 2>&1
 python tools/mlp_timeline.py > gpurun_out/ev/mlp_timeline.txt 2>&1
 python tools/generic_profile.py > gpurun_out/ev/generic_path.txt 2>&1
+bash tools/generic_kernels.sh 64 500 > gpurun_out/ev/generic_kernels.txt 2>&1
 bash tools/collect_profiles.sh ${ROUND:-r04} > gpurun_out/ev/collect.log 2>&1
 ls gpurun_out/prof_${ROUND:-r04} | head -30
 du -sh gpurun_out
