@@ -479,8 +479,13 @@ __global__ __launch_bounds__(128) void g_shaper_table_kernel(GShaper P, int size
 }
 
 // the sin-MLP of one (sample, shaper) with the hidden activations in registers: compile-time width W (4 / 8 / 16), run-time
-// depth; the shaper index is workgroup-uniform, so every weight is a scalar operand.  Sines through the v_sin_f32 reduction of
-// nws_sin_turns (2.4e-7 absolute, against 1.5e-7 for the polynomial nws_sinf that the table construction keeps).
+// depth; the shaper index is workgroup-uniform, so every weight is a scalar operand.  Sines as v_sin_f32(fract(x / 2 pi)) -
+// the form of the fused sin-MLP kernel (exciter_newt.hip bank_sin; there the 1 / 2 pi sits in the weights): the one rounding of
+// x / 2 pi is 6e-8 |x| / 2 pi turns, 4e-7 rad at |x| = 6 (sum |W| + |b| of the shipped checkpoints stays below 4), against
+// 1.5e-7 for the polynomial nws_sinf that the table construction and the stand-alone shaper keep.
+__device__ __forceinline__ float g_sin_mlp(float x) {
+  return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x * 0.15915493667125702f));
+}
 template <int W>
 __device__ __forceinline__ float g_exact_shaper_reg(const GShaper& P, int s, float x) {
   const float a = P.in_scale[s] * x;
@@ -489,7 +494,7 @@ __device__ __forceinline__ float g_exact_shaper_reg(const GShaper& P, int s, flo
     const float* w0 = P.w[0] + (size_t)s * W;
     const float* b0 = P.b[0] + (size_t)s * W;
 #pragma unroll
-    for (int j = 0; j < W; ++j) h[j] = nws_sinf_fast(fmaf(w0[j], a, b0[j]));
+    for (int j = 0; j < W; ++j) h[j] = g_sin_mlp(fmaf(w0[j], a, b0[j]));
   }
   for (int layer = 1; layer < P.depth - 1; ++layer) {
     const float* wl = P.w[layer] + (size_t)s * W * W;
@@ -499,7 +504,7 @@ __device__ __forceinline__ float g_exact_shaper_reg(const GShaper& P, int s, flo
       float acc = bl[i];
 #pragma unroll
       for (int j = 0; j < W; ++j) acc = fmaf(wl[i * W + j], h[j], acc);
-      g[i] = nws_sinf_fast(acc);
+      g[i] = g_sin_mlp(acc);
     }
 #pragma unroll
     for (int i = 0; i < W; ++i) h[i] = g[i];
@@ -508,7 +513,7 @@ __device__ __forceinline__ float g_exact_shaper_reg(const GShaper& P, int s, flo
   float acc = P.b[P.depth - 1][s];
 #pragma unroll
   for (int j = 0; j < W; ++j) acc = fmaf(wl[j], h[j], acc);
-  return nws_sinf_fast(acc);
+  return g_sin_mlp(acc);
 }
 
 // NEWT.forward up to the mixer (shaping.py:68-76): film (B, 4S, T) channel-major, upsampled xhop on the fly;
