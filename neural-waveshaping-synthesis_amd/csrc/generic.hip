@@ -1226,6 +1226,16 @@ int nws_g_gru(const float* w_ih, const float* w_hh, const float* b_ih, const flo
   const size_t lds = ((size_t)2 * hidden + C_in) * sizeof(float);
   if (lds > 160 * 1024) return NWS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  if (hidden == 128 && C_in == 2 && !getenv("NWS_G_GRU_RUNTIME")) {
+    // the reference's default recurrence (GRU(2 -> 128)) inside an otherwise non-default configuration: the fused path's
+    // kernel (control_gru.hip: 0.44 us per step against 0.8 for the runtime-size recurrence below), same layouts
+    NwsWeights w{};
+    w.gru_w_ih = w_ih;
+    w.gru_w_hh = w_hh;
+    w.gru_b_ih = b_ih;
+    w.gru_b_hh = b_hh;
+    return nws_control_gru_state(&w, control, B, C_total, T, h0, out, hT, stream);
+  }
   if (hidden <= 128 && !getenv("NWS_G_GRU_L2")) {
     // W_hh in registers: four lanes per hidden unit (whole waves: units rounded up to 16)
     const int threads = 4 * ((hidden + 15) & ~15);
