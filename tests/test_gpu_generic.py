@@ -195,8 +195,10 @@ NeuralWaveshaping.n_waveshapers = {S}
 def _big_gin(case):
     """Sizes beyond the round-4 kernels' buckets, so that their fall-backs keep a test: a GRU of 160 units (W_hh does not fit the
     registers of 4 H lanes: the L2-streaming recurrence), 70 shapers (> 64: oscillator bank, mixer and shapers as stage kernels),
-    5 NEWT output channels (> 4: same)."""
-    hid, S, oc = {"gru160": (160, 6, 1), "shapers70": (24, 70, 2), "out5": (24, 5, 5)}[case]
+    5 NEWT output channels (> 4: same), 700 harmonics x 40 shapers (the mixer's fp16 fragments do not fit LDS: the
+    thread-per-sample oscillator kernel)."""
+    hid, S, oc, harm = {"gru160": (160, 6, 1, 20), "shapers70": (24, 70, 2, 20), "out5": (24, 5, 5, 20),
+                        "harm700": (24, 40, 2, 700)}[case]
     text = f"""
 Reverb.sr = 500
 Reverb.length_in_seconds = 1
@@ -212,7 +214,7 @@ NEWT.out_channels = {oc}
 NEWT.control_embedding_size = 12
 NEWT.n_waveshapers = {S}
 HarmonicOscillator.sample_rate = 16000
-HarmonicOscillator.n_harmonics = 20
+HarmonicOscillator.n_harmonics = {harm}
 ControlModule.embedding_size = 12
 ControlModule.hidden_size = {hid}
 ControlModule.control_size = 2
@@ -223,7 +225,7 @@ NeuralWaveshaping.n_waveshapers = {S}
     return text, 16, 16000, S
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18, 19, 20, "gru160", "shapers70", "out5"])
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18, 19, 20, "gru160", "shapers70", "out5", "harm700"])
 def test_random_gin_configurations_match_the_oracle(seed):
     """Ten seeded random points of the gin surface, randomly initialised by the product's own constructors: the runtime-size
     path (csrc/generic.hip) against the oracle run on the same state dict and draws, exact shapers and FastNEWT.  The oracle is
