@@ -149,7 +149,8 @@ struct NoiseMfmaLds {
   _Float16 hhi[kUtt][kRowHalfs];   // HALF the taps (128) of the frame being accumulated, times the utterance's scale:
   _Float16 hlo[kUtt][kRowHalfs];   // staging half rows keeps the block at 36 KB of LDS = 4 workgroups per CU
   __attribute__((aligned(16))) float unscale[kUtt];   // 1 / (tap scale * noise scale) per utterance
-  float win[3 * kHop];             // padded noise [128 (t-1), 128 (t-1) + 384), times the noise scale: frames t-1 and t
+  float win[4 * kHop];             // padded noise [128 (t-1), 128 (t-1) + 384), times the noise scale: frames t-1 and t (+ 128 of
+                                   // padding: every thread stores two entries, so both loads are requested up front)
 };
 
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -208,38 +209,37 @@ __global__ __launch_bounds__(256, 4) void fir_noise_mfma_kernel(const float* __r
     for (int it = 0; it < 4; ++it) {
       const int b = b0 + my_row + 8 * it;
       const bool ok = frame >= 0 && frame < T && b < B;
+      // always-in-bounds addresses and a select afterwards: as `ok ? *ptr : zero` hipcc predicated every COMPONENT on its own
+      // (64 global_load_dword per lane instead of 16 global_load_dwordx4: four instructions over the same cache lines)
+      const int bc = b < B ? b : B - 1, fc = frame < 0 ? 0 : (frame < T ? frame : T - 1);
       // (two index expressions off the same row start: written as `src + 124 - 4 p` hipcc put a temporary on the stack)
-      const float* src = &fir[((size_t)b * T + frame) * kHalf + 4 * p32];
-      const float* src_lo = &fir[((size_t)b * T + frame) * kHalf + 4 * (31 - p32)];
-      const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      v[it + 4] = ok ? *reinterpret_cast<const float4*>(src) : zero;
-      v[it] = ok ? *reinterpret_cast<const float4*>(src_lo) : zero;     // the raw quad A; mirrored when staged
+      const float* src = &fir[((size_t)bc * T + fc) * kHalf + 4 * p32];
+      const float* src_lo = &fir[((size_t)bc * T + fc) * kHalf + 4 * (31 - p32)];
+      const float4 hi4 = *reinterpret_cast<const float4*>(src), lo4 = *reinterpret_cast<const float4*>(src_lo);
+      const float keep = ok ? 1.0f : 0.0f;
+      v[it + 4] = make_float4(hi4.x * keep, hi4.y * keep, hi4.z * keep, hi4.w * keep);
+      v[it] = make_float4(lo4.x * keep, lo4.y * keep, lo4.z * keep, lo4.w * keep);     // the raw quad A; mirrored when staged
     }
   };
+  // the 384 noise samples both frames are cut from, once (reflect padding resolved here), pre-scaled.  Requested BEFORE the
+  // tap rows: the vector-memory counter retires in order, so waiting for these two leaves the 16 row loads in flight
+  float wv[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int e = tid + 256 * q, i = kHop * (t - 1) + e;
+    const bool in = e < 3 * kHop && i >= 0 && i < N + kL - 1;
+    const float nv = padded_noise(noise, len, origin, in ? i : origin);   // unconditional: both loads issue back to back
+    wv[q] = in ? nv * kNoiseScale : 0.0f;
+  }
   float4 cur[8], prv[8];
   load_rows(t, cur);
   load_rows(t - 1, prv);
+  L.win[tid] = wv[0];
+  L.win[tid + 256] = wv[1];
 
-  // the 384 noise samples both frames are cut from, once (reflect padding resolved here), pre-scaled
-  for (int e = tid; e < 3 * kHop; e += 256) {
-    const int i = kHop * (t - 1) + e;
-    L.win[e] = (i >= 0 && i < N + kL - 1) ? padded_noise(noise, len, origin, i) * kNoiseScale : 0.0f;
-  }
-
-  // one power-of-two scale per utterance (both frames): largest |tap| -> [2^14, 2^15).  Keeps hi AND lo of every tap that
-  // matters clear of the fp16 subnormals whatever the filter gain (-120 dB noise floors included); exact to undo.
-  float scale[4];   // of row my_row + 8 it (each 32-lane half has its own rows)
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    auto amax4 = [](const float4& a) { return fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))); };
-    float mx = fmaxf(amax4(cur[it + 4]), amax4(prv[it + 4]));     // the upper halves hold every distinct tap of the two rows
-    mx = half_max(mx);   // over the 32 lanes that hold this row
-    int ex = (int)((__float_as_uint(mx) >> 23) & 0xff);  // biased exponent of the row maximum
-    ex = ex < 16 ? 16 : (ex > 250 ? 250 : ex);
-    scale[it] = __uint_as_float((unsigned)(268 - ex) << 23);          // 2^(14 - e)
-    if (p32 == 0) L.unscale[my_row + 8 * it] = __uint_as_float((unsigned)(ex - 14) << 23) * (1.0f / kNoiseScale);  // 2^(e - 14) / 2^10
-  }
-  __syncthreads();  // win complete
+  // (LDS-only barrier: __syncthreads() would also wait for the tap rows requested above, and the staging of the noise copies
+  // below - LDS and vector work only - is what their latency is there to hide)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // win complete
 
   // reversed noise frames, eight shifted copies each: frame 0: R[u] = f_t[(-u) & 255] = win[128 + ((-u) & 255)];
   // frame 1: R[u] = f_{t-1}[(128 - u) & 255] = win[(128 - u) & 255].  One thread fills 8 consecutive v (one 16-byte chunk).
@@ -264,6 +264,19 @@ __global__ __launch_bounds__(256, 4) void fir_noise_mfma_kernel(const float* __r
     }
     *reinterpret_cast<f16x8*>(&L.rhi[fr][c][v0]) = h8;
     *reinterpret_cast<f16x8*>(&L.rlo[fr][c][v0]) = l8;
+  }
+  // one power-of-two scale per utterance (both frames): largest |tap| -> [2^14, 2^15).  Keeps hi AND lo of every tap that
+  // matters clear of the fp16 subnormals whatever the filter gain (-120 dB noise floors included); exact to undo.
+  float scale[4];   // of row my_row + 8 it (each 32-lane half has its own rows)
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    auto amax4 = [](const float4& a) { return fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))); };
+    float mx = fmaxf(amax4(cur[it + 4]), amax4(prv[it + 4]));     // the upper halves hold every distinct tap of the two rows
+    mx = half_max(mx);   // over the 32 lanes that hold this row
+    int ex = (int)((__float_as_uint(mx) >> 23) & 0xff);  // biased exponent of the row maximum
+    ex = ex < 16 ? 16 : (ex > 250 ? 250 : ex);
+    scale[it] = __uint_as_float((unsigned)(268 - ex) << 23);          // 2^(14 - e)
+    if (p32 == 0) L.unscale[my_row + 8 * it] = __uint_as_float((unsigned)(ex - 14) << 23) * (1.0f / kNoiseScale);  // 2^(e - 14) / 2^10
   }
   auto stage_rows = [&](const float4 (&v)[8], const int khalf) {  // taps [128 khalf, 128 khalf + 128) of all 32 rows
 #pragma unroll
