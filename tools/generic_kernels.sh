@@ -12,7 +12,7 @@ import csv, sys
 print(f'{"kernel":72s} calls   avg us')
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Name"]
-    if any(k in n for k in ("g_", "td_mlp", "col125", "row512", "row_kernel")):
+    if any(k in n for k in ("g_", "td_mlp", "col125", "row512", "row_kernel", "control_gru")):
         n = n.replace("(anonymous namespace)::", "").replace("void ", "")
         print(f'{n[:72]:72s} {r["Calls"]:>5} {float(r["AverageNs"]) / 1e3:8.1f}')
 PY
