@@ -28,6 +28,10 @@ constexpr int kKPad = 16 * kKSteps;         // 112
 constexpr int kS = NWS_N_SHAPERS;           // 64
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#ifndef NWS_LUT_GROUP
+#define NWS_LUT_GROUP 4
+#endif
+constexpr int kLutGroup = NWS_LUT_GROUP;   // table gathers in flight together in the fused tail (one memory round trip per group)
 constexpr int kTile = 128;                  // samples per workgroup (= control hop)
 constexpr float kTau = 6.283185307179586f;  // fl32(math.tau)
 constexpr float kPi = 3.141592653589793f;   // fl32(math.pi)
@@ -938,12 +942,12 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
       const f32x16 Bb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, L.ffrag[q0][1][m][col]), bfrag, f32x16{}, 0, 0, 0);
       const f32x16 Gn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, L.ffrag[q0][2][m][col]), bfrag, f32x16{}, 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float fr[4];
-        float2 tv[4];
+      for (int g = 0; g < 16 / kLutGroup; ++g) {
+        float fr[kLutGroup];
+        float2 tv[kLutGroup];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e;
+        for (int e = 0; e < kLutGroup; ++e) {
+          const int r = kLutGroup * g + e;
           const float idx = fmaf(G[r], acc[r], Bb[r]);   // FiLM in table units (bias and origin folded at staging)
           // floor + clamp + integer index without a conversion: idx + (2^23 - 1/2) rounds to 2^23 + floor(idx) (at exact
           // integers k possibly k - 1 with fraction 1: the same point of the piecewise-linear table up to one rounding of
@@ -953,10 +957,10 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
           const unsigned o = lane_off_bytes + ((unsigned)(int)fl << 3);
           fr[e] = idx - fl;
           tv[e] = DBG == 2 ? float2{idx, 0.0f}
-                           : *reinterpret_cast<const float2*>(LF.pairs + (size_t)(32 * m + 8 * g + e) * LF.row_bytes + o);
+                           : *reinterpret_cast<const float2*>(LF.pairs + (size_t)(32 * m + (r & 3) + 8 * (r >> 2)) * LF.row_bytes + o);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) part = fmaf(Gn[4 * g + e], fmaf(tv[e].y, fr[e], tv[e].x), part);
+        for (int e = 0; e < kLutGroup; ++e) part = fmaf(Gn[kLutGroup * g + e], fmaf(tv[e].y, fr[e], tv[e].x), part);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
