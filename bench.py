@@ -414,6 +414,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1 or force_dist
+    if os.environ.get("NWS_BENCH_INIT_PG_ONLY") == "1" and not distributed:
+        # diagnosis only: an initialised RCCL communicator beside the single-GPU issue pattern (what does its mere presence cost?)
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("nccl", device_id=dev)
+        dist.barrier()
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -448,7 +457,7 @@ def main():
     pipe = None
     if use_pipe:
         pmod = importlib.import_module("neural-waveshaping-synthesis_amd.pipeline")
-        n_control = a.control_streams if a.control_streams > 0 else (1 if distributed else 2)
+        n_control = a.control_streams if a.control_streams > 0 else 2
         pipe = pmod.ForwardPipeline(model, depth=a.depth if a.depth > 0 else len(streams) + 2,
                                     audio_streams=len(streams), control_streams=n_control, batched_gru=a.gru == "batched",
                                     chain_exciters=bool(a.chain_exciters))
@@ -508,8 +517,8 @@ def main():
             au = pipe.next_audio_stream() if do_compute else pipe.audio[i % len(pipe.audio)]
             y = None
             if do_compute:
-                with torch.cuda.stream(au):             # draws where they are consumed: nothing ever runs on the null stream
-                    pu, nz = par.shared_draws(101, N - 1, dev, generator=shared_gen)   # identical on all ranks
+                # the two draws inside submit(), from the generator every rank seeded identically: the same
+                # issue pattern as the single-GPU run, nothing but the exchange added
                 if blocks is not None and do_gather:
                     # sub-batch exchange: block q leaves for the peers as soon as ITS reverb is enqueued (on the audio stream,
                     # inside submit), under the reverb of block q + 1; the previous step's exchange is waited for first
@@ -520,10 +529,10 @@ def main():
                             _pending.wait()
                         _works.append(gather_rows(_i, out, row0, n))
 
-                    pipe.submit(f0, control, phase_u=pu, noise=nz, row_blocks=blocks, on_block=on_block)
+                    pipe.submit(f0, control, generator=shared_gen, row_blocks=blocks, on_block=on_block)
                     with torch.cuda.stream(au):
                         return peer_finish(i) if peer is not None else _Works(works)
-                y = pipe.submit(f0, control, phase_u=pu, noise=nz)
+                y = pipe.submit(f0, control, generator=shared_gen)
             with torch.cuda.stream(au):                 # ordered after this batch's reverb
                 if pending is not None:
                     pending.wait()
@@ -564,10 +573,10 @@ def main():
             pending.wait()
         join_streams()
         torch.cuda.synchronize()
+        el = time.perf_counter() - t0      # this rank's K steps, from the common start to its own last kernel
         if distributed:
-            dist.barrier()
-        el = time.perf_counter() - t0
-        per_rank = [el]
+            dist.barrier()                  # (the closing barrier itself - a collective launch and a host synchronise - is not
+        per_rank = [el]                     # part of any rank's steps: the job's time is the MAX over ranks, taken below)
         if distributed:
             tt = torch.tensor([el], dtype=torch.float64, device="cpu" if share_gpu else dev)
             allr = [torch.zeros_like(tt) for _ in range(world)]
@@ -658,6 +667,14 @@ def main():
                 wrong += 0 if torch.equal(y, model(f0, control, phase_u=pu_c, noise=nz_c)) else 1
             torch.cuda.synchronize()
             extra["pipeline_selfcheck"] = {"batches": len(ys), "mismatching": wrong}
+            # the timed loop's own route to the draws: submit(generator=g) must equal a plain forward with the two draws taken
+            # from an identically seeded generator (what makes the ranks of a sharded batch agree without a collective)
+            g1, g2 = par.make_shared_generator(dev, seed=777), par.make_shared_generator(dev, seed=777)
+            y_g = pipe.submit(f0, control, generator=g1)
+            pipe.synchronize()
+            pu_g, nz_g = par.shared_draws(101, N - 1, dev, generator=g2)
+            extra["pipeline_selfcheck"]["generator_route_matches"] = bool(torch.equal(y_g, model(f0, control, phase_u=pu_g, noise=nz_g)))
+            torch.cuda.synchronize()
             if distributed:
                 # the last gathered buffer must hold this rank's own last batch at its rows, bit for bit
                 if share_gpu:

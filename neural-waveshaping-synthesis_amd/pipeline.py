@@ -103,7 +103,7 @@ class ForwardPipeline:
         n = B // chunks
         return [(q * n, n) for q in range(chunks)]
 
-    def submit(self, f0, control, *, phase_u=None, noise=None, out=None, row_blocks=None, on_block=None):
+    def submit(self, f0, control, *, phase_u=None, noise=None, out=None, row_blocks=None, on_block=None, generator=None):
         m = self.model
         f0 = _req(f0 if f0.is_contiguous() else f0.contiguous(), "f0")
         control = _req(control if control.is_contiguous() else control.contiguous(), "control")
@@ -127,9 +127,11 @@ class ForwardPipeline:
             # the two hidden draws of forward(), in the reference's order, on the side stream: two more small launches that
             # the audio streams do not have to carry (the generator advances in submit order either way)
             # (same generator consumption as torch.rand_like / torch.rand: the same uniform_ kernel on 101 resp. 128 T - 1 elements)
-            pu = torch.rand(_lib.N_HARMONICS, out=slot.pu) if phase_u is None else phase_u      # RNG draw #1 (generators.py:55)
+            # (`generator`: the draws come from it instead of the device's default generator - ranks of a sharded batch pass
+            # identically seeded generators and so draw the same values with no collective, parallel.make_shared_generator)
+            pu = torch.rand(_lib.N_HARMONICS, out=slot.pu, generator=generator) if phase_u is None else phase_u      # RNG draw #1 (generators.py:55)
             pu = _req(pu.reshape(-1), "phase_u", _lib.N_HARMONICS)
-            nz = torch.rand(m.control_hop * T - 1, out=slot.nz) if noise is None else noise     # RNG draw #2 (:30)
+            nz = torch.rand(m.control_hop * T - 1, out=slot.nz, generator=generator) if noise is None else noise     # RNG draw #2 (:30)
             nz = _req(nz, "noise", m.control_hop * T - 1)
             self.eng.forward_control(f0, control, slot.ws, batched_gru=batched)
             slot.ev_control.record(cs)
