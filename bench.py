@@ -484,6 +484,8 @@ def main():
 
     blocks = pmod.ForwardPipeline.row_blocks(B, a.gather_chunks) if (distributed and use_pipe) else None
 
+    slot_work = [None] * max(1, nbuf)       # last exchange that wrote each gather buffer
+
     def gather_rows(i, y, row0, n):
         """rows [row0, row0 + n) of this step's waveforms to every rank, on the CURRENT stream"""
         if peer is not None:
@@ -532,12 +534,23 @@ def main():
                     pipe.submit(f0, control, generator=shared_gen, row_blocks=blocks, on_block=on_block)
                     with torch.cuda.stream(au):
                         return peer_finish(i) if peer is not None else _Works(works)
-                y = pipe.submit(f0, control, generator=shared_gen)
+                # the batch is rendered straight into this rank's rows of the gather buffer (no local copy: the all-gather is
+                # in place for RCCL, the peer pushes skip the local shard); the slot's previous exchange is complete - the
+                # audio stream waited for a later one already - and the explicit wait below costs nothing then
+                slot_i = i % nbuf
+                with torch.cuda.stream(au):
+                    if slot_work[slot_i] is not None:
+                        slot_work[slot_i].wait()
+                        slot_work[slot_i] = None
+                    dst = peer.local_rows(slot_i) if peer is not None else full[slot_i][rank * B:(rank + 1) * B]
+                y = pipe.submit(f0, control, generator=shared_gen, out=dst)
             with torch.cuda.stream(au):                 # ordered after this batch's reverb
                 if pending is not None:
                     pending.wait()
                 if do_gather:
-                    return gather(i, y if y is not None else gather_src)
+                    work = gather(i, y if y is not None else gather_src)
+                    slot_work[i % nbuf] = work
+                    return work
             return None
         s = streams[i % len(streams)]
         with torch.cuda.stream(s):

@@ -108,7 +108,9 @@ class PeerCopyAllGather:
 
     Set-up (once): each rank allocates `nbuf` gather buffers of (world * b, N), exports them as IPC handles
     (dmabuf IPC; HSA_ENABLE_IPC_MODE_LEGACY=0 must be set, as it is on the GPU boxes) and opens every peer's buffers.
-    Per step: `gather(y, slot)` enqueues world copies on the CURRENT stream, then one tiny stream-ordered collective
+    Per step: `gather(y, slot)` forks one copy per peer onto that peer's own copy stream (in-order streams would run the
+    world - 1 copies one after the other: one link busy at a time), joins them back into the CURRENT stream, skips the local
+    copy when the shard was rendered in place (`local_rows(slot)`), then one tiny stream-ordered collective
     (4-byte all-reduce; on the "gloo" test backend a host barrier after a stream sync) whose completion on rank q implies
     that every rank's copies into q's buffer were complete when that rank joined it.  Returns (full_buffer, work).
 
@@ -150,6 +152,9 @@ class PeerCopyAllGather:
                 opened.append(t)
             self.remote.append(opened)
         self._flag = torch.zeros(1, dtype=torch.float32, device=self.device)
+        # one copy stream per peer: the pushes of a step run side by side, each on its own point-to-point link
+        self._copy_streams = ([torch.cuda.Stream(device=self.device) for _ in range(self.world)]
+                              if self.device.type == "cuda" and self.world > 1 else None)
         self._held = [False] * nbuf          # handed to the consumer, not yet released
         self._released = [None] * nbuf       # event of the consumer's last use of the slot
         self._last_work = None               # completion signal of the previous gather
@@ -187,15 +192,44 @@ class PeerCopyAllGather:
         self._last_work = work
         return self.full[slot], work
 
+    def local_rows(self, slot: int) -> torch.Tensor:
+        """This rank's own rows of full[slot]: render into them (forward(..., out=...)) and `gather` has nothing to copy locally.
+        The current stream is made to wait for the consumer's last released use of the slot first."""
+        ev = self._released[slot]
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+        lo = self.rank * self.rows
+        return self.full[slot][lo:lo + self.rows]
+
+    def _push(self, src: torch.Tensor, slot: int, lo: int):
+        """src -> rows [lo, lo + len(src)) of every rank's full[slot]; ordered after the current stream's work so far, and the
+        current stream continues after all of the copies"""
+        n = src.shape[0]
+        cur = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
+        fork = cur.record_event() if self._copy_streams is not None else None
+        joins = []
+        for k in range(self.world):             # start with the right-hand neighbour: the ranks' pushes spread over the links
+            p = (self.rank + k) % self.world
+            dst = self.remote[p][slot][lo:lo + n]
+            if p == self.rank and dst.data_ptr() == src.data_ptr():
+                continue                        # rendered in place
+            if self._copy_streams is None:
+                dst.copy_(src, non_blocking=True)
+                continue
+            st = self._copy_streams[p]
+            st.wait_event(fork)
+            with torch.cuda.stream(st):
+                dst.copy_(src, non_blocking=True)
+                joins.append(st.record_event())
+        for ev in joins:
+            cur.wait_event(ev)
+
     def push_rows(self, y: torch.Tensor, slot: int, row0: int, nrows: int):
-        """Sub-batch form: push rows [row0, row0 + nrows) of this rank's shard into every peer's buffer on the
-        current stream; call `finish(slot)` after the last block."""
+        """Sub-batch form: push rows [row0, row0 + nrows) of this rank's shard into every peer's buffer (ordered
+        after the current stream); call `finish(slot)` after the last block."""
         if row0 == 0:
             self._claim(slot)
-        lo = self.rank * self.rows + row0
-        for k in range(self.world):
-            p = (self.rank + k) % self.world
-            self.remote[p][slot][lo:lo + nrows].copy_(y[row0:row0 + nrows], non_blocking=True)
+        self._push(y[row0:row0 + nrows], slot, self.rank * self.rows + row0)
 
     def finish(self, slot: int):
         """the completion signal of gather(), on its own (after push_rows of every block)"""
@@ -205,8 +239,5 @@ class PeerCopyAllGather:
         if y.shape != (self.rows, self.n) or not y.is_contiguous():
             raise ValueError(f"expected a contiguous {(self.rows, self.n)} shard, got {tuple(y.shape)}")
         self._claim(slot)
-        lo = self.rank * self.rows
-        for k in range(self.world):             # start with the right-hand neighbour: the ranks' pushes spread over the links
-            p = (self.rank + k) % self.world
-            self.remote[p][slot][lo:lo + self.rows].copy_(y, non_blocking=True)
+        self._push(y, slot, self.rank * self.rows)
         return self._signal(slot)
