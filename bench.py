@@ -545,8 +545,9 @@ def main():
                     dst = peer.local_rows(slot_i) if peer is not None else full[slot_i][rank * B:(rank + 1) * B]
                 y = pipe.submit(f0, control, generator=shared_gen, out=dst)
             with torch.cuda.stream(au):                 # ordered after this batch's reverb
-                if pending is not None:
-                    pending.wait()
+                # (the audio stream does NOT wait for the previous exchange: collectives are ordered among themselves on RCCL's
+                # stream, the peer pushes by PeerCopyAllGather's claim, and a gather buffer is only rendered into again after
+                # the slot's own exchange, slot_work above - so a slow exchange delays exchanges, not oscillator kernels)
                 if do_gather:
                     work = gather(i, y if y is not None else gather_src)
                     slot_work[i % nbuf] = work
