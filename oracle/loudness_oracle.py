@@ -19,7 +19,8 @@ librosa==0.8.0).  Its published algorithm, restated here:
       - 10 log10(max(amin^2, ref^2)); log_spec = max(log_spec, log_spec.max() - top_db).
 Parity status: UNPINNED against librosa itself (absent, no network).  The STFT half is pinned against an independent
 implementation with the same documented semantics (torch.stft, center=True, reflect, periodic hann) in
-tests/test_oracle_loudness.py; the dB half is a direct transcription of the formulas above.
+tests/test_oracle_loudness.py, against scipy.signal.stft (a second one), and the window against scipy.signal.get_window - the
+very call librosa makes, scipy being in the image; the dB half is a direct transcription of the formulas above.
 """
 import numpy as np
 

@@ -38,3 +38,30 @@ def test_extract_perceptual_loudness_shapes_and_interpolation():
     t = np.arange(16000) / 16000.0
     tone = lo.extract_perceptual_loudness(np.sin(2 * np.pi * 440 * t), n_fft=1024, hop_length=128)
     assert np.ptp(tone[8:-8]) < 2e-3
+
+
+def test_window_is_the_one_librosa_asks_scipy_for():
+    """librosa.stft(window="hann") obtains its window from scipy.signal.get_window("hann", n_fft, fftbins=True)
+    (librosa 0.8.0 filters.get_window); scipy IS in the image, so this half of the chain is pinned on the real dependency."""
+    import scipy.signal
+
+    for n_fft in (64, 256, 1024, 2048):
+        w = scipy.signal.get_window("hann", n_fft, fftbins=True)
+        assert np.abs(lo.hann_periodic(n_fft) - w).max() <= 1e-15
+
+
+def test_stft_magnitude_matches_scipy_stft():
+    """A second independent implementation of the same framing (scipy.signal.stft with boundary="even" = numpy's reflect
+    padding by n_fft/2, no zero padding of the tail); scipy scales by 1 / sum(window), librosa does not."""
+    import scipy.signal
+
+    g = np.random.default_rng(3)
+    for n, n_fft, hop in ((4096, 1024, 128), (2048, 256, 64), (16384, 2048, 512)):
+        x = g.standard_normal(n)
+        w = scipy.signal.get_window("hann", n_fft, fftbins=True)
+        _, _, Z = scipy.signal.stft(x, window=w, nperseg=n_fft, noverlap=n_fft - hop, nfft=n_fft, boundary="even", padded=False,
+                                    return_onesided=True)
+        ref = np.abs(Z) * w.sum()
+        got = lo.stft_magnitude(x, n_fft, hop)
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+        assert np.abs(got - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
