@@ -1556,8 +1556,14 @@ static int g_exciter_newt_fused(const NwsGenericModel* m, const float* f0_up, co
     const int MT = S <= 32 ? 1 : 2, SBM = 32 * MT, K16 = (K + 15) / 16;
     int tpw = 4;
     while (tpw > 1 && (long long)((N + 128 * tpw - 1) / (128 * tpw)) * B < 1024) tpw >>= 1;
+    // ... and as long as the FiLM rows of the workgroup's frames fit LDS next to the fragments (short hops: many frames per tile)
+    auto lds_of = [&](int t) {
+      const size_t frames = (size_t)(128 * t / m->hop + 3);
+      return ((size_t)K16 * MT * 512 + 16 * K16 + 5 * (size_t)SBM + (exc_only ? 0 : (size_t)8 * SBM * frames)) * sizeof(float);
+    };
+    while (tpw > 1 && lds_of(tpw) > 80 * 1024) tpw >>= 1;     // two workgroups per CU
     const int nf = 128 * tpw / m->hop + 3;
-    const size_t lds = ((size_t)K16 * MT * 512 + 16 * K16 + 5 * (size_t)SBM + (exc_only ? 0 : (size_t)8 * SBM * nf)) * sizeof(float);
+    const size_t lds = lds_of(tpw);
     if (lds <= 160 * 1024) {
       // scratch: [fragments K16 x MT x 512 floats | scale, 1 / scale, pad | table pairs]
       gf16x8* frag = reinterpret_cast<gf16x8*>(scratch);
