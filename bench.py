@@ -665,13 +665,20 @@ def main():
                     with torch.cuda.stream(au):
                         pend = peer_finish(i) if peer is not None else _Works(works)
                     continue
-                y = pipe.submit(f0, control, phase_u=pu_c, noise=nz_c)
-                ys.append(y)
                 if distributed:
+                    # rendered in place into the gather buffer, as the timed loop does (the rows are cloned for the comparison
+                    # below before the slot is rendered into again: nbuf batches later)
                     with torch.cuda.stream(au):
                         if pend is not None:
                             pend.wait()
+                        dst_c = peer.local_rows(i % nbuf) if peer is not None else full[i % nbuf][rank * B:(rank + 1) * B]
+                    y = pipe.submit(f0, control, phase_u=pu_c, noise=nz_c, out=dst_c)
+                    with torch.cuda.stream(au):
                         pend = gather(i, y)
+                        ys.append(y.clone())
+                    continue
+                y = pipe.submit(f0, control, phase_u=pu_c, noise=nz_c)
+                ys.append(y)
             if pend is not None:
                 pend.wait()
             pipe.synchronize()
