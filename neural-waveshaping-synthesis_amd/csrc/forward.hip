@@ -253,7 +253,9 @@ int nws_profile_begin(int slots, unsigned stage_mask) {
   if (slots <= 0) return NWS_ERR_BAD_ARG;
   g_prof.ev = new hipEvent_t[(size_t)slots * kStages * 2];
   for (size_t i = 0; i < (size_t)slots * kStages * 2; ++i) {
-    hipError_t e = hipEventCreate(&g_prof.ev[i]);
+    // timing only: no system-scope fence (cache writeback + invalidation) when the event is recorded - it would sit right in
+    // front of and behind the kernel being timed, inside the step that is being timed
+    hipError_t e = hipEventCreateWithFlags(&g_prof.ev[i], hipEventDisableSystemFence);
     if (e != hipSuccess) return (int)e;
   }
   g_prof.slots = slots;
