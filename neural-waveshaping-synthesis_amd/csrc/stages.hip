@@ -75,11 +75,17 @@ __global__ __launch_bounds__(256) void td_mlp_kernel(MlpArgs a, const float* __r
 #pragma unroll
           for (int s2 = 0; s2 < 16; ++s2) av[s2] = 0.0f;
         }
+        // the chunk's 16 activations first, all in flight together (as `k < cin ? cur[...] : 0` every read was predicated on its
+        // own and waited for right in front of its MFMA: one LDS latency per MFMA, the matrix pipe a third busy); rows beyond
+        // cin are read from row cin - 1 instead and meet zero weights
+        float bv[16];
 #pragma unroll
         for (int s2 = 0; s2 < 16; ++s2) {
-          const float bv = kb + s2 < cin ? cur[(kb + s2) * 33 + col] : 0.0f;
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv, acc, 0, 0, 0);
+          const int k = kb + s2 < cin ? kb + s2 : cin - 1;
+          bv[s2] = cur[k * 33 + col];
         }
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2], acc, 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
