@@ -520,7 +520,8 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
                                                            float* __restrict__ exciter_out,
                                                            float* __restrict__ newt_out,
                                                            const float* __restrict__ bank = nullptr,
-                                                           const float* __restrict__ add_in = nullptr) {
+                                                           const float* __restrict__ add_in = nullptr,
+                                                           const int xcd_groups = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   ExcLds& L = *reinterpret_cast<ExcLds*>(smem_raw);
   ShaperLds& SH = *reinterpret_cast<ShaperLds*>(smem_raw + ((sizeof(ExcLds) + 15) & ~size_t(15)));
@@ -530,10 +531,25 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
   const int wave = tid >> 6;
   const int half = lane >> 5;
   const int col = lane & 31;
-  const int jb = blockIdx.x * HPB;        // first hop of the workgroup
+  // Workgroups go to the eight XCDs round-robin in launch order (linear id % 8, MI355X_MICROARCH).  Neighbouring hop groups
+  // share two of their four FiLM rows; as grid (groups, B) with jb = blockIdx.x HPB they always sat on different L2s and every
+  // row came from HBM twice (105 MB per launch against 69 MB algorithmic).  xcd_groups > 0 (= hop groups per utterance): a 1-D
+  // grid whose id p runs on XCD p % 8 as that XCD's (p / 8)-th workgroup; XCD k takes the k-th of eight contiguous, equally
+  // long (+-1) ranges of the (utterance, hop group) sequence, so neighbours in time are neighbours in launch order on ONE L2.
+  // Placement only: same results.
+  int bx, b;
+  if (xcd_groups > 0) {
+    const unsigned p = blockIdx.x, total = gridDim.x, k = p & 7u, r = total & 7u;
+    const unsigned l = k * (total >> 3) + (k < r ? k : r) + (p >> 3);
+    b = __builtin_amdgcn_readfirstlane((int)(l / (unsigned)xcd_groups));   // (uniform: keep it in a scalar register)
+    bx = (int)l - b * xcd_groups;
+  } else {
+    bx = (int)blockIdx.x;
+    b = (int)blockIdx.y;
+  }
+  const int jb = bx * HPB;                 // first hop of the workgroup
   const int j = jb + (wave >> 2);          // this wave's hop
   const int w4 = wave & 3;                 // quarter of the hop
-  const int b = blockIdx.y;
   const int N = T * NWS_HOP;
   constexpr int kThreads = 256 * HPB;
 
@@ -1368,10 +1384,14 @@ int nws_exciter_newt_add(const NwsWeights* w, const float* f0, const float* f0_u
       if (w->lut_pairs != nullptr && w->lut_max - w->lut_min == 6.0f && pow2) {
         // FastNEWT hot path.  exciter_opts (nws_hip.h): round-1 FiLM interpolation on the VALU / one fp16 term per sine in
         // every K-step / in K-steps 1..6 only
-        const dim3 g2((T + 1) / 2, B);
+        // XCD-contiguous hop groups (see the kernel); NWS_EXCITER_XCD=0 restores grid (groups, B) (measurements)
+        static const bool xcd_map = [] { const char* e = getenv("NWS_EXCITER_XCD"); return !(e && e[0] == '0'); }();
+        const int groups = (T + 1) / 2;
+        const int xcd_groups = xcd_map && (long long)groups * B >= 64 && (long long)groups * B < (1ll << 31) ? groups : 0;
+        const dim3 g2 = xcd_groups ? dim3((unsigned)(groups * B), 1) : dim3(groups, B);
         const int opts = w->exciter_opts;
 #define NWS_HOT(O) exciter_newt_kernel<kModeLutPairsDiv6, 0, 2, O><<<g2, 512, base, st>>>( \
-            *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out, nullptr, add_in)
+            *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out, nullptr, add_in, xcd_groups)
         if (opts & NWS_EXCITER_VALU_FILM) NWS_HOT(0);
         else if (opts & NWS_EXCITER_ONE_TERM) NWS_HOT(kOptFilmMfma | kOptOneTerm);
         else if (opts & NWS_EXCITER_HYBRID_W) NWS_HOT(kOptFilmMfma | kOptHybrid | kOptHybridW);

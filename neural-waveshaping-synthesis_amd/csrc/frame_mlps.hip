@@ -996,14 +996,21 @@ __device__ __forceinline__ void wr_store_rows(__amdgpu_buffer_rsrc_t out, const 
 template <bool TAPS, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void frame_mlps_wr_kernel(NwsWeights w, const float* __restrict__ gru_out, int F, int T,
                                                                  float* __restrict__ emb_out, float* __restrict__ film_out,
-                                                                 float* __restrict__ H_out, float* __restrict__ fir_out) {
+                                                                 float* __restrict__ H_out, float* __restrict__ fir_out,
+                                                                 const int xcd_blocks = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   WrLds& L = *reinterpret_cast<WrLds*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int path = blockIdx.y;                      // 0: proj + newt.mlp -> film; 1: proj + h_generator -> H -> fir
+  // Both paths of a frame block read the same 256 GRU rows.  As grid (blocks, 2) the two workgroups of a block sat on different
+  // XCDs (linear id % 8, MI355X_MICROARCH) and the rows came from HBM twice (88 MB per launch against 66 MB algorithmic).
+  // xcd_blocks > 0: a 1-D grid of 16-workgroup groups - ids 16 g + x and 16 g + 8 + x are block 8 g + x on path 0 / 1, i.e. the
+  // same XCD, eight launch slots apart; ids past the last block leave at once.  Placement only: same results.
+  const int fb = xcd_blocks > 0 ? (int)(blockIdx.x >> 4) * 8 + (int)(blockIdx.x & 7) : (int)blockIdx.x;
+  const int path = xcd_blocks > 0 ? (int)((blockIdx.x >> 3) & 1) : (int)blockIdx.y;   // 0: proj + newt.mlp -> film; 1: proj + h_generator -> H -> fir
+  if (xcd_blocks > 0 && fb >= xcd_blocks) return;
   const int half = lane >> 5, col = lane & 31;
-  const int f0 = blockIdx.x * kWrFrames + 32 * wave; // first frame of this wave
+  const int f0 = fb * kWrFrames + 32 * wave;         // first frame of this wave
   const int frame = f0 + col;                        // this lane's frame (standard orientation)
   const char* T2 = static_cast<const char*>(w.mlp_frags) + kT2Base;
   char* const S0 = L.slot[0];
@@ -1066,7 +1073,7 @@ __global__ __launch_bounds__(512, 2) void frame_mlps_wr_kernel(NwsWeights w, con
   // ABL == 6: cycle timeline - s_memtime at numbered points, every wave of workgroup (0, path), into emb_out as long long [path][wave][32]
   int probe_n = 0;
   auto probe = [&]() {
-    if (ABL == 6 && blockIdx.x == 0 && lane == 0 && probe_n < 32)
+    if (ABL == 6 && fb == 0 && lane == 0 && probe_n < 32)
       reinterpret_cast<long long*>(emb_out)[(path * 8 + wave) * 32 + probe_n] = (long long)__builtin_readcyclecounter();
     ++probe_n;
   };
@@ -1337,19 +1344,23 @@ int nws_frame_mlps(const NwsWeights* w, const float* gru_out, const float* fir_d
                               (int)sizeof(WrLds));
       if (e != hipSuccess) return (int)e;
     }
-    const dim3 gridw((unsigned)((F + kWrFrames - 1) / kWrFrames), 2);
+    // both paths of a frame block on one XCD (see the kernel); NWS_MLP_XCD=0 restores grid (blocks, 2) (measurements)
+    static const bool xcd_map = [] { const char* e = getenv("NWS_MLP_XCD"); return !(e && e[0] == '0'); }();
+    const unsigned nblk = (unsigned)((F + kWrFrames - 1) / kWrFrames);
+    const int xcd_blocks = xcd_map ? (int)nblk : 0;
+    const dim3 gridw = xcd_map ? dim3(16 * ((nblk + 7) / 8), 1) : dim3(nblk, 2);
     const int abl = g_mlp_dbg >> 4;
     if (abl == 6 && g_mlp_probe) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(frame_mlps_wr_kernel<false, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WrLds));
-      frame_mlps_wr_kernel<false, 6><<<gridw, 512, sizeof(WrLds), (hipStream_t)stream>>>(*w, gru_out, (int)F, T, static_cast<float*>(g_mlp_probe), film_out, nullptr, fir_out);
+      frame_mlps_wr_kernel<false, 6><<<gridw, 512, sizeof(WrLds), (hipStream_t)stream>>>(*w, gru_out, (int)F, T, static_cast<float*>(g_mlp_probe), film_out, nullptr, fir_out, xcd_blocks);
     } else if (abl == 1 || abl == 2 || abl == 3 || abl == 5) {
       auto fn = abl == 1 ? frame_mlps_wr_kernel<false, 1> : abl == 2 ? frame_mlps_wr_kernel<false, 2> : abl == 3 ? frame_mlps_wr_kernel<false, 3> : frame_mlps_wr_kernel<false, 5>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WrLds));
-      fn<<<gridw, 512, sizeof(WrLds), (hipStream_t)stream>>>(*w, gru_out, (int)F, T, nullptr, film_out, nullptr, fir_out);
+      fn<<<gridw, 512, sizeof(WrLds), (hipStream_t)stream>>>(*w, gru_out, (int)F, T, nullptr, film_out, nullptr, fir_out, xcd_blocks);
     } else if (!emb_out && !H_out)
-      frame_mlps_wr_kernel<false><<<gridw, 512, sizeof(WrLds), (hipStream_t)stream>>>(*w, gru_out, (int)F, T, nullptr, film_out, nullptr, fir_out);
+      frame_mlps_wr_kernel<false><<<gridw, 512, sizeof(WrLds), (hipStream_t)stream>>>(*w, gru_out, (int)F, T, nullptr, film_out, nullptr, fir_out, xcd_blocks);
     else
-      frame_mlps_wr_kernel<true><<<gridw, 512, sizeof(WrLds), (hipStream_t)stream>>>(*w, gru_out, (int)F, T, emb_out, film_out, H_out, fir_out);
+      frame_mlps_wr_kernel<true><<<gridw, 512, sizeof(WrLds), (hipStream_t)stream>>>(*w, gru_out, (int)F, T, emb_out, film_out, H_out, fir_out, xcd_blocks);
     NWS_CHECK_LAUNCH();
     return NWS_OK;
   }
