@@ -175,15 +175,20 @@ __device__ __forceinline__ void load_shaper_lds(ShaperLds& L, const NwsWeights& 
 // Exact shapers, bank form (kModeExactBank).  In the fused tail a lane holds 32 DIFFERENT shapers of one sample, so every
 // (sample, shaper) evaluation fetched its own 170 weights from LDS: 42 ds_read_b128 per evaluation, and the LDS return
 // path (not the sines) bounded the kernel.  Here the FiLM'ed shaper inputs of the workgroup's 128 samples go through LDS
-// once (xi[shaper][sample], 32 KB); then wave v evaluates shapers 16v .. 16v+15 with lane = sample, two samples per lane:
+// once (xi[shaper][sample]); then every wave evaluates its shapers with lane = sample, two samples per lane:
 // the shaper index is wave-uniform, its weights come from the nws_shaper_turns() table by SCALAR loads and feed the
 // VALU as SGPR operands - no LDS traffic for weights, no VGPRs for them either.  Per-wave partial sums of the 64 -> 1
 // mix meet in LDS.  Table row of shaper s (176 floats, every layer already times 1 / (2 pi)):
 //   [0,8) w0  [8,16) b0  [16,80) w2t[in][out]  [80,88) b2  [88,152) w4t[in][out]  [152,160) b4  [160,168) w6  168 b6  169 in_scale
+// LDS: the planes go where the mixer's fragment tables were (dead once the K loop is over) and hold ONE M-tile of the
+// accumulators at a time (32 shapers: 16.5 KB + the partial sums < the 28 KB of whi / wlo), two passes: the workgroup needs
+// the 38.8 KB of ExcLds and nothing else - 4 workgroups = 4 waves per SIMD on a CU.  (Round 4, up to here: all 64 shapers at
+// once in 35 KB BEHIND ExcLds = 74.6 KB per workgroup, i.e. two workgroups = 2 waves per SIMD for a kernel that is a chain
+// of quarter-rate sines and dependent packed FMAs.)
 // ---------------------------------------------------------------------------------------------
 constexpr int kBankRow = NWS_SHAPER_TURNS_ROW;
 struct BankLds {
-  float xi[kS][kTile + 4];   // +4: the two M-tile halves of a store instruction land in different banks
+  float xi[32][kTile + 4];   // +4: the two M-tile halves of a store instruction land in different banks
   float red[4][kTile];
 };
 
@@ -511,7 +516,7 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 // (0.328 ms).  (Wrong results seen with that build under two overlapping audio streams were first blamed on the scratch;
 // the multi-stream problem turned out to be independent of it, see pipeline.py.  The build still rejects scratch.)
 template <int MODE, int DBG = 0, int HPB = 1, int OPT = 0>
-__global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) ? 3 : ((OPT & kOptFilmMfma) ? 5 : ((OPT & kOptScalarSines) ? 6 : (HPB == 2 ? 7 : 5))))) void exciter_newt_kernel(NwsWeights w, const float* __restrict__ f0,
+__global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) ? 4 : ((OPT & kOptFilmMfma) ? 5 : ((OPT & kOptScalarSines) ? 6 : (HPB == 2 ? 7 : 5))))) void exciter_newt_kernel(NwsWeights w, const float* __restrict__ f0,
                                                            const float* __restrict__ f0_up,
                                                            const double* __restrict__ carry,
                                                            const float* __restrict__ phase_u,
@@ -985,6 +990,63 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
     if (half == 0) newt_out[(size_t)b * N + n] = add_in != nullptr ? add_in[(size_t)b * N + n] + total : total;
     return;
   }
+  if (is_bank(MODE)) {
+    static_assert(sizeof(BankLds) <= sizeof(L.whi) + sizeof(L.wlo), "the shaper-input planes take the place of the fragment tables");
+    BankLds& BK = *reinterpret_cast<BankLds*>(smem_raw);
+    const f32x2 w1_b = splat2(lc.w1);
+    // bank passes: lane = samples `lane` and 64 + `lane` of the hop (frame pairs (j-1, j) and (j, j+1))
+    const int n_a = jb * kTile + lane, n_b = n_a + 64;
+    const NwsLerp la = nws_lerp_coeff(n_a, T), lb = nws_lerp_coeff(n_b, T);
+    const int qa = la.i0 - (jb - 1), qb = lb.i0 - (jb - 1);
+    float pa = 0.0f, pb = 0.0f;
+    __syncthreads();   // every wave is through its K loop: whi / wlo are dead, the planes may be written
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      // FiLM'ed inputs of M-tile m (shapers 32 m .. 32 m + 31): accumulator registers 4g..4g+3 are shapers 32m + 8g + 4half + 0..3
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int s4 = 32 * m + 8 * g + 4 * half;
+        const float4 fa0 = *reinterpret_cast<const float4*>(&L.fa[q0][0][s4]), fd0 = *reinterpret_cast<const float4*>(&L.fd[q0][0][s4]);
+        const float4 fa1 = *reinterpret_cast<const float4*>(&L.fa[q0][1][s4]), fd1 = *reinterpret_cast<const float4*>(&L.fd[q0][1][s4]);
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int r0 = 4 * g + 2 * h2;
+          const f32x2 x2 = m == 0 ? f32x2{acc0[r0], acc0[r0 + 1]} : f32x2{acc1[r0], acc1[r0 + 1]};   // harmonic_mixer output, bias included
+          const f32x2 g_i = fma2(w1_b, h2 == 0 ? f32x2{fd0.x, fd0.y} : f32x2{fd0.z, fd0.w}, h2 == 0 ? f32x2{fa0.x, fa0.y} : f32x2{fa0.z, fa0.w});
+          const f32x2 b_i = fma2(w1_b, h2 == 0 ? f32x2{fd1.x, fd1.y} : f32x2{fd1.z, fd1.w}, h2 == 0 ? f32x2{fa1.x, fa1.y} : f32x2{fa1.z, fa1.w});
+          const f32x2 xi = fma2(g_i, x2, b_i);  // FiLM (models/modules/dynamic.py:8)
+          BK.xi[8 * g + 4 * half + 2 * h2][32 * w4 + col] = xi.x;
+          BK.xi[8 * g + 4 * half + 2 * h2 + 1][32 * w4 + col] = xi.y;
+        }
+      }
+      __syncthreads();
+      // wave v: shapers 32 m + 8 v .. + 7 of this pass
+      const int lv = __builtin_amdgcn_readfirstlane(8 * wave);
+#pragma unroll 1
+      for (int k = 0; k < 8; ++k) {
+        const int sh_idx = 32 * m + lv + k;
+        const float* __restrict__ W = bank + (size_t)sh_idx * kBankRow;   // a __restrict__ kernel argument: scalar loads
+        const float ya = bank_shaper<MODE == kModeExactBank>(W, BK.xi[lv + k][lane]);
+        const float yb = bank_shaper<MODE == kModeExactBank>(W, BK.xi[lv + k][64 + lane]);
+        pa = fmaf(fmaf(la.w1, L.fd[qa][2][sh_idx], L.fa[qa][2][sh_idx]), ya, pa);   // normalising FiLM gain x newt.mixer weight
+        pb = fmaf(fmaf(lb.w1, L.fd[qb][2][sh_idx], L.fa[qb][2][sh_idx]), yb, pb);
+      }
+      if (m == 0) __syncthreads();   // the planes of pass 0 have been read by everybody
+    }
+    BK.red[wave][lane] = pa;
+    BK.red[wave][64 + lane] = pb;
+    __syncthreads();
+    if (tid < kTile) {
+      const int n_o = jb * kTile + tid;
+      const NwsLerp lo = nws_lerp_coeff(n_o, T);
+      const int qo = lo.i0 - (jb - 1);
+      const float sum = (BK.red[0][tid] + BK.red[1][tid]) + (BK.red[2][tid] + BK.red[3][tid]);
+      const float bias_o = fmaf(lo.w1, L.bsum[qo + 1] - L.bsum[qo], L.bsum[qo]);
+      const float tot_o = sum + (bias_o + w.newt_out_b[0]);
+      newt_out[(size_t)b * N + n_o] = add_in != nullptr ? add_in[(size_t)b * N + n_o] + tot_o : tot_o;
+    }
+    return;
+  }
   const f32x2 w1_2 = splat2(lc.w1);
   f32x2 part2 = {0.0f, 0.0f};
   // accumulator registers 4g..4g+3 of M-tile m are the 4 consecutive shapers 32m + 8g + 4half + 0..3
@@ -1011,12 +1073,6 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
         const f32x2 g_n = fma2(w1_2, NWS_PAIR(fd[2]), NWS_PAIR(fa[2]));  // already times newt.mixer.weight
         const f32x2 xi = fma2(g_i, x2, b_i);  // FiLM (models/modules/dynamic.py:8)
         f32x2 sh;
-        if (is_bank(MODE)) {
-          BankLds& BK = *reinterpret_cast<BankLds*>(&SH);
-          BK.xi[s4 + 2 * h2][32 * w4 + col] = xi.x;
-          BK.xi[s4 + 2 * h2 + 1][32 * w4 + col] = xi.y;
-          continue;
-        }
         if (DBG == 2) {
           sh = xi;
         } else if (MODE == kModeLutPairsDiv6) {
@@ -1032,38 +1088,6 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
       // fence the scheduler per group of 4 shapers: bounded number of gathers / FiLM operands live at once
       __builtin_amdgcn_sched_barrier(0);
     }
-  }
-  if (is_bank(MODE)) {
-    BankLds& BK = *reinterpret_cast<BankLds*>(&SH);
-    __syncthreads();
-    // wave v: shapers 16v .. 16v+15; lane: samples `lane` and 64 + `lane` of the hop (frame pairs (j-1, j) and (j, j+1))
-    const int n_a = jb * kTile + lane, n_b = n_a + 64;
-    const NwsLerp la = nws_lerp_coeff(n_a, T), lb = nws_lerp_coeff(n_b, T);
-    const int qa = la.i0 - (jb - 1), qb = lb.i0 - (jb - 1);
-    const int sv = __builtin_amdgcn_readfirstlane(16 * wave);
-    float pa = 0.0f, pb = 0.0f;
-#pragma unroll 1
-    for (int k = 0; k < 16; ++k) {
-      const int sh_idx = sv + k;
-      const float* __restrict__ W = bank + (size_t)sh_idx * kBankRow;   // a __restrict__ kernel argument: scalar loads
-      const float ya = bank_shaper<MODE == kModeExactBank>(W, BK.xi[sh_idx][lane]);
-      const float yb = bank_shaper<MODE == kModeExactBank>(W, BK.xi[sh_idx][64 + lane]);
-      pa = fmaf(fmaf(la.w1, L.fd[qa][2][sh_idx], L.fa[qa][2][sh_idx]), ya, pa);   // normalising FiLM gain x newt.mixer weight
-      pb = fmaf(fmaf(lb.w1, L.fd[qb][2][sh_idx], L.fa[qb][2][sh_idx]), yb, pb);
-    }
-    BK.red[wave][lane] = pa;
-    BK.red[wave][64 + lane] = pb;
-    __syncthreads();
-    if (tid < kTile) {
-      const int n_o = jb * kTile + tid;
-      const NwsLerp lo = nws_lerp_coeff(n_o, T);
-      const int qo = lo.i0 - (jb - 1);
-      const float sum = (BK.red[0][tid] + BK.red[1][tid]) + (BK.red[2][tid] + BK.red[3][tid]);
-      const float bias_o = fmaf(lo.w1, L.bsum[qo + 1] - L.bsum[qo], L.bsum[qo]);
-      const float tot_o = sum + (bias_o + w.newt_out_b[0]);
-      newt_out[(size_t)b * N + n_o] = add_in != nullptr ? add_in[(size_t)b * N + n_o] + tot_o : tot_o;
-    }
-    return;
   }
   const float partial = part2.x + part2.y;
   // the normalising FiLM biases went through the mixer per FRAME: interpolate their sum like any other parameter
@@ -1406,11 +1430,14 @@ int nws_exciter_newt_add(const NwsWeights* w, const float* f0, const float* f0_u
                                                                sample_rate, exciter_out, newt_out, nullptr, add_in);
     } else {
       if (!w->shaper_w0 || !w->shaper_w2 || !w->shaper_w4 || !w->shaper_w6) return NWS_ERR_BAD_ARG;
+      // (measurements: NWS_EXCITER_BANK_LDS_PAD=<bytes> of unused LDS per workgroup lowers the bank kernel's occupancy -
+      // 35840 restores the two workgroups per CU it had while the shaper-input planes lived behind ExcLds)
+      static const size_t bank_pad = [] { const char* e = getenv("NWS_EXCITER_BANK_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
       if (w->shaper_turns != nullptr && (w->exciter_opts & NWS_EXCITER_BANK_NOFRACT))
-        exciter_newt_kernel<kModeExactBankNF><<<grid, 256, base + sizeof(BankLds), st>>>(
+        exciter_newt_kernel<kModeExactBankNF><<<grid, 256, base + bank_pad, st>>>(
             *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out, w->shaper_turns, add_in);
       else if (w->shaper_turns != nullptr)
-        exciter_newt_kernel<kModeExactBank><<<grid, 256, base + sizeof(BankLds), st>>>(
+        exciter_newt_kernel<kModeExactBank><<<grid, 256, base + bank_pad, st>>>(
             *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out, w->shaper_turns, add_in);
       else
         exciter_newt_kernel<kModeExact><<<grid, 256, base + sizeof(ShaperLds), st>>>(
