@@ -1414,7 +1414,9 @@ int nws_exciter_newt_add(const NwsWeights* w, const float* f0, const float* f0_u
         const int xcd_groups = xcd_map && (long long)groups * B >= 64 && (long long)groups * B < (1ll << 31) ? groups : 0;
         const dim3 g2 = xcd_groups ? dim3((unsigned)(groups * B), 1) : dim3(groups, B);
         const int opts = w->exciter_opts;
-#define NWS_HOT(O) exciter_newt_kernel<kModeLutPairsDiv6, 0, 2, O><<<g2, 512, base, st>>>( \
+        // (measurements: NWS_EXCITER_LDS_PAD=<bytes> of unused LDS per workgroup lowers the occupancy of the hot kernel)
+        static const size_t hot_pad = [] { const char* e = getenv("NWS_EXCITER_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
+#define NWS_HOT(O) exciter_newt_kernel<kModeLutPairsDiv6, 0, 2, O><<<g2, 512, base + hot_pad, st>>>( \
             *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out, nullptr, add_in, xcd_groups)
         if (opts & NWS_EXCITER_VALU_FILM) NWS_HOT(0);
         else if (opts & NWS_EXCITER_ONE_TERM) NWS_HOT(kOptFilmMfma | kOptOneTerm);
