@@ -42,9 +42,10 @@ enum Opt {
   kOptFilmMfma = 2,     // FiLM interpolation (3 parameter types x 64 shapers x 32 samples per wave) as six bf16 MFMAs
   kOptOneTerm = 4,      // sines as ONE fp16 term in EVERY K-step (drops W_hi * v_lo: 2 MFMAs per product; 11-bit activations)
   kOptHybrid = 8,       // two-term sines in K-step 0 (mixer bias + harmonics 1..15), one term in K-steps 1..6
-  kOptHybridW = 16      // with kOptHybrid: the mixer WEIGHTS of harmonics 16..101 as one fp16 term too (1 MFMA per product)
+  kOptHybridW = 16,     // with kOptHybrid: the mixer WEIGHTS of harmonics 16..101 as one fp16 term too (1 MFMA per product)
+  kOptLowReg = 32       // with kOptFilmMfma: the tail keeps at most two FiLM tiles live (80 VGPRs: three 8-wave workgroups per CU)
 };
-static_assert((kOptScalarSines ^ kOptFilmMfma ^ kOptOneTerm ^ kOptHybrid ^ kOptHybridW) == 31, "Opt bits must be distinct");
+static_assert((kOptScalarSines ^ kOptFilmMfma ^ kOptOneTerm ^ kOptHybrid ^ kOptHybridW ^ kOptLowReg) == 63, "Opt bits must be distinct");
 enum Mode { kModeLut = 0, kModeExact = 1, kModeExciterOnly = 2, kModeLutPairs = 3, kModeLutPairsDiv6 = 4, kModeExactBank = 5,
             kModeExactBankNF = 6 };   // NF: no v_fract in front of the sines of the hidden and output layers (NWS_EXCITER_BANK_NOFRACT)
 __host__ __device__ constexpr bool is_bank(int mode) { return mode == kModeExactBank || mode == kModeExactBankNF; }
@@ -516,7 +517,7 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 // (0.328 ms).  (Wrong results seen with that build under two overlapping audio streams were first blamed on the scratch;
 // the multi-stream problem turned out to be independent of it, see pipeline.py.  The build still rejects scratch.)
 template <int MODE, int DBG = 0, int HPB = 1, int OPT = 0>
-__global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) ? 4 : ((OPT & kOptFilmMfma) ? 5 : ((OPT & kOptScalarSines) ? 6 : (HPB == 2 ? 7 : 5))))) void exciter_newt_kernel(NwsWeights w, const float* __restrict__ f0,
+__global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) ? 4 : ((OPT & kOptLowReg) ? 6 : (OPT & kOptFilmMfma) ? 5 : ((OPT & kOptScalarSines) ? 6 : (HPB == 2 ? 7 : 5))))) void exciter_newt_kernel(NwsWeights w, const float* __restrict__ f0,
                                                            const float* __restrict__ f0_up,
                                                            const double* __restrict__ carry,
                                                            const float* __restrict__ phase_u,
@@ -956,6 +957,40 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
                                 : uint4{0u, 0u, 0u, 0u};       // K slots 8..15 unused: zero B, whatever A holds there
     const bf16x8 bfrag = __builtin_bit_cast(bf16x8, bop);
     float part = 0.0f;
+    if (OPT & kOptLowReg) {
+      // Register diet (93 -> <= 80 VGPRs: a third 8-wave workgroup fits a CU, 6 waves per SIMD instead of 4).  Same arithmetic,
+      // other order: the index FiLM of a whole M-tile first, IN PLACE of the accumulator tile (acc, G, Bb live: 48 + the other
+      // tile's 16), only then the gain tile Gn (its MFMA runs under the first gathers) and the lookups.
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        f32x16& acc = m == 0 ? acc0 : acc1;
+        {
+          const f32x16 G = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, L.ffrag[q0][0][m][col]), bfrag, f32x16{}, 0, 0, 0);
+          const f32x16 Bb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, L.ffrag[q0][1][m][col]), bfrag, f32x16{}, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = fmaf(G[r], acc[r], Bb[r]);   // FiLM in table units (bias and origin folded at staging)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x16 Gn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, L.ffrag[q0][2][m][col]), bfrag, f32x16{}, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 16 / kLutGroup; ++g) {
+          float fr[kLutGroup];
+          float2 tv[kLutGroup];
+#pragma unroll
+          for (int e = 0; e < kLutGroup; ++e) {
+            const int r = kLutGroup * g + e;
+            const float idx = acc[r];
+            const float fl = __builtin_amdgcn_fmed3f(floorf(idx), 0.0f, LF.top);
+            const unsigned o = lane_off_bytes + ((unsigned)(int)fl << 3);
+            fr[e] = idx - fl;
+            tv[e] = *reinterpret_cast<const float2*>(LF.pairs + (size_t)(32 * m + (r & 3) + 8 * (r >> 2)) * LF.row_bytes + o);
+          }
+#pragma unroll
+          for (int e = 0; e < kLutGroup; ++e) part = fmaf(Gn[kLutGroup * g + e], fmaf(tv[e].y, fr[e], tv[e].x), part);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const f32x16& acc = m == 0 ? acc0 : acc1;
@@ -1414,6 +1449,8 @@ int nws_exciter_newt_add(const NwsWeights* w, const float* f0, const float* f0_u
         const int xcd_groups = xcd_map && (long long)groups * B >= 64 && (long long)groups * B < (1ll << 31) ? groups : 0;
         const dim3 g2 = xcd_groups ? dim3((unsigned)(groups * B), 1) : dim3(groups, B);
         const int opts = w->exciter_opts;
+        // NWS_EXCITER_LOWREG=1: the 80-register form of the default kernel (kOptLowReg)
+        static const bool low_reg = [] { const char* e = getenv("NWS_EXCITER_LOWREG"); return e && e[0] == '1'; }();
         // (measurements: NWS_EXCITER_LDS_PAD=<bytes> of unused LDS per workgroup lowers the occupancy of the hot kernel)
         static const size_t hot_pad = [] { const char* e = getenv("NWS_EXCITER_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
 #define NWS_HOT(O) exciter_newt_kernel<kModeLutPairsDiv6, 0, 2, O><<<g2, 512, base + hot_pad, st>>>( \
@@ -1422,6 +1459,7 @@ int nws_exciter_newt_add(const NwsWeights* w, const float* f0, const float* f0_u
         else if (opts & NWS_EXCITER_ONE_TERM) NWS_HOT(kOptFilmMfma | kOptOneTerm);
         else if (opts & NWS_EXCITER_HYBRID_W) NWS_HOT(kOptFilmMfma | kOptHybrid | kOptHybridW);
         else if (opts & NWS_EXCITER_HYBRID) NWS_HOT(kOptFilmMfma | kOptHybrid);
+        else if (low_reg) NWS_HOT(kOptFilmMfma | kOptLowReg);
         else NWS_HOT(kOptFilmMfma);
 #undef NWS_HOT
       } else if (w->lut_pairs != nullptr)
