@@ -1449,16 +1449,17 @@ int nws_exciter_newt_add(const NwsWeights* w, const float* f0, const float* f0_u
         const int xcd_groups = xcd_map && (long long)groups * B >= 64 && (long long)groups * B < (1ll << 31) ? groups : 0;
         const dim3 g2 = xcd_groups ? dim3((unsigned)(groups * B), 1) : dim3(groups, B);
         const int opts = w->exciter_opts;
-        // NWS_EXCITER_LOWREG=1: the 80-register form of the default kernel (kOptLowReg)
-        static const bool low_reg = [] { const char* e = getenv("NWS_EXCITER_LOWREG"); return e && e[0] == '1'; }();
+        // the 80-register tail (kOptLowReg: three workgroups per CU) is the default; NWS_EXCITER_LOWREG=0 keeps the 93-register
+        // one (measurements: same results, 3 % slower alone, 6 % slower on realistic F0)
+        static const bool low_reg = [] { const char* e = getenv("NWS_EXCITER_LOWREG"); return !(e && e[0] == '0'); }();
         // (measurements: NWS_EXCITER_LDS_PAD=<bytes> of unused LDS per workgroup lowers the occupancy of the hot kernel)
         static const size_t hot_pad = [] { const char* e = getenv("NWS_EXCITER_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
 #define NWS_HOT(O) exciter_newt_kernel<kModeLutPairsDiv6, 0, 2, O><<<g2, 512, base + hot_pad, st>>>( \
             *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out, nullptr, add_in, xcd_groups)
         if (opts & NWS_EXCITER_VALU_FILM) NWS_HOT(0);
-        else if (opts & NWS_EXCITER_ONE_TERM) NWS_HOT(kOptFilmMfma | kOptOneTerm);
-        else if (opts & NWS_EXCITER_HYBRID_W) NWS_HOT(kOptFilmMfma | kOptHybrid | kOptHybridW);
-        else if (opts & NWS_EXCITER_HYBRID) NWS_HOT(kOptFilmMfma | kOptHybrid);
+        else if (opts & NWS_EXCITER_ONE_TERM) { if (low_reg) NWS_HOT(kOptFilmMfma | kOptOneTerm | kOptLowReg); else NWS_HOT(kOptFilmMfma | kOptOneTerm); }
+        else if (opts & NWS_EXCITER_HYBRID_W) { if (low_reg) NWS_HOT(kOptFilmMfma | kOptHybrid | kOptHybridW | kOptLowReg); else NWS_HOT(kOptFilmMfma | kOptHybrid | kOptHybridW); }
+        else if (opts & NWS_EXCITER_HYBRID) { if (low_reg) NWS_HOT(kOptFilmMfma | kOptHybrid | kOptLowReg); else NWS_HOT(kOptFilmMfma | kOptHybrid); }
         else if (low_reg) NWS_HOT(kOptFilmMfma | kOptLowReg);
         else NWS_HOT(kOptFilmMfma);
 #undef NWS_HOT

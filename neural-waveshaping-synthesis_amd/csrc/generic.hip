@@ -1561,6 +1561,15 @@ static int g_exciter_newt_fused(const NwsGenericModel* m, const float* f0_up, co
       const size_t frames = (size_t)(128 * t / m->hop + 3);
       return ((size_t)K16 * MT * 512 + 16 * K16 + 5 * (size_t)SBM + (exc_only ? 0 : (size_t)8 * SBM * frames)) * sizeof(float);
     };
+    // FOUR workgroups per CU when fewer tiles per wave allow it (120 registers permit 4 waves per SIMD; the fragments alone
+    // are 28 KB at the default sizes: 44.7 KB = 3 workgroups with four tiles per wave, 40.6 KB = 4 with two), else two.
+    // NWS_G_TILE_LDS=<bytes> moves the first limit (measurements; 81920 = the rule before)
+    static const size_t lds_goal = [] { const char* e = getenv("NWS_G_TILE_LDS"); return e ? (size_t)atoi(e) : (size_t)40960; }();
+    {
+      int t4 = tpw;
+      while (t4 > 1 && lds_of(t4) > lds_goal) t4 >>= 1;
+      if (lds_of(t4) <= lds_goal) tpw = t4;
+    }
     while (tpw > 1 && lds_of(tpw) > 80 * 1024) tpw >>= 1;     // two workgroups per CU
     const int nf = 128 * tpw / m->hop + 3;
     const size_t lds = lds_of(tpw);
