@@ -137,6 +137,43 @@ def check_valu_mfma_hazard(obj, wait_states=2):
     return found
 
 
+# Register budgets that decide how many workgroups a CU holds (round 4: the oscillator kernel at 93 VGPRs ran TWO 8-wave
+# workgroups per CU although the resource remark said "5 waves per SIMD" - a workgroup brings 2 waves per SIMD, so the steps are
+# 4 / 6 / 8 waves = 128 / 80 / 64 registers; the third workgroup was worth 3-6 %).  (substring of the mangled kernel name,
+# largest VGPR + AGPR count, what it buys); a kernel that outgrows its line fails the build instead of silently losing occupancy.
+REGISTER_BUDGETS = (
+    ("exciter_newt_kernelILi4ELi0ELi2ELi34E", 80, "default oscillator kernel: three 8-wave workgroups per CU"),
+    ("exciter_newt_kernelILi4ELi0ELi2ELi38E", 80, "one-term variant: three 8-wave workgroups per CU"),
+    ("exciter_newt_kernelILi4ELi0ELi2ELi42E", 80, "hybrid variant: three 8-wave workgroups per CU"),
+    ("exciter_newt_kernelILi4ELi0ELi2ELi58E", 80, "hybrid-W variant: three 8-wave workgroups per CU"),
+    ("exciter_newt_kernelILi5ELi0ELi1ELi0E", 128, "exact-shaper bank kernel: four 4-wave workgroups per CU (38.8 KB of LDS each)"),
+    ("exciter_newt_kernelILi6ELi0ELi1ELi0E", 128, "exact-shaper bank kernel (no v_fract): four 4-wave workgroups per CU"),
+    ("g_exciter_newt_mfma_kernel", 128, "runtime-size oscillator kernel: four 4-wave workgroups per CU"),
+)
+
+
+def kernel_registers(remarks):
+    """{mangled kernel name: VGPRs + AGPRs} from hipcc's -Rpass-analysis=kernel-resource-usage output"""
+    regs, name = {}, None
+    for line in remarks.splitlines():
+        if "Function Name:" in line:
+            name = line.split("Function Name:")[1].split("[-Rpass")[0].strip()
+            regs[name] = 0
+        elif name is not None and (" VGPRs:" in line or " AGPRs:" in line) and "Spill" not in line:
+            regs[name] += int(line.split("GPRs:")[1].split()[0])
+    return regs
+
+
+def check_register_budgets(remarks, budgets=None):
+    """[(kernel, registers, budget, reason), ...] for every kernel of `remarks` that exceeds its line of REGISTER_BUDGETS"""
+    over = []
+    for kernel, n in kernel_registers(remarks).items():
+        for key, budget, why in (REGISTER_BUDGETS if budgets is None else budgets):
+            if key in kernel and n > budget:
+                over.append((kernel, n, budget, why))
+    return over
+
+
 def build_torch_ops(force=False, verbose=True):
     """torch.ops.newt_hip.*: one host-only translation unit (no kernels) compiled with g++ against the torch headers and linked
     to libnws_hip.so next to it.  Needs an importable torch; returns None (with a note) when there is none - the ctypes
@@ -208,6 +245,10 @@ def build_hip(force=False, verbose=True):
                 rest.append(line)
         if spilled:
             raise RuntimeError(f"{src}: kernels using scratch memory (spills or stack): {spilled}")
+        over = check_register_budgets(r.stderr)
+        if over:
+            lines = "\n".join(f"  {k}: {n} registers > {b} ({why})" for k, n, b, why in over)
+            raise RuntimeError(f"{src}: kernels over their register budget (REGISTER_BUDGETS: workgroups per CU):\n{lines}")
         swz = check_packed_swizzles(obj)
         if swz:
             lines = "\n".join(f"  {k}: {i}" for k, i in swz[:12])

@@ -321,6 +321,43 @@ def test_build_guard_finds_valu_writes_in_front_of_matrix_reads():
     assert [k for k, _, _ in found] == ["bad_kernel"] and "v_fma_mixhi_f16 v127" in found[0][1], found
 
 
+def test_build_guard_register_budgets():
+    """Third guard of build.py (round 4): kernels whose register count decides how many workgroups a CU holds have a budget; a
+    build that outgrows it fails instead of silently dropping a workgroup (the oscillator kernel ran two instead of three
+    8-wave workgroups per CU at 93 registers).  Parses hipcc's resource remarks; sees an overrun in a listing that has one, and
+    every budgeted kernel of the real build is found and inside its line."""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location("nws_build", os.path.join(ROOT, "neural-waveshaping-synthesis_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    remarks = """
+x.hip:1:1: remark: Function Name: _ZN3foo19exciter_newt_kernelILi4ELi0ELi2ELi34EEEvPf [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     TotalSGPRs: 43 [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     VGPRs: 93 [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     AGPRs: 0 [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     VGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark: Function Name: _ZN3foo26g_exciter_newt_mfma_kernelILi2ELi1EEEvPf [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     VGPRs: 96 [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     AGPRs: 32 [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark: Function Name: _ZN3foo12other_kernelEvPf [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     VGPRs: 250 [-Rpass-analysis=kernel-resource-usage]
+"""
+    assert b.kernel_registers(remarks) == {"_ZN3foo19exciter_newt_kernelILi4ELi0ELi2ELi34EEEvPf": 93,
+                                           "_ZN3foo26g_exciter_newt_mfma_kernelILi2ELi1EEEvPf": 128, "_ZN3foo12other_kernelEvPf": 250}
+    over = b.check_register_budgets(remarks)
+    assert [("exciter_newt_kernelILi4ELi0ELi2ELi34E" in k, n, bud) for k, n, bud, _ in over] == [(True, 93, 80)], over
+    # the real translation units: every budget line matches at least one kernel, and none is exceeded
+    seen = set()
+    for src in ("exciter_newt.hip", "generic.hip"):
+        cmd = [b._hipcc(), *b.FLAGS, *b.EXTRA_FLAGS.get(src, []), "-c", os.path.join(b.CSRC, src), "-o", os.devnull]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert b.check_register_budgets(r.stderr) == [], src
+        seen |= {key for key, _, _ in b.REGISTER_BUDGETS for k in b.kernel_registers(r.stderr) if key in k}
+    assert seen == {key for key, _, _ in b.REGISTER_BUDGETS}, seen
+
+
 def test_precision_rule_is_a_worst_case_bound_from_the_weights():
     """Engine.exciter_opts' automatic choice (precision.hybrid_w_error_bound): host logic, no GPU.  The shipped checkpoint's bound
     is far above 1e-5 (-> every mixer product two-term); it scales linearly with ||ir||_1 and with the high-harmonic weights
