@@ -28,8 +28,9 @@ __global__ __launch_bounds__(256) void td_mlp_kernel(MlpArgs a, const float* __r
                                                      int out_size, int depth, int T, float eps, float slope,
                                                      float* __restrict__ y) {
   extern __shared__ float lds[];
-  int maxw = in_size > hidden ? in_size : hidden;
-  maxw = maxw > out_size ? maxw : out_size;
+  // (the last layer's outputs leave from the accumulators: the planes hold inputs and hidden activations only, so a 128 -> 256
+  // output layer does not halve the workgroups per CU - 35.8 instead of 69.6 KB at the default sizes, 4 instead of 2)
+  const int maxw = in_size > hidden ? in_size : hidden;
   float* bufA = lds;                       // [maxw][33]
   float* bufB = lds + (size_t)maxw * 33;   // [maxw][33]
   float* red = bufB + (size_t)maxw * 33;   // [2][8][32]
@@ -87,18 +88,23 @@ __global__ __launch_bounds__(256) void td_mlp_kernel(MlpArgs a, const float* __r
 #pragma unroll
         for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2], acc, 0, 0, 0);
       }
+      if (last) {
+        // accumulator register r of lane (col, half) = channel 32 mt + row(r, half), frame t0 + col: 32 lanes = 128 contiguous bytes
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c = 32 * mt + td_frag_row(r, half);
-        if (c < cout) nxt[c * 33 + col] = acc[r] + bias[c];
+        for (int r = 0; r < 16; ++r) {
+          const int c = 32 * mt + td_frag_row(r, half);
+          if (c < cout && live) y[((size_t)b * out_size + c) * T + t] = acc[r] + bias[c];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = 32 * mt + td_frag_row(r, half);
+          if (c < cout) nxt[c * 33 + col] = acc[r] + bias[c];
+        }
       }
     }
+    if (last) break;
     __syncthreads();
-    if (last) {
-      for (int c = cg; c < cout; c += 8)
-        if (live) y[((size_t)b * out_size + c) * T + t] = nxt[c * 33 + f];
-      break;
-    }
     // LayerNorm over the `hidden` channels of frame f: mean, then variance about the mean (two passes, like ATen)
     float s1 = 0.0f;
     for (int c = cg; c < cout; c += 8) s1 += nxt[c * 33 + f];
@@ -203,8 +209,7 @@ int nws_td_mlp(const float* x, int B, int in_size, int hidden, int out_size, int
       a.ln_b[i] = ln_b[i];
     }
   }
-  int maxw = in_size > hidden ? in_size : hidden;
-  maxw = maxw > out_size ? maxw : out_size;
+  const int maxw = in_size > hidden ? in_size : hidden;     // (the output layer stores from registers: see the kernel)
   const size_t lds = ((size_t)2 * maxw * 33 + 512) * sizeof(float);
   if (lds > 160 * 1024) return NWS_ERR_UNSUPPORTED;   // layer widths up to ~600
   static unsigned long long attr_devices = 0;
