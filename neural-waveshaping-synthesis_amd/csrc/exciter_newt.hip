@@ -1514,6 +1514,8 @@ int nws_debug_exciter_newt(int variant, const NwsWeights* w, const float* f0, co
       case 6: NWS_OPT_LAUNCH(6); break;
       case 10: NWS_OPT_LAUNCH(10); break;
       case 26: NWS_OPT_LAUNCH(26); break;
+      case 34: NWS_OPT_LAUNCH(34); break;   // kOptFilmMfma | kOptLowReg: the default kernel
+      case 58: NWS_OPT_LAUNCH(58); break;   // ... | kOptHybrid | kOptHybridW | kOptLowReg: the opt-in hybrid-W kernel
       default: return NWS_ERR_BAD_ARG;
     }
     NWS_CHECK_LAUNCH();

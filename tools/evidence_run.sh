@@ -10,7 +10,7 @@ python bench.py --no-cpu-baseline --inputs realistic --legs 0 --pmc off > gpurun
 python bench.py --no-cpu-baseline --exact --steps 50 --legs 0 --pmc off > gpurun_out/ev/bench_exact_shapers.json 2>/dev/null
 NWS_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --pmc off --gather rccl > gpurun_out/ev/bench_world1_rccl.json 2>/dev/null
 NWS_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --pmc off --gather copy > gpurun_out/ev/bench_world1_copy.json 2>/dev/null
-VARIANTS=12,20,36 python tools/exciter_variants.py > gpurun_out/ev/exciter_variants.txt 2>&1
+VARIANTS=12,44,36,68 python tools/exciter_variants.py > gpurun_out/ev/exciter_variants.txt 2>&1
 python tools/gru_variants.py > gpurun_out/ev/gru_variants.txt 2>&1
 python scripts/time_buffer_sizes.py --use-fast-newt --checkpoint tests/golden/weights_vn.npz 2>/dev/null | grep '^buffer' > gpurun_out/ev/buffer_fast.txt
 python scripts/time_buffer_sizes.py --checkpoint tests/golden/weights_vn.npz 2>/dev/null | grep '^buffer' > gpurun_out/ev/buffer_exact.txt

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Timing + agreement of the fused oscillator/NEWT kernel's compile-time options (nws_debug_exciter_newt variants 10 + OPT
-bits: 1 scalar sines, 2 FiLM interpolation on the matrix pipe, 4 one-term fp16 sines) at B=64, T=500.  GPU only."""
+bits: 1 scalar sines, 2 FiLM interpolation on the matrix pipe, 4 one-term fp16 sines, 8 + 16 hybrid products, 32 the 80-register
+tail; 12 = the round-3 default, 44 = the default, 36 / 68 = the hybrid-W opt-in without / with the 80-register tail) at B=64, T=500.  GPU only."""
 import ctypes as C
 import importlib
 import os
@@ -16,7 +17,7 @@ nws.ensure_default_config()
 m = nws.NeuralWaveshaping.load_from_checkpoint(os.path.join(ROOT, "tests/golden/weights_vn.npz")).cuda().eval()
 m.newt = nws.FastNEWT(m.newt)
 B, T = int(os.environ.get("B", 64)), int(os.environ.get("T", 500))
-variants = [int(v) for v in os.environ.get("VARIANTS", "12,20,36").split(",")]
+variants = [int(v) for v in os.environ.get("VARIANTS", "12,44,36,68").split(",")]
 eng = m._engine
 w, _, _ = eng.weights()
 for kind in ("rand", "real"):
