@@ -405,6 +405,10 @@ struct ExcLds {
   float kf[kKPad];              // (float)c: harmonic numbers as packed-FMA operands, read instead of computed
 };
 
+// LDS budget behind the occupancy figures: ExcLds is ALL the dynamic LDS of the hot kernel (three 8-wave workgroups
+// per CU = 116 KB) and of the exact-shaper bank kernel (four 4-wave workgroups = 155 KB of the 160 KB)
+static_assert(sizeof(ExcLds) <= 40960, "ExcLds above 40 KB: the bank kernel drops from four to three workgroups per CU");
+
 // Where K slot kk of shaper s lives in the fragment tables (units: halfs).  K-steps 0..5 are v_mfma_f32_32x32x16_f16
 // fragments (lane (i, h) holds slots 16 ks + 8 h + 0..7); the remainder - slots 96..103: harmonics 96..101 and two zero
 // slots - is ONE v_mfma_f32_32x32x8_f16 step (lane (i, h) holds slots 96 + 4 h + 0..3, the first 8 bytes of a 16-byte
