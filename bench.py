@@ -26,7 +26,7 @@ import time
 # the pipeline keeps 2 audio + 1 control stream busy next to torch's default stream and, for N > 1, RCCL's own streams; HIP maps
 # streams onto 4 hardware queues by default and streams that share a queue serialise (measured: 0.75 vs 0.59 ms per step with
 # RCCL initialised).  Must be set before the HIP runtime starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL / peer-mapped buffers across processes
 
 import numpy as np  # noqa: E402
@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--gather-chunks", type=int, default=1,
                     help="N > 1: push the rendered waveforms in this many sub-batches (4 = 4 x 16 utterances), each as soon as ITS "
                          "reverb has been enqueued, instead of one all-gather after the whole batch (SURVEY 8(e))")
+    ap.add_argument("--gather-slots", type=int, default=8,
+                    help="N > 1: gather buffers in rotation (>= the workspace ring); the submitting thread runs at most this many "
+                         "batches ahead of the GPU, because a buffer is only free once its exchange has been issued")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="time budget of the cpu_baseline leg")
     ap.add_argument("--batch1-iters", type=int, default=200)
@@ -462,96 +465,115 @@ def main():
                                     audio_streams=len(streams), control_streams=n_control, batched_gru=a.gru == "batched",
                                     chain_exciters=bool(a.chain_exciters))
         streams = pipe.audio
-    nbuf = len(pipe.slots) if use_pipe else len(streams)
+    # gather buffers: a ring of its own (not the workspace ring): a buffer is free again once its exchange is out, and the
+    # submitting thread may run at most this many batches ahead of the GPU (parallel.CompletionDrivenExchange)
+    nbuf = max(len(pipe.slots), a.gather_slots) if (use_pipe and distributed) else (len(pipe.slots) if use_pipe else len(streams))
     full, peer = None, None
     gather_kind = a.gather if distributed else None
     if distributed and (a.gather == "copy" or share_gpu):
         # copy-engine all-gather: peer-mapped gather buffers, one device-to-device copy per peer (also the only form that
         # works for two smoke-test ranks on ONE device, where RCCL refuses to initialise)
-        peer = par.PeerCopyAllGather(B, N, dev, nbuf=nbuf)
+        peer = par.PeerCopyAllGather(B, N, dev, nbuf=nbuf, sync_signal=use_pipe)
         full = peer.full
         gather_kind = "copy"
     elif distributed:
         full = [torch.empty((B * world, N), dtype=torch.float32, device=dev) for _ in range(nbuf)]
 
-    class _Works:      # several collectives of one step behind the single handle the loop carries
-        def __init__(self, works):
-            self.works = [w for w in works if w is not None]
-
-        def wait(self):
-            for w in self.works:
-                w.wait()
-
     blocks = pmod.ForwardPipeline.row_blocks(B, a.gather_chunks) if (distributed and use_pipe) else None
+    # N > 1 with the pipeline: every exchange is issued by a helper thread, on its own stream, once the HOST has seen its batch
+    # complete (no hardware queue parked on a cross-queue barrier: +30 % per step with nothing to send otherwise, LABBOOK round 5)
+    xchg = par.CompletionDrivenExchange(dev, nbuf, stream=pipe.exchange) if (distributed and use_pipe) else None
+    DIAG = set(filter(None, os.environ.get("NWS_BENCH_DIAG", "").split(",")))     # diagnosis switches (tools/world1_diag.sh)
+    fake_side = torch.cuda.Stream(device=dev) if "queued" in DIAG else None
 
-    slot_work = [None] * max(1, nbuf)       # last exchange that wrote each gather buffer
+    if xchg is not None and "wprof" in DIAG:
+        xchg.profile = []
+    tiny = [torch.zeros(64, device=dev) for _ in range(3)]
 
-    def gather_rows(i, y, row0, n):
-        """rows [row0, row0 + n) of this step's waveforms to every rank, on the CURRENT stream"""
+    def issue_whole(i, y):
+        """worker thread, exchange stream current: this step's waveforms to every rank (the timed loop never reads the gathered
+        rows, so a peer-copy slot is released at once)"""
+        if peer is not None:
+            peer.gather(y, i % nbuf)
+            peer.release(i % nbuf)
+        else:
+            par.gather_full(full[i % nbuf], y, async_op=False)        # sync op = launched on the current (exchange) stream
+
+    def issue_block(i, y, row0, n, last):
+        """worker thread: rows [row0, row0 + n) of this step's waveforms to every rank"""
         if peer is not None:
             peer.push_rows(y, i % nbuf, row0, n)
-            return None
-        return par.gather_row_block(full[i % nbuf], y, row0, n)
+            if last:
+                peer.finish(i % nbuf)
+                peer.release(i % nbuf)
+        else:
+            par.gather_row_block(full[i % nbuf], y, row0, n, async_op=False)
+
+    def post_behind(stream, slot_i, issue):
+        """the exchange `issue` leaves once everything enqueued on `stream` so far is complete"""
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        if "noexch" in DIAG:      # diagnosis: the mechanism alone (events, helper thread), nothing issued
+            xchg.post(slot_i, ev, lambda: None)
+            return
+        if "blit3" in DIAG:       # diagnosis: three tiny launches on the exchange stream in place of the collective
+            def blits():
+                tiny[0].fill_(0.0)
+                tiny[1].fill_(1.0)
+                tiny[2].copy_(tiny[0])
+            xchg.post(slot_i, ev, blits)
+            return
+        if "queued" in DIAG:      # diagnosis: the round-4 form, a device-side wait on a side queue (what costs +30 %)
+            fake_side.wait_event(ev)
+            with torch.cuda.stream(fake_side):
+                issue()
+            return
+        xchg.post(slot_i, ev, issue)
 
     def gather(i, y):
-        """all-gather of this step's waveforms on the CURRENT stream; returns a work handle (or None)"""
-        if blocks is not None:      # (compute skipped: the same sub-batch messages, back to back)
-            works = [gather_rows(i, y, r0, n) for r0, n in blocks]
-            return peer_finish(i) if peer is not None else _Works(works)
+        """(whole forwards round-robin, --pipeline 0) all-gather of this step's waveforms on the CURRENT stream; work handle"""
         if peer is not None:
             work = peer.gather(y, i % nbuf)[1]
             peer.release(i % nbuf)
             return work
         return par.gather_full(full[i % nbuf], y)
 
-    def peer_finish(i):
-        """completion signal of a sub-batch exchange; the loop never reads the gathered rows, so the slot is released at once"""
-        work = peer.finish(i % nbuf)[1]
-        peer.release(i % nbuf)
-        return work
-
-    def step(i, pending, do_gather=True, do_compute=True):
+    def step(i, pending, do_gather=True, do_compute=True, plain=False):
         if use_pipe:
-            if not distributed:
-                pipe.submit(f0, control)
+            if not distributed or plain:
+                pipe.submit(f0, control)        # the single-GPU issue pattern (also timed beside the N > 1 one: world1_overhead)
                 return None
-            # the audio stream submit() is about to use for this batch (gather-only steps just alternate)
-            au = pipe.next_audio_stream() if do_compute else pipe.audio[i % len(pipe.audio)]
-            y = None
-            if do_compute:
-                # the two draws inside submit(), from the generator every rank seeded identically (SURVEY 8(e)): the same
-                # issue pattern as the single-GPU run, nothing but the exchange added
-                if blocks is not None and do_gather:
-                    # sub-batch exchange: block q leaves for the peers as soon as ITS reverb is enqueued (on the audio stream,
-                    # inside submit), under the reverb of block q + 1; the previous step's exchange is waited for first
-                    works = []
+            slot_i = i % nbuf
+            if not do_compute:
+                # exchange alone: a resident (B, N) shard leaves every step, same messages, nothing to wait for
+                xchg.acquire(slot_i)
+                if blocks is not None:
+                    for row0, n in blocks:
+                        xchg.post(slot_i, None, lambda _i=i, _r=row0, _n=n: issue_block(_i, gather_src, _r, _n, _r + _n == B))
+                else:
+                    xchg.post(slot_i, None, lambda _i=i: issue_whole(_i, gather_src))
+                return None
+            au = pipe.next_audio_stream()       # the audio stream submit() is about to use for this batch
+            # the gather buffer is free once ITS previous exchange is out: the host waits until that one has been issued (i.e. its
+            # batch was complete), the audio stream waits for its completion (usually long over: a satisfied wait)
+            with torch.cuda.stream(au):
+                xchg.acquire(slot_i, au)
+                dst = peer.local_rows(slot_i) if peer is not None else full[slot_i][rank * B:(rank + 1) * B]
+            # the two draws inside submit(), from the generator every rank seeded identically (SURVEY 8(e)): the same issue
+            # pattern as the single-GPU run, nothing but the exchange added
+            if blocks is not None and do_gather:
+                # sub-batch exchange: block q leaves as soon as the host has seen ITS reverb complete, under the reverb of
+                # block q + 1 (rendered into a batch of its own: the list-of-views all_gather must not alias its input)
+                def on_block(row0, n, out, _i=i, _slot=slot_i, _au=au):
+                    post_behind(_au, _slot, lambda: issue_block(_i, out, row0, n, row0 + n == B))
 
-                    def on_block(row0, n, out, _i=i, _works=works, _pending=pending):
-                        if row0 == blocks[0][0] and _pending is not None:
-                            _pending.wait()
-                        _works.append(gather_rows(_i, out, row0, n))
-
-                    pipe.submit(f0, control, generator=shared_gen, row_blocks=blocks, on_block=on_block)
-                    with torch.cuda.stream(au):
-                        return peer_finish(i) if peer is not None else _Works(works)
-                # the batch is rendered straight into this rank's rows of the gather buffer (no local copy: the all-gather is
-                # in place for RCCL, the peer pushes skip the local shard); the slot's previous exchange is complete - the
-                # audio stream waited for a later one already - and the explicit wait below costs nothing then
-                slot_i = i % nbuf
-                with torch.cuda.stream(au):
-                    if slot_work[slot_i] is not None:
-                        slot_work[slot_i].wait()
-                        slot_work[slot_i] = None
-                    dst = peer.local_rows(slot_i) if peer is not None else full[slot_i][rank * B:(rank + 1) * B]
-                y = pipe.submit(f0, control, generator=shared_gen, out=dst)
-            with torch.cuda.stream(au):                 # ordered after this batch's reverb
-                # (the audio stream does NOT wait for the previous exchange: collectives are ordered among themselves on RCCL's
-                # stream, the peer pushes by PeerCopyAllGather's claim, and a gather buffer is only rendered into again after
-                # the slot's own exchange, slot_work above - so a slow exchange delays exchanges, not oscillator kernels)
-                if do_gather:
-                    work = gather(i, y if y is not None else gather_src)
-                    slot_work[i % nbuf] = work
-                    return work
+                pipe.submit(f0, control, generator=shared_gen, row_blocks=blocks, on_block=on_block)
+                return None
+            # the batch is rendered straight into this rank's rows of the gather buffer (no local copy: the all-gather is
+            # in place for RCCL, the peer pushes skip the local shard)
+            y = pipe.submit(f0, control, generator=shared_gen, out=dst)
+            if do_gather:
+                post_behind(au, slot_i, lambda _i=i, _y=y: issue_whole(_i, _y))
             return None
         s = streams[i % len(streams)]
         with torch.cuda.stream(s):
@@ -574,6 +596,8 @@ def main():
         for s in streams:
             torch.cuda.current_stream().wait_stream(s)
 
+    host_issue = {}
+
     def timed(n_steps, **kw):
         """n_steps of the issue pattern, bracketed by barrier + synchronize on both sides; seconds, max over ranks"""
         pending = None
@@ -581,13 +605,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        prof = None
+        if os.environ.get("NWS_BENCH_CPROFILE") == "1":      # diagnosis: where the host's time per step goes
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         for i in range(n_steps):
             pending = step(i, pending, **kw)
+        host_issue["s_per_step"] = (time.perf_counter() - t0) / max(1, n_steps)   # host time to ENQUEUE a step (no sync inside)
+        if prof is not None:
+            import pstats
+            prof.disable()
+            pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
         if pending is not None:
             pending.wait()
+        if xchg is not None:
+            xchg.drain()                    # every exchange issued and complete
         join_streams()
         torch.cuda.synchronize()
-        el = time.perf_counter() - t0      # this rank's K steps, from the common start to its own last kernel
+        el = time.perf_counter() - t0      # this rank's K steps, from the common start to its own last exchange
         if distributed:
             dist.barrier()                  # (the closing barrier itself - a collective launch and a host synchronise - is not
         per_rank = [el]                     # part of any rank's steps: the job's time is the MAX over ranks, taken below)
@@ -613,11 +649,18 @@ def main():
             pending = step(i, pending)
         if pending is not None:
             pending.wait()
+        if xchg is not None:
+            xchg.drain()
         join_streams()
         torch.cuda.synchronize()
         # live HIP-event timing of the dominant kernel (and the GRU) on their launch streams, inside the timed region
         _lib.check(_lib.lib().nws_profile_begin(a.steps, (1 << 3) | (1 << 1)))
         elapsed, per_rank = timed(a.steps)
+        extra["host_issue_ms_per_step"] = round(host_issue["s_per_step"] * 1e3, 4)
+        if xchg is not None and xchg.profile:
+            pr = np.array(xchg.profile[-a.steps:]) * 1e6
+            extra["exchange_worker_us"] = {"wait_p50": float(np.median(pr[:, 0])), "issue_p50": float(np.median(pr[:, 1])),
+                                           "record_p50": float(np.median(pr[:, 2])), "issue_mean": float(pr[:, 1].mean())}
         ms = (C.c_float * (a.steps * 6))()
         n = C.c_int(0)
         _lib.check(_lib.lib().nws_profile_collect(ms, C.byref(n)))
@@ -629,18 +672,44 @@ def main():
             # the gathered batch must hold every rank's rows (rank r at rows [r*B, (r+1)*B))
             last = full[(a.steps - 1) % nbuf]
             assert torch.isfinite(last).all() and float(last[B * (world - 1):].abs().max()) > 0.0
-            # exchange and compute told apart (outside the headline region, same issue pattern): the all-gather alone
-            # (compute skipped: a resident (B, N) shard is gathered every step) and the compute alone (no gather)
-            k2 = max(10, min(a.steps, 100))
-            g_el, g_ranks = timed(k2, do_compute=False)
-            c_el, c_ranks = timed(k2, do_gather=False)
+            # exchange and compute told apart (outside the headline region; every region primed by a few untimed steps of its own
+            # kind and as long as the headline's, so that fill / drain weigh the same): the all-gather alone (compute skipped: a
+            # resident (B, N) shard leaves every step), the N > 1 issue pattern without its exchange, and the plain single-GPU
+            # issue pattern (no shared generator, no gather buffer) - what this rank would do alone
+            k2 = max(10, min(a.steps, 200))
+
+            def region(**kw):
+                for j in range(8):
+                    step(j, None, **kw)
+                if xchg is not None:
+                    xchg.drain()
+                join_streams()
+                return timed(k2, **kw)
+
+            if use_pipe and "plainfirst" in DIAG:
+                extra["plain_first_ms"] = region(plain=True)[0] / k2 * 1e3
+            g_el, g_ranks = region(do_compute=False)
+            c_el, c_ranks = region(do_gather=False)
             extra["exchange"] = {"kind": gather_kind, "chunks": len(blocks) if blocks else 1,
+                                 "issue": ("completion-driven: a helper thread issues each batch's exchange on its own stream once "
+                                           "the host has seen the batch complete (parallel.CompletionDrivenExchange)") if xchg is not None
+                                 else "stream-ordered behind each forward",
+                                 "gather_slots": nbuf,
                                  # 1.0 = the exchange is completely hidden under the compute of the neighbouring steps
                                  "overlap_efficiency": (c_el / k2) / (elapsed / a.steps),
                                  "gather_ms": g_el / k2 * 1e3, "compute_only_ms": c_el / k2 * 1e3,
                                  "steps": k2, "bytes_gathered_per_rank_per_step": B * world * N * 4,
                                  "gather_ms_per_rank": [round(t / k2 * 1e3, 4) for t in g_ranks],
-                                 "compute_only_ms_per_rank": [round(t / k2 * 1e3, 4) for t in c_ranks]}
+                                 "compute_only_ms_per_rank": [round(t / k2 * 1e3, 4) for t in c_ranks],
+                                 "rccl_world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                                 "device_of_rank": f"cuda:{local_rank}"}
+            if use_pipe:
+                p_el, p_ranks = region(plain=True)
+                extra["exchange"]["single_gpu_pattern_ms"] = p_el / k2 * 1e3
+                extra["exchange"]["single_gpu_pattern_ms_per_rank"] = [round(t / k2 * 1e3, 4) for t in p_ranks]
+                # the N > 1 step over the step of the plain single-GPU issue pattern in the same process: at world size 1 (forced)
+                # the price of the exchange machinery with nothing to send; at N > 1 what the exchange costs each rank
+                extra["exchange"]["world1_overhead" if world == 1 else "step_over_single_gpu_pattern"] = (elapsed / a.steps) / (p_el / k2)
 
         if use_pipe:
             # self-check outside the timed region: the issue pattern of the timed loop (pipeline, and the all-gather when
@@ -649,38 +718,30 @@ def main():
             draws = [(torch.rand(101, device=dev, generator=gchk), torch.rand(N - 1, device=dev, generator=gchk))
                      for _ in range(12)]
             torch.cuda.synchronize()
-            ys, pend = [], None
+            ys = []
             for i, (pu_c, nz_c) in enumerate(draws):
                 au = pipe.next_audio_stream()
-                if distributed and blocks is not None:
-                    works = []
-
-                    def on_block_c(row0, n, out, _i=i, _works=works, _pend=pend):
-                        if row0 == blocks[0][0] and _pend is not None:
-                            _pend.wait()
-                        _works.append(gather_rows(_i, out, row0, n))
-
-                    y = pipe.submit(f0, control, phase_u=pu_c, noise=nz_c, row_blocks=blocks, on_block=on_block_c)
-                    ys.append(y)
-                    with torch.cuda.stream(au):
-                        pend = peer_finish(i) if peer is not None else _Works(works)
+                if not distributed:
+                    ys.append(pipe.submit(f0, control, phase_u=pu_c, noise=nz_c))
                     continue
-                if distributed:
-                    # rendered in place into the gather buffer, as the timed loop does (the rows are cloned for the comparison
-                    # below before the slot is rendered into again: nbuf batches later)
-                    with torch.cuda.stream(au):
-                        if pend is not None:
-                            pend.wait()
-                        dst_c = peer.local_rows(i % nbuf) if peer is not None else full[i % nbuf][rank * B:(rank + 1) * B]
-                    y = pipe.submit(f0, control, phase_u=pu_c, noise=nz_c, out=dst_c)
-                    with torch.cuda.stream(au):
-                        pend = gather(i, y)
-                        ys.append(y.clone())
+                slot_i = i % nbuf
+                with torch.cuda.stream(au):
+                    xchg.acquire(slot_i, au)
+                    dst_c = peer.local_rows(slot_i) if peer is not None else full[slot_i][rank * B:(rank + 1) * B]
+                if blocks is not None:
+                    def on_block_c(row0, n, out, _i=i, _slot=slot_i, _au=au):
+                        post_behind(_au, _slot, lambda: issue_block(_i, out, row0, n, row0 + n == B))
+
+                    ys.append(pipe.submit(f0, control, phase_u=pu_c, noise=nz_c, row_blocks=blocks, on_block=on_block_c))
                     continue
-                y = pipe.submit(f0, control, phase_u=pu_c, noise=nz_c)
-                ys.append(y)
-            if pend is not None:
-                pend.wait()
+                # rendered in place into the gather buffer, as the timed loop does (the rows are cloned for the comparison below
+                # before the slot is rendered into again: nbuf batches later)
+                y = pipe.submit(f0, control, phase_u=pu_c, noise=nz_c, out=dst_c)
+                with torch.cuda.stream(au):
+                    ys.append(y.clone())
+                post_behind(au, slot_i, lambda _i=i, _y=y: issue_whole(_i, _y))
+            if xchg is not None:
+                xchg.drain()
             pipe.synchronize()
             torch.cuda.synchronize()
             wrong = 0

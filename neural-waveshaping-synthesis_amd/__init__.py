@@ -11,7 +11,7 @@ import os as _os
 
 # ForwardPipeline runs 3+ streams beside the caller's own (and RCCL's); HIP folds streams onto 4 hardware queues by default
 # and streams sharing a queue serialise.  Only effective if the HIP runtime has not started yet; harmless otherwise.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 from . import ginlite as gin  # noqa: F401,E402
 from ._lib import LIB_PATH, NwsError  # noqa: F401

@@ -11,6 +11,9 @@ CPU tests can drive this file with the oracle instead of the HIP engine.
 """
 from __future__ import annotations
 
+import queue
+import threading
+
 import torch
 import torch.distributed as dist
 
@@ -100,6 +103,120 @@ def gather_row_block(full: torch.Tensor, y: torch.Tensor, row0: int, n: int, gro
     return dist.all_gather(views, y[row0:row0 + n], group=group, async_op=async_op)
 
 
+class _Ticket:
+    __slots__ = ("issued", "done", "exc", "keep")
+
+    def __init__(self):
+        self.issued = threading.Event()     # the worker has enqueued the exchange (or failed)
+        self.done = None                    # torch.cuda.Event behind the exchange on the exchange stream
+        self.exc = None
+        self.keep = None
+
+
+class CompletionDrivenExchange:
+    """Issues every batch's exchange from a helper thread, on a stream of its own, at the moment the HOST has seen the batch
+    complete - so that no hardware queue ever sits on a device-side wait for another queue.
+
+    Why (measured on MI355X, round 5, `tools/world1_diag.sh`): the obvious form - enqueue the all-gather right behind the
+    batch's reverb, ordered by an event (`stream_x.wait_event(ev_audio)`; what torch.distributed does internally between the
+    caller's stream and its NCCL stream) - leaves the exchange queue with an UNSATISFIED cross-queue barrier at its head for
+    the whole step, every step.  With nothing to send (world size 1, even an empty `record -> wait -> record` hop in place of
+    the collective) that alone cost the pipelined step +30 % (0.392 -> 0.518 ms) beside two control streams and two audio
+    streams: the command processor's dispatch from the OTHER queues slows down while a queue is parked on a barrier packet.
+    The same hop on an event the host has already seen complete is free (0.394 ms), and so is this class.
+
+    Protocol (one instance per process / device):
+      * `acquire(slot, stream)` before rows of gather buffer `slot` are rendered again: the host waits until the slot's
+        previous exchange has been ISSUED (which implies its batch was complete), and `stream` waits for its completion on
+        the device - by then usually long over, i.e. a satisfied wait;
+      * render into the slot, record an event behind the batch, `post(slot, event, issue)`: the worker thread blocks on the
+        event (host side, GIL released), then calls `issue()` with the exchange stream current.  `issue` enqueues the
+        collective with `async_op=False` (torch.distributed then launches on the CURRENT stream: no internal stream hop) or
+        the peer copies;
+      * `drain()` at the end of a region.
+    The submitting thread can run at most `nslots` batches ahead of the GPU (it has to: a gather buffer is only free once its
+    exchange is out), which bounds the run-ahead exactly like the ring of workspaces of ForwardPipeline does.
+    Works without a GPU too (`device` cpu: no events, `issue` runs as soon as the worker gets to it) - the gloo tests."""
+
+    def __init__(self, device, nslots: int, stream=None):
+        """`stream`: the exchange stream (ForwardPipeline.exchange: placed on the command processor's pipes where its launches
+        do not delay the pipeline's own, pipeline.placed_streams); default a new one."""
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.stream = (stream if stream is not None else torch.cuda.Stream(device=self.device)) if self.cuda else None
+        self._tickets = [None] * int(nslots)
+        self.profile = None                 # a list: the worker appends (wait, issue, record) seconds per exchange (diagnosis)
+        self._all = []
+        self._q = queue.SimpleQueue()
+        self._thread = threading.Thread(target=self._run, name="nws-exchange", daemon=True)
+        self._thread.start()
+
+    def _run(self):
+        import time
+        if self.cuda:
+            torch.cuda.set_device(self.device)
+            torch.cuda.set_stream(self.stream)          # thread-local: everything this thread enqueues goes to the exchange stream
+        torch.set_grad_enabled(False)
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            t, ready, issue = item
+            try:
+                t0 = time.perf_counter()
+                if ready is not None:
+                    ready.synchronize()                 # host-side: the rows are final (GIL released while waiting)
+                t1 = time.perf_counter()
+                t.keep = issue()
+                t2 = time.perf_counter()
+                if self.cuda:
+                    t.done = self.stream.record_event()
+                if self.profile is not None:
+                    self.profile.append((t1 - t0, t2 - t1, time.perf_counter() - t2))
+            except BaseException as e:                  # handed to the submitting thread by acquire() / drain()
+                t.exc = e
+            t.issued.set()
+
+    def post(self, slot: int, ready, issue):
+        """`ready`: torch.cuda.Event recorded behind the kernels that write the rows (None: nothing to wait for);
+        `issue()`: enqueues the exchange on the current stream (called on the worker thread)."""
+        t = _Ticket()
+        self._tickets[slot] = t
+        self._all.append(t)
+        if len(self._all) > 4 * len(self._tickets) + 16:
+            self._all = [x for x in self._all if not x.issued.is_set()] + self._all[-len(self._tickets):]
+        self._q.put((t, ready, issue))
+        return t
+
+    @staticmethod
+    def _check(t):
+        if t.exc is not None:
+            raise RuntimeError("exchange worker failed") from t.exc
+
+    def acquire(self, slot: int, stream=None):
+        t = self._tickets[slot]
+        if t is None:
+            return
+        t.issued.wait()
+        self._check(t)
+        if self.cuda and t.done is not None:
+            (stream or torch.cuda.current_stream(self.device)).wait_event(t.done)
+        self._tickets[slot] = None
+
+    def drain(self):
+        """Every posted exchange issued AND complete (host-side)."""
+        for t in self._all:
+            t.issued.wait()
+            self._check(t)
+        self._all = []
+        if self.cuda:
+            self.stream.synchronize()
+
+    def close(self):
+        self._q.put(None)
+        self._thread.join(timeout=10)
+
+
 class PeerCopyAllGather:
     """All-gather of the rendered waveforms WITHOUT collective kernels: every rank pushes its (b, N) shard straight into
     every peer's gather buffer with device-to-device copies (hipMemcpyAsync on peer-mapped memory = the SDMA copy
@@ -121,7 +238,12 @@ class PeerCopyAllGather:
         gather's completion signal - so a push into rank q's slot s is ordered after q's last read of it (nbuf >= 2).
     """
 
-    def __init__(self, rows: int, n_samples: int, device, nbuf: int = 2, group=None, dtype=torch.float32):
+    def __init__(self, rows: int, n_samples: int, device, nbuf: int = 2, group=None, dtype=torch.float32,
+                 sync_signal: bool = False):
+        """sync_signal: the completion signal is a synchronous collective = launched on the CURRENT stream (torch.distributed
+        launches `async_op=False` collectives there), for callers that keep all exchanges on one stream of their own
+        (CompletionDrivenExchange): no hop to torch's NCCL stream and back, no work handle."""
+        self.sync_signal = bool(sync_signal)
         if not dist.is_initialized():
             raise RuntimeError("PeerCopyAllGather needs an initialised process group (handle exchange)")
         self.group = group
@@ -187,6 +309,9 @@ class PeerCopyAllGather:
         if self.backend == "gloo":              # CPU-side test backend: no stream-ordered collectives
             st.synchronize()
             dist.barrier(group=self.group)
+            return self.full[slot], None
+        if self.sync_signal:                    # on the current stream itself: later pushes from this stream are ordered behind it
+            dist.all_reduce(self._flag, group=self.group, async_op=False)
             return self.full[slot], None
         work = dist.all_reduce(self._flag, group=self.group, async_op=True)   # ordered after the copies on this stream
         self._last_work = work

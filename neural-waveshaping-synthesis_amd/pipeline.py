@@ -50,6 +50,46 @@ class _Slot:
         self.keep = None
 
 
+_STREAM_SETS = {}
+
+
+def placed_streams(dev, audio_streams: int = 2, control_streams: int = 2):
+    """(exchange stream, audio streams, control streams) of a device, created ONCE per process and shape and put on the command
+    processor's pipes in a fixed pattern.
+
+    Measured on MI355X (round 5, `tools/queue_order_probe.sh`, profiles/r05/queue_placement.txt): HIP creates a stream's
+    hardware queue at the stream's FIRST use, and the k-th hardware queue of a process (all priorities counted together) is
+    served by pipe k % 4 of the command processor.  A pipe dispatches one kernel at a time, and the oscillator kernel keeps its
+    pipe busy for its whole duration (16 000 workgroups are handed out as slots free up), so
+      * the two audio and two control streams must sit on FOUR DIFFERENT pipes: the next batch's recurrence queued on an audio
+        stream's pipe waits for the oscillator kernel to finish dispatching (0.399 ms per step -> 0.47 / 0.53 with the second
+        control stream on the first / second audio stream's pipe; period 4 in the number of queues created in between);
+      * a fifth queue (the exchange of the multi-GPU path) shares a pipe with one of the four whatever happens: beside a
+        control stream AND created before it, three small launches per step on it are free (x1.00-1.02); created after it, or
+        beside an audio stream, they cost 8-12 % of the step.
+    Hence the first-use order  exchange, audio 0, audio 1, control 0, control 1  (consecutive queues: the four on four pipes,
+    the exchange queue ahead of control 1 on its pipe), and ONE set per process: every ForwardPipeline of the same shape runs
+    on the same streams (a second set would land on whatever pipes the creation count has reached - bench legs that built
+    their own pipelines used to run up to 15 % slower than the same code alone)."""
+    key = (torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device(), audio_streams,
+           control_streams)
+    got = _STREAM_SETS.get(key)
+    if got is not None:
+        return got
+    xs = torch.cuda.Stream(device=dev)
+    # a side stream only pays off if its work is small next to the audio half: high priority keeps its few workgroups
+    # from queueing behind thousands of oscillator workgroups at dispatch
+    audio = [torch.cuda.Stream(device=dev) for _ in range(audio_streams)]
+    control = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(control_streams)]
+    touch = torch.zeros(64, device=dev)
+    for st in [xs] + audio + control:          # first use, in this order, one at a time
+        with torch.cuda.stream(st):
+            touch.fill_(0.0)
+        st.synchronize()
+    _STREAM_SETS[key] = (xs, audio, control)
+    return _STREAM_SETS[key]
+
+
 class ForwardPipeline:
     def __init__(self, model, depth: int = 4, audio_streams: int = 2, control_streams: int = 1, batched_gru: bool = False,
                  chain_exciters: bool = False):
@@ -59,10 +99,9 @@ class ForwardPipeline:
         self.eng = model._engine
         _, _, dev = self.eng.weights()
         self.dev = dev
-        # a side stream only pays off if its work is small next to the audio half: high priority keeps its few workgroups
-        # from queueing behind thousands of oscillator workgroups at dispatch
-        self.audio = [torch.cuda.Stream(device=dev) for _ in range(audio_streams)]
-        self.control = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(control_streams)]
+        # streams placed on the command processor's pipes (placed_streams); `exchange` is for a multi-GPU caller's
+        # parallel.CompletionDrivenExchange (unused otherwise: an idle queue costs nothing)
+        self.exchange, self.audio, self.control = placed_streams(dev, audio_streams, control_streams)
         self.slots = [_Slot() for _ in range(depth)]
         self.batched_gru = batched_gru
         # The oscillator + waveshaper kernel saturates vector issue on every CU: two of them side by side (the audio halves

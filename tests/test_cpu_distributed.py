@@ -145,3 +145,58 @@ def test_world8_weak_scaling_rehearsal(tmp_path):
         wrong_place = np.abs(full - np.roll(ref, b, axis=0)).max(axis=1)
         assert wrong_place.min() > 100 * err.max()                 # (a permuted layout would not pass the bound above)
     assert not np.array_equal(got[0][0][:101], got[0][1][:101])
+
+
+def _worker_cde(rank, world, port, tmp):
+    """The issue pattern of `bench.py --gpus N` (pipeline + parallel.CompletionDrivenExchange) on gloo: every step renders into
+    this rank's rows of a gather buffer taken from a ring of three, posts the exchange (whole batch, or four row blocks) to the
+    helper thread, and re-acquires the buffer three steps later."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        b, n, nslots, steps = 8, 40, 3, 10
+        x = par.CompletionDrivenExchange(torch.device("cpu"), nslots)
+        full = [torch.full((world * b, n), float("nan")) for _ in range(nslots)]
+        seen = []
+        for i in range(steps):
+            s = i % nslots
+            x.acquire(s)                                   # the previous exchange of this buffer has been issued (= is complete on gloo)
+            if i >= nslots:
+                seen.append(full[s].clone())               # ... so its rows are final: every rank's batch i - nslots
+            y = full[s][rank * b:(rank + 1) * b]
+            y.copy_(torch.arange(b * n, dtype=torch.float32).reshape(b, n) + 1000.0 * i + 100000.0 * rank)
+            if i % 2 == 0:
+                x.post(s, None, lambda _s=s, _y=y: par.gather_full(full[_s], _y, async_op=False))
+            else:
+                src = y.clone()                            # the list-of-views all_gather must not alias its input
+                for r0 in range(0, b, 2):
+                    x.post(s, None, lambda _s=s, _src=src, _r0=r0: par.gather_row_block(full[_s], _src, _r0, 2, async_op=False))
+        x.drain()
+        for i in range(steps - nslots, steps):
+            seen.append(full[i % nslots].clone())
+        # a failing exchange surfaces in the submitting thread
+        x.post(0, None, lambda: (_ for _ in ()).throw(ValueError("boom")))
+        try:
+            x.drain()
+            raised = False
+        except RuntimeError as e:
+            raised = isinstance(e.__cause__, ValueError)
+        x.close()
+        np.save(os.path.join(tmp, f"c{rank}.npy"), np.stack([t.numpy() for t in seen]))
+        np.save(os.path.join(tmp, f"e{rank}.npy"), np.array([raised]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_completion_driven_exchange_two_ranks(tmp_path):
+    world, b, n, steps = 2, 8, 40, 10
+    port = 30500 + (os.getpid() % 2000)
+    mp.spawn(_worker_cde, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(tmp_path / f"c{r}.npy") for r in range(world)]
+    assert np.array_equal(got[0], got[1]) and got[0].shape == (steps, world * b, n)
+    for i in range(steps):
+        for r in range(world):
+            want = np.arange(b * n, dtype=np.float32).reshape(b, n) + 1000.0 * i + 100000.0 * r
+            assert np.array_equal(got[0][i][r * b:(r + 1) * b], want), (i, r)
+    assert all(np.load(tmp_path / f"e{r}.npy")[0] for r in range(world))

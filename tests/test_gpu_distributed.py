@@ -14,7 +14,7 @@ from conftest import ROOT, load_npz
 from gpu_util import build_model, dev
 
 pytestmark = pytest.mark.gpu
-ENV = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="8")
+ENV = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="16")
 SMALL = ["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--batch1-iters", "0", "--batch", "4", "--frames", "16"]
 
 
