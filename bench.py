@@ -506,8 +506,8 @@ def main():
             if last:
                 peer.finish(i % nbuf)
                 peer.release(i % nbuf)
-        else:
-            par.gather_row_block(full[i % nbuf], y, row0, n, async_op=False)
+        else:       # one all_gather_into_tensor per block into the block-major gather buffer (parallel.gather_block_major)
+            par.gather_block_major(full[i % nbuf], y, row0 // n, len(blocks), async_op=False)
 
     def post_behind(stream, slot_i, issue):
         """the exchange `issue` leaves once everything enqueued on `stream` so far is complete"""
@@ -703,6 +703,9 @@ def main():
                                  "compute_only_ms_per_rank": [round(t / k2 * 1e3, 4) for t in c_ranks],
                                  "rccl_world_size": dist.get_world_size(), "backend": dist.get_backend(),
                                  "device_of_rank": f"cuda:{local_rank}"}
+            devs = [None] * world       # which device every rank of the job really ran on (one process per GPU)
+            dist.all_gather_object(devs, f"cuda:{local_rank} ({torch.cuda.get_device_properties(dev).name})")
+            extra["exchange"]["devices_per_rank"] = devs
             if use_pipe:
                 p_el, p_ranks = region(plain=True)
                 extra["exchange"]["single_gpu_pattern_ms"] = p_el / k2 * 1e3
@@ -764,6 +767,8 @@ def main():
                 # the last gathered buffer must hold EVERY rank's last batch at its rows, bit for bit: each rank re-renders
                 # the other ranks' batches itself (their inputs come from seeded generators, the draws are shared)
                 last = full[(len(ys) - 1) % nbuf]
+                if blocks is not None and peer is None:      # RCCL sub-batches fill the buffer block-major
+                    last = par.block_major_view(last, world, len(blocks)).reshape(world * B, N)
                 ok = True
                 for r in range(world):
                     y_r = ys[-1] if r == rank else model(*make_inputs(a, dev, r), phase_u=draws[-1][0], noise=draws[-1][1])

@@ -105,6 +105,10 @@ def _worker8(rank, world, port, b, T, tmp):
             for wk in works:
                 wk.wait()
             assert torch.equal(full, full_blocks) and not torch.isnan(full).any()
+            full_bm = torch.full((world * b, N), float("nan"))          # one all_gather_into_tensor per block, block-major buffer
+            for q in range(len(blocks)):
+                par.gather_block_major(full_bm, y, q, len(blocks)).wait()
+            assert torch.equal(par.block_major_view(full_bm, world, len(blocks)).reshape(world * b, N), full)
             assert torch.equal(full[rank * b:(rank + 1) * b], y)
             outs.append(torch.cat([pu, nz, full.reshape(-1)]).numpy())
         np.save(os.path.join(tmp, f"w{rank}.npy"), np.stack(outs))
