@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NWS_ABI_VERSION 4
+#define NWS_ABI_VERSION 5
 
 #define NWS_N_HARMONICS 101
 #define NWS_N_SHAPERS 64
@@ -100,6 +100,11 @@ typedef struct NwsWeights {
   /* options of the fused oscillator + waveshaper kernel's FastNEWT path (0 = default: FiLM interpolation on the matrix
    * pipe, sines as two fp16 terms = 22-bit products) */
   int32_t exciter_opts;
+  /* optional (64) from nws_exciter_bound(): X[s] >= |harmonic_mixer output of shaper s| for ANY phases (sum_k |W[s][k]| + |b[s]|,
+   * rounded up).  With it the fused kernel proves per workgroup, from the FiLM rows it stages, which groups of eight shapers keep
+   * their table index inside the table whatever the oscillator does, and runs those lookups without floor / clamp (bit-identical
+   * there; everything else takes the reference's clamped form, shaping.py:136-151).  NULL -> every lookup clamped. */
+  const float* exciter_bound;
 } NwsWeights;
 #define NWS_EXCITER_VALU_FILM 1 /* round-1 form: FiLM parameters interpolated on the VALU (kept for A/B timing) */
 #define NWS_EXCITER_ONE_TERM 2  /* sines as ONE fp16 term: 2 instead of 3 MFMAs per product and no residual split (-15 %
@@ -111,7 +116,7 @@ typedef struct NwsWeights {
                                    (one MFMA per product there instead of two) */
 #define NWS_EXCITER_BANK_NOFRACT 16 /* exact sin-MLP shapers (shaping.py:36-37): the hidden and output layers' pre-activations are
                                    provably inside v_sin_f32's own +-256-turn domain (sum |W| + |b| per row, checked by the caller
-                                   from the weights), so their sines skip the v_fract: 24 of an evaluation's 25 */
+                                   from the weights), so their sines skip the v_fract: 17 of an evaluation's 25 (the 8 first-layer sines keep it: their argument is unbounded) */
 
 int nws_abi_version(void);
 /* sizeof of the C structs above as this library was compiled (0 NwsWeights, 1 NwsReverbPlan, 2 NwsForwardAux, 3 NwsShaperDesc, 4 NwsGenericModel): lets a
@@ -314,6 +319,9 @@ int nws_shaper_table(const NwsWeights* w, int table_size, float table_min, float
    (7 K-steps x 2 M-tiles x 2 halves x 32 lanes x 8 halfs, twice) */
 #define NWS_MIXER_FRAGS_BYTES 28672
 int nws_mixer_frags(const float* mixer_w, const float* mixer_b, void* frags_out, void* stream);
+/* X[s] = (sum_k |mixer_w[s][k]| + |mixer_b[s]|) * (1 + 2^-10): the worst-case magnitude of the exciter of shaper s
+ * (NwsWeights.exciter_bound) */
+int nws_exciter_bound(const float* mixer_w, const float* mixer_b, float* bound_out /* device, 64 floats */, void* stream);
 /* Exact-mode companion of nws_lut_pairs: the TrainableNonlinearity weights (models/modules/shaping.py:15-37) of `w`
  * (shaper_* fields) as the (64, NWS_SHAPER_TURNS_ROW) fp32 table the fused kernel's shaper bank reads. */
 #define NWS_SHAPER_TURNS_ROW 176
@@ -479,38 +487,8 @@ int nws_forward_generic(const NwsGenericModel* m, const float* f0, const float* 
                         const void* reverb_tables, const void* reverb_spectrum, void* reverb_workspace,
                         size_t reverb_workspace_bytes, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Measurements / tests: which frame-MLP kernel nws_frame_mlps launches - 0 automatic (wave-resident frames from 8192 frames up,
- * tile kernels below; env NWS_MLP_KERNEL=tiles|frames), 1 the tile kernels, 2 wave-resident frames at any size. */
-int nws_debug_frame_mlps_kernel(int mode);
-int nws_debug_frame_mlps_probe(void* buf /* device, 4096 B: cycle timeline written by mode 2 + (6 << 8) */);
-
-/* Diagnostics only: ablation variants of the fused kernel for timing (1 no sin, 2 no LUT gather, 3 no shaper tail,
- * 4 no MFMA; 0 = product kernel).  Outputs of variants != 0 are meaningless. */
-int nws_debug_exciter_newt(int variant, const NwsWeights* w, const float* f0, const double* carry, const float* phase_u,
-                           const float* rand_phase, const float* film, int B, int T, float sample_rate,
-                           float* newt_out, void* stream);
-
-/* Diagnostics only: timing ablations of control_gru_kernel (0 product; 1 half the LDS reads of h, 2 half the FMAs, 3 no
- * transcendentals in the gates, 4 no per-step barrier, 5 no LDS reads of h).  Outputs of variants != 0 are meaningless. */
-int nws_debug_control_gru(int variant, const NwsWeights* w, const float* control, int B, int C, int T, float* gru_out,
-                          void* stream);
-
-/* Diagnostics only: candidate sine implementations (0 = nws_sinf as shipped, 1 = v_sin_f32 after an exact-product
- * reduction to turns, 2 = single odd polynomial after the same reduction); y[i] = sum of `reps` sines (reps = 1: sin(x[i])). */
-int nws_debug_sin(int mode, const float* x, float* y, int64_t n, int reps, void* stream);
-
-/* Diagnostics only: the MI355X co-execution hazard the build guards against (csrc/coexec_probe.hip, DESIGN.md 5.3, LABBOOK.md "5.2").
- * nws_coexec_pk_probe evaluates eight packed-fp32 instruction forms `iters` times per thread and adds, per form, the
- * number of results that differ from scalar arithmetic on the same operands to report[0..7] (device uint32[8], zeroed by
- * the caller; forms 4..7 are the swizzled-src1 ones).  nws_coexec_mfma_load runs a bare MFMA loop beside it:
- * kind 0 v_mfma_f32_32x32x16_f16, 1 v_mfma_f32_16x16x32_f16, 2 v_mfma_f32_32x32x8f16, 3 v_mfma_f32_32x32x2f32. */
-int nws_coexec_pk_probe(int blocks, int iters, unsigned* report, void* stream);
-/* same for packed fp16, v_fma_mix*, scalar-register second operands and fp64 (11 forms listed in csrc/coexec_probe.hip;
- * report: device uint32[11]) */
-int nws_coexec_pk_probe2(int blocks, int iters, unsigned* report, void* stream);
-/* probe 1 in waves 0-1 and a v_mfma_f32_16x16x32_f16 loop in waves 2-3 of the SAME workgroups (one kernel) */
-int nws_coexec_pk_probe_mixed(int blocks, int iters, int mfma_iters, unsigned* report, float* sink, void* stream);
-int nws_coexec_mfma_load(int kind, int blocks, int iters, float* sink /* device float[256] */, void* stream);
+/* Diagnostic entry points (kernel ablations for timing, the co-execution hazard probes) are declared in nws_hip_debug.h: they are
+ * exported by the same library but are not part of the product ABI. */
 
 /*
  * Live profiling of nws_forward (bench.py's roofline leg): hipEvents are recorded on the launch stream around

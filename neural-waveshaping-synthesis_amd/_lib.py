@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnws_hip.so")
 
-ABI_VERSION = 4          # include/nws_hip.h NWS_ABI_VERSION
+ABI_VERSION = 5          # include/nws_hip.h NWS_ABI_VERSION
 EXCITER_VALU_FILM = 1    # NwsWeights.exciter_opts bits (include/nws_hip.h)
 EXCITER_ONE_TERM = 2
 EXCITER_HYBRID = 4
@@ -48,6 +48,7 @@ class NwsWeights(C.Structure):
         ("newt_out_w", _fp), ("newt_out_b", _fp),
         ("noise_window", _fp),
         ("exciter_opts", C.c_int32),
+        ("exciter_bound", _fp),
     ]
 
 
@@ -122,6 +123,7 @@ _PROTOTYPES = {
     "nws_reverb": (C.c_int, [C.POINTER(NwsReverbPlan), _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, C.c_size_t, _fp]),
     "nws_shaper_table": (C.c_int, [C.POINTER(NwsWeights), C.c_int, C.c_float, C.c_float, _fp, _fp]),
     "nws_mixer_frags": (C.c_int, [_fp, _fp, _fp, _fp]),
+    "nws_exciter_bound": (C.c_int, [_fp, _fp, _fp, _fp]),
     "nws_shaper_turns": (C.c_int, [_fp, _fp, _fp]),
     "nws_lut_pairs": (C.c_int, [_fp, C.c_int, _fp, _fp]),
     "nws_shaper_apply": (C.c_int, [C.POINTER(NwsWeights), _fp, C.c_int64, C.c_int64, _fp, _fp]),

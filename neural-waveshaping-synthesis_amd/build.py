@@ -45,6 +45,7 @@ def _stamp():
             h.update(f.encode())
             h.update(open(p, "rb").read())
     h.update(open(os.path.join(HERE, "..", "include", "nws_hip.h"), "rb").read())
+    h.update(open(os.path.join(HERE, "..", "include", "nws_hip_debug.h"), "rb").read())
     return h.hexdigest()
 
 
@@ -187,6 +188,7 @@ def build_torch_ops(force=False, verbose=True):
     src = os.path.join(CSRC, "torch_ops.cpp")
     h = hashlib.sha256(open(src, "rb").read())
     h.update(open(os.path.join(HERE, "..", "include", "nws_hip.h"), "rb").read())
+    h.update(open(os.path.join(HERE, "..", "include", "nws_hip_debug.h"), "rb").read())
     h.update(torch.__version__.encode())
     stamp, stamp_file = h.hexdigest(), OPS_LIB + ".stamp"
     if not force and os.path.exists(OPS_LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:

@@ -38,14 +38,14 @@ constexpr float kPi = 3.141592653589793f;   // fl32(math.pi)
 
 // OPT bits of exciter_newt_kernel (compile-time variants of the FastNEWT hot path)
 enum Opt {
-  kOptScalarSines = 1,  // main loop in scalar fp32: a v_pk_*_f32 does not overlap with the matrix pipe, a v_fma_f32 does
+  // (bit 1 was kOptScalarSines, the main loop in scalar fp32: measured slower in round 2, selected by no path since; retired in round 5)
   kOptFilmMfma = 2,     // FiLM interpolation (3 parameter types x 64 shapers x 32 samples per wave) as six bf16 MFMAs
   kOptOneTerm = 4,      // sines as ONE fp16 term in EVERY K-step (drops W_hi * v_lo: 2 MFMAs per product; 11-bit activations)
   kOptHybrid = 8,       // two-term sines in K-step 0 (mixer bias + harmonics 1..15), one term in K-steps 1..6
   kOptHybridW = 16,     // with kOptHybrid: the mixer WEIGHTS of harmonics 16..101 as one fp16 term too (1 MFMA per product)
   kOptLowReg = 32       // with kOptFilmMfma: the tail keeps at most two FiLM tiles live (80 VGPRs: three 8-wave workgroups per CU)
 };
-static_assert((kOptScalarSines ^ kOptFilmMfma ^ kOptOneTerm ^ kOptHybrid ^ kOptHybridW ^ kOptLowReg) == 63, "Opt bits must be distinct");
+static_assert((kOptFilmMfma ^ kOptOneTerm ^ kOptHybrid ^ kOptHybridW ^ kOptLowReg) == 62, "Opt bits must be distinct");
 enum Mode { kModeLut = 0, kModeExact = 1, kModeExciterOnly = 2, kModeLutPairs = 3, kModeLutPairsDiv6 = 4, kModeExactBank = 5,
             kModeExactBankNF = 6 };   // NF: no v_fract in front of the sines of the hidden and output layers (NWS_EXCITER_BANK_NOFRACT)
 __host__ __device__ constexpr bool is_bank(int mode) { return mode == kModeExactBank || mode == kModeExactBankNF; }
@@ -196,7 +196,8 @@ struct BankLds {
 // FRACT = false: the pre-activation goes to v_sin_f32 as it is (in turns).  The instruction reduces arguments inside +-256 turns
 // by itself; hidden and output layers of a sin-MLP see |pre| <= sum |W| + |b| (their inputs are sines), which the host checks
 // against that domain once per weights version (engine.py: bank_nofract_safe; 0.6 turns for the shipped checkpoints).  One
-// quarter-rate instruction per sine instead of two: 24 of the 25 sines of an evaluation.
+// quarter-rate instruction per sine instead of two: 17 of the 25 sines of an evaluation (8 + 8 + 1; the 8 first-layer sines keep
+// their v_fract, their argument is unbounded).
 template <bool FRACT>
 __device__ __forceinline__ float bank_sin(float t) { return FRACT ? sin_of_turns(t) : __builtin_amdgcn_sinf(t); }
 
@@ -400,6 +401,9 @@ struct ExcLds {
     uint4 ffrag[3][3][2][32];
   };
   float bsum[4];
+  // bit s of okmask[slot]: the table index of shaper s provably stays inside the table for every sample that interpolates
+  // between the slot's two frames (staging, from NwsWeights.exciter_bound); 0 = unknown -> the clamped lookup
+  unsigned long long okmask[3];
   // K slot c = 16ks + 8half + e: slot 0 is the mixer BIAS (its "sine" is the constant 1), slot c >= 1 is harmonic c
   float shift[kKPad];           // phase shift of slot c (0 for slot 0 and the padding slots 102..111)
   float kf[kKPad];              // (float)c: harmonic numbers as packed-FMA operands, read instead of computed
@@ -488,13 +492,6 @@ __device__ __forceinline__ f32x2 sin_turns2_fract(f32x2 x) {
   return f32x2{__builtin_amdgcn_sinf(t.x), __builtin_amdgcn_sinf(t.y)};
 }
 
-// scalar twin of sin_turns2_fract (same roundings): plain v_mul/v_fma/v_add issue in half the cycles of their packed forms
-// and, unlike those, beside the matrix pipe (tools/ubench/valu_rate.hip)
-__device__ __forceinline__ float sin_turns_fract(float x) {
-  const float c_hi = 0.15915493667125702f, c_lo = 6.4206382432985265e-09f;
-  return __builtin_amdgcn_sinf(fmaf(x, c_lo, fmaf(x, c_hi, -__builtin_rintf(x * c_hi))));
-}
-
 // two sines at once: every step except rint and v_sin_f32 is a packed-fp32 instruction
 __device__ __forceinline__ f32x2 sin_turns2(f32x2 x) {
   const f32x2 c_hi = splat2(0.15915493667125702f), c_lo = splat2(6.4206382432985265e-09f);
@@ -521,7 +518,7 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 // (0.328 ms).  (Wrong results seen with that build under two overlapping audio streams were first blamed on the scratch;
 // the multi-stream problem turned out to be independent of it, see pipeline.py.  The build still rejects scratch.)
 template <int MODE, int DBG = 0, int HPB = 1, int OPT = 0>
-__global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) ? 4 : ((OPT & kOptLowReg) ? 6 : (OPT & kOptFilmMfma) ? 5 : ((OPT & kOptScalarSines) ? 6 : (HPB == 2 ? 7 : 5))))) void exciter_newt_kernel(NwsWeights w, const float* __restrict__ f0,
+__global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) ? 4 : ((OPT & kOptLowReg) ? 6 : (OPT & kOptFilmMfma) ? 5 : (HPB == 2 ? 7 : 5)))) void exciter_newt_kernel(NwsWeights w, const float* __restrict__ f0,
                                                            const float* __restrict__ f0_up,
                                                            const double* __restrict__ carry,
                                                            const float* __restrict__ phase_u,
@@ -638,6 +635,7 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
         // index FiLM pre-scaled to table units: idx = (size/6) (g x + b - min) = g' x + b'  (a few ulp of idx away from the
         // reference's rounding chain, like the folded origin of the kModeLutPairsDiv6 path; held to the same e2e parity bar)
         const float c = (float)w.lut_size * (1.0f / 6.0f);
+        float ga = 0.0f, gd = 0.0f, ba = 0.0f, bd = 0.0f;
 #pragma unroll
         for (int ty = 0; ty < 3; ++ty) {
           const float u0 = r0[ty * kS], u1 = r1[ty * kS];
@@ -645,9 +643,13 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
           if (ty == 0) {
             a = u0 * c;
             d = (u1 - u0) * c;
+            ga = a;
+            gd = d;
           } else if (ty == 1) {
             a = (u0 - w.lut_min) * c;
             d = (u1 - u0) * c;
+            ba = a;
+            bd = d;
           } else {
             a = ow * u0;
             d = ow * u1 - a;
@@ -663,6 +665,20 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
           const unsigned d1 = top16(rd);
           const unsigned d2 = top16(rd - __builtin_bit_cast(float, d1));
           L.ffrag[wave][ty][lane >> 5][lane & 31] = uint4{(a0 >> 16) | a1, (a2 >> 16) | d0, (d1 >> 16) | d2, 0u};
+        }
+        if ((OPT & kOptLowReg) && MODE == kModeLutPairsDiv6) {
+          // Range proof for this slot's lookups (shaping.py:136-151 clamps `lower` into the table; inside the table the clamp
+          // is the identity).  idx = G x + B with G, B linear in the interpolation weight between the slot's two frames and
+          // |x| <= X[s] whatever the oscillator does, so idx lies between the extremes taken at the two frames:
+          // B_f -+ |G_f| X.  One table cell of margin on either side plus 2^-9 of |G| X covers every rounding between here and
+          // the tail (the three-term FiLM interpolation, the 22-bit - or, opted in, 11-bit - mixer products).  NaNs compare
+          // false: not proven.
+          const float X = w.exciter_bound != nullptr ? w.exciter_bound[lane] : __builtin_inff();
+          const float r_a = fabsf(ga) * X, r_b = fabsf(ga + gd) * X;
+          const float e = 1.0f + fmaxf(r_a, r_b) * (1.0f / 512.0f);
+          const float lo = fminf(ba - r_a, (ba + bd) - r_b), hi = fmaxf(ba + r_a, (ba + bd) + r_b);
+          const unsigned long long okm = __ballot(lo >= e && hi <= (float)(w.lut_size - 1) - e);
+          if (lane == 0) L.okmask[wave] = okm;
         }
       } else
 #pragma unroll
@@ -753,7 +769,7 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
   const f32x2 ph2 = splat2(phase);
   // rint(e P) for e = 0..7, P = phase / 2 pi = turns per harmonic number (shared integer parts of the sine reduction, below)
   // (the FiLM-on-the-matrix-pipe variants, i.e. the product path; the round-1 VALU-FiLM form at 72 registers has no room)
-  constexpr bool kSharedTurns = (OPT & kOptFilmMfma) && !(OPT & kOptScalarSines);
+  constexpr bool kSharedTurns = (OPT & kOptFilmMfma) != 0;
   f32x2 turns_e[4];
   if (kSharedTurns) {
     const float P = phase * 0.15915493667125702f;
@@ -768,11 +784,6 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
   // sines of one pair of K slots: arg = fl(fl(k*phase) + shift), the reference's own rounding chain, then sin
   auto sine_pair = [&](const f32x2 kfp, const f32x2 shp) -> f32x2 {
     if (DBG == 1) return kfp * ph2 + shp;
-    if (small_args && (OPT & kOptScalarSines)) {
-      // the same arithmetic, instruction for instruction, in scalar fp32 (-ffp-contract=off: k*phase and + shift round apart)
-      const float a0 = kfp.x * phase + shp.x, a1 = kfp.y * phase + shp.y;
-      return f32x2{sin_turns_fract(a0), sin_turns_fract(a1)};
-    }
     if (small_args) return sin_turns2_fract(kfp * ph2 + shp);
     const f32x2 arg2 = kfp * ph2 + shp;
     return f32x2{nws_sin_wide(arg2.x), nws_sin_wide(arg2.y)};
@@ -961,12 +972,54 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
                                 : uint4{0u, 0u, 0u, 0u};       // K slots 8..15 unused: zero B, whatever A holds there
     const bf16x8 bfrag = __builtin_bit_cast(bf16x8, bop);
     float part = 0.0f;
+    unsigned ok_tile[2] = {0u, 0u};   // bit k of ok_tile[m]: shaper 32 m + k proven in range for this wave's samples
+    if (OPT & kOptLowReg) {
+      const int q0u = __builtin_amdgcn_readfirstlane(q0);
+      if (__all(q0 == q0u)) {           // (a wave's 32 samples share their frame pair; anything else takes the clamped form)
+        const unsigned long long okm = L.okmask[q0u];
+        ok_tile[0] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)okm);
+        ok_tile[1] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(okm >> 32));
+      }
+    }
     if (OPT & kOptLowReg) {
       // Register diet (93 -> <= 80 VGPRs: a third 8-wave workgroup fits a CU, 6 waves per SIMD instead of 4).  Same arithmetic,
       // other order: the index FiLM of a whole M-tile first, IN PLACE of the accumulator tile (acc, G, Bb live: 48 + the other
       // tile's 16), only then the gain tile Gn (its MFMA runs under the first gathers) and the lookups.
+      // Two copies of a tile's sixteen lookups, chosen ONCE per tile by a wave-uniform test behind the tile's three MFMAs (a branch per
+      // group of four lookups cost the register allocator the in-place tiles: 218 spilled registers; a branch around the whole tile
+      // body had the FiLM stage hoisted out of both arms into fresh registers: 12 spilled): `proven` = all 32 shapers of the tile
+      // provably index inside the table for this wave's samples -> floor(idx) is the table cell and idx - floor(idx) = fract(idx)
+      // exactly (below 2^23): v_fract + v_cvt_u32 + v_lshl_add where the clamped form of shaping.py:136-151 needs floor, med3,
+      // cvt, sub, lshl_add.  Same bits wherever both apply.
+      auto lookups = [&](auto m_tag, auto proven_tag, const f32x16& acc, const f32x16& Gn) {
+        constexpr int m = decltype(m_tag)::value;
+        constexpr bool proven = decltype(proven_tag)::value;
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
+        for (int g = 0; g < 16 / kLutGroup; ++g) {
+          float fr[kLutGroup];
+          float2 tv[kLutGroup];
+#pragma unroll
+          for (int e = 0; e < kLutGroup; ++e) {
+            const int r = kLutGroup * g + e;
+            const float idx = acc[r];
+            unsigned o;
+            if (proven) {
+              o = lane_off_bytes + ((unsigned)idx << 3);
+              fr[e] = __builtin_amdgcn_fractf(idx);
+            } else {
+              const float fl = __builtin_amdgcn_fmed3f(floorf(idx), 0.0f, LF.top);
+              o = lane_off_bytes + ((unsigned)(int)fl << 3);
+              fr[e] = idx - fl;
+            }
+            tv[e] = *reinterpret_cast<const float2*>(LF.pairs + (size_t)(32 * m + (r & 3) + 8 * (r >> 2)) * LF.row_bytes + o);
+          }
+#pragma unroll
+          for (int e = 0; e < kLutGroup; ++e) part = fmaf(Gn[kLutGroup * g + e], fmaf(tv[e].y, fr[e], tv[e].x), part);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      auto tile = [&](auto m_tag) {
+        constexpr int m = decltype(m_tag)::value;
         f32x16& acc = m == 0 ? acc0 : acc1;
         {
           const f32x16 G = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, L.ffrag[q0][0][m][col]), bfrag, f32x16{}, 0, 0, 0);
@@ -976,24 +1029,12 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
         }
         __builtin_amdgcn_sched_barrier(0);
         const f32x16 Gn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, L.ffrag[q0][2][m][col]), bfrag, f32x16{}, 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < 16 / kLutGroup; ++g) {
-          float fr[kLutGroup];
-          float2 tv[kLutGroup];
-#pragma unroll
-          for (int e = 0; e < kLutGroup; ++e) {
-            const int r = kLutGroup * g + e;
-            const float idx = acc[r];
-            const float fl = __builtin_amdgcn_fmed3f(floorf(idx), 0.0f, LF.top);
-            const unsigned o = lane_off_bytes + ((unsigned)(int)fl << 3);
-            fr[e] = idx - fl;
-            tv[e] = *reinterpret_cast<const float2*>(LF.pairs + (size_t)(32 * m + (r & 3) + 8 * (r >> 2)) * LF.row_bytes + o);
-          }
-#pragma unroll
-          for (int e = 0; e < kLutGroup; ++e) part = fmaf(Gn[kLutGroup * g + e], fmaf(tv[e].y, fr[e], tv[e].x), part);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
+        // the tile's sixteen lookups per lane in one of two forms, chosen by ONE wave-uniform branch
+        if (ok_tile[m] == 0xffffffffu) lookups(m_tag, std::true_type{}, acc, Gn);
+        else lookups(m_tag, std::false_type{}, acc, Gn);
+      };
+      tile(std::integral_constant<int, 0>{});
+      tile(std::integral_constant<int, 1>{});
     } else
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -1285,6 +1326,15 @@ __global__ void mixer_frags_kernel(const float* __restrict__ mixer_w, const floa
   out[kKSteps * 2 * 2 * 32 * 8 + at] = l;
 }
 
+// X[s] = (sum_k |W[s][k]| + |b[s]|) rounded up: one wave per shaper
+__global__ void exciter_bound_kernel(const float* __restrict__ mixer_w, const float* __restrict__ mixer_b, float* __restrict__ out) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  float v = 0.0f;
+  for (int k = lane; k < kK; k += 64) v += fabsf(mixer_w[(size_t)s * kK + k]);
+  v = wave_sum_to_lane63(v);
+  if (lane == 63) out[s] = (v + fabsf(mixer_b[s])) * (1.0f + 1.0f / 1024.0f);
+}
+
 __global__ void lut_pairs_kernel(const float* __restrict__ table, int size, float2* __restrict__ pairs) {
   const int s = blockIdx.y;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < size; i += gridDim.x * blockDim.x) {
@@ -1384,6 +1434,13 @@ int nws_mixer_frags(const float* mixer_w, const float* mixer_b, void* frags_out,
   return NWS_OK;
 }
 
+int nws_exciter_bound(const float* mixer_w, const float* mixer_b, float* bound_out, void* stream) {
+  if (!mixer_w || !mixer_b || !bound_out) return NWS_ERR_BAD_ARG;
+  exciter_bound_kernel<<<kS, 64, 0, (hipStream_t)stream>>>(mixer_w, mixer_b, bound_out);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
 int nws_shaper_turns(const NwsWeights* w, float* table_out, void* stream) {
   if (!w || !table_out || !w->shaper_in_scale || !w->shaper_w0 || !w->shaper_b0 || !w->shaper_w2 || !w->shaper_b2 ||
       !w->shaper_w4 || !w->shaper_b4 || !w->shaper_w6 || !w->shaper_b6)
@@ -1461,9 +1518,9 @@ int nws_exciter_newt_add(const NwsWeights* w, const float* f0, const float* f0_u
 #define NWS_HOT(O) exciter_newt_kernel<kModeLutPairsDiv6, 0, 2, O><<<g2, 512, base + hot_pad, st>>>( \
             *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out, nullptr, add_in, xcd_groups)
         if (opts & NWS_EXCITER_VALU_FILM) NWS_HOT(0);
-        else if (opts & NWS_EXCITER_ONE_TERM) { if (low_reg) NWS_HOT(kOptFilmMfma | kOptOneTerm | kOptLowReg); else NWS_HOT(kOptFilmMfma | kOptOneTerm); }
+        else if (opts & NWS_EXCITER_ONE_TERM) NWS_HOT(kOptFilmMfma | kOptOneTerm | kOptLowReg);
         else if (opts & NWS_EXCITER_HYBRID_W) { if (low_reg) NWS_HOT(kOptFilmMfma | kOptHybrid | kOptHybridW | kOptLowReg); else NWS_HOT(kOptFilmMfma | kOptHybrid | kOptHybridW); }
-        else if (opts & NWS_EXCITER_HYBRID) { if (low_reg) NWS_HOT(kOptFilmMfma | kOptHybrid | kOptLowReg); else NWS_HOT(kOptFilmMfma | kOptHybrid); }
+        else if (opts & NWS_EXCITER_HYBRID) NWS_HOT(kOptFilmMfma | kOptHybrid | kOptLowReg);
         else if (low_reg) NWS_HOT(kOptFilmMfma | kOptLowReg);
         else NWS_HOT(kOptFilmMfma);
 #undef NWS_HOT
@@ -1515,8 +1572,6 @@ int nws_debug_exciter_newt(int variant, const NwsWeights* w, const float* f0, co
     switch (variant - 10) {
       case 0: NWS_OPT_LAUNCH(0); break;
       case 2: NWS_OPT_LAUNCH(2); break;
-      case 6: NWS_OPT_LAUNCH(6); break;
-      case 10: NWS_OPT_LAUNCH(10); break;
       case 26: NWS_OPT_LAUNCH(26); break;
       case 34: NWS_OPT_LAUNCH(34); break;   // kOptFilmMfma | kOptLowReg: the default kernel
       case 58: NWS_OPT_LAUNCH(58); break;   // ... | kOptHybrid | kOptHybridW | kOptLowReg: the opt-in hybrid-W kernel

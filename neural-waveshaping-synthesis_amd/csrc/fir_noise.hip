@@ -216,9 +216,11 @@ __global__ __launch_bounds__(256, 4) void fir_noise_mfma_kernel(const float* __r
       const float* src = &fir[((size_t)bc * T + fc) * kHalf + 4 * p32];
       const float* src_lo = &fir[((size_t)bc * T + fc) * kHalf + 4 * (31 - p32)];
       const float4 hi4 = *reinterpret_cast<const float4*>(src), lo4 = *reinterpret_cast<const float4*>(src_lo);
-      const float keep = ok ? 1.0f : 0.0f;
-      v[it + 4] = make_float4(hi4.x * keep, hi4.y * keep, hi4.z * keep, hi4.w * keep);
-      v[it] = make_float4(lo4.x * keep, lo4.y * keep, lo4.z * keep, lo4.w * keep);     // the raw quad A; mirrored when staged
+      // zeroed by a select on the loaded values (not by a multiplication: 0 * Inf = NaN would leak a clamped row's Inf / NaN into
+      // a frame that has to be silent, and into the utterance's scale search)
+      const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      v[it + 4] = ok ? hi4 : zero4;
+      v[it] = ok ? lo4 : zero4;     // the raw quad A; mirrored when staged
     }
   };
   // the 384 noise samples both frames are cut from, once (reflect padding resolved here), pre-scaled.  Requested BEFORE the

@@ -1334,7 +1334,10 @@ int nws_frame_mlps(const NwsWeights* w, const float* gru_out, const float* fir_d
   const long long F = (long long)B * T;
   // (from the point where the 64-frame tile kernel needs a second round of workgroups: 256 tiles)
   const bool many = (long long)B * ((T + kFT2 - 1) / kFT2) > 256;
-  if (w->mlp_frags != nullptr && mode != 1 && (many || mode == 2) && F * NWS_FILM_CH < (1ll << 31)) {
+  // (the wave-resident kernel addresses its outputs through buffer resources with 32-bit BYTE offsets - num_records and the
+  // per-lane offsets of the film rows, the widest output: F * 256 * 4 bytes must stay below 2^31, i.e. F < 2^21 frames = 64 x 8.7 min;
+  // beyond that the tile kernels below, which index with size_t, take over)
+  if (w->mlp_frags != nullptr && mode != 1 && (many || mode == 2) && F * NWS_FILM_CH * (long long)sizeof(float) < (1ll << 31)) {
     static unsigned long long attr_wr = 0;
     if (nws_first_use_on_device(attr_wr)) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_mlps_wr_kernel<false>),

@@ -1226,7 +1226,10 @@ int nws_g_gru(const float* w_ih, const float* w_hh, const float* b_ih, const flo
   const size_t lds = ((size_t)2 * hidden + C_in) * sizeof(float);
   if (lds > 160 * 1024) return NWS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (hidden == 128 && C_in == 2 && !getenv("NWS_G_GRU_RUNTIME")) {
+  // (measurement switches, read once: NWS_G_GRU_RUNTIME keeps the runtime-size recurrence for the default shape, NWS_G_GRU_L2 the
+  // form that reads W_hh from L2 every step)
+  static const bool env_runtime = getenv("NWS_G_GRU_RUNTIME") != nullptr, env_l2 = getenv("NWS_G_GRU_L2") != nullptr;
+  if (hidden == 128 && C_in == 2 && !env_runtime) {
     // the reference's default recurrence (GRU(2 -> 128)) inside an otherwise non-default configuration: the fused path's
     // kernel (control_gru.hip: 0.44 us per step against 0.8 for the runtime-size recurrence below), same layouts
     NwsWeights w{};
@@ -1236,7 +1239,7 @@ int nws_g_gru(const float* w_ih, const float* w_hh, const float* b_ih, const flo
     w.gru_b_hh = b_hh;
     return nws_control_gru_state(&w, control, B, C_total, T, h0, out, hT, stream);
   }
-  if (hidden <= 128 && !getenv("NWS_G_GRU_L2")) {
+  if (hidden <= 128 && !env_l2) {
     // W_hh in registers: four lanes per hidden unit (whole waves: units rounded up to 16)
     const int threads = 4 * ((hidden + 15) & ~15);
     const int kq = hidden <= 32 ? 8 : hidden <= 64 ? 16 : 32;
@@ -1280,6 +1283,8 @@ static int g_phase_impl(const float* f0, const float* f0_up, int B, int T, int h
   const float scale = (float)T / (float)N;
   hipStream_t st = (hipStream_t)stream;
   const long long G = (N + kPhChunk - 1) / kPhChunk;
+  // (NWS_G_PHASE_SERIAL is re-read on every call on purpose - tests/test_gpu_generic.py flips it in-process; a getenv is ~0.1 us
+  // of a call that launches two kernels)
   if (G < 2 || G > 65535 || B > 65535 || getenv("NWS_G_PHASE_SERIAL")) {      // short rows: one workgroup per utterance, one launch
     g_phase_kernel<<<B, 1024, 0, st>>>(f0, f0_up, T, (int)N, scale, sample_rate, f0_up_out, phase_out);
     NWS_CHECK_LAUNCH();

@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #include "../../include/nws_hip.h"
+#include "../../include/nws_hip_debug.h"
 
 #define NWS_WAVE 64
 

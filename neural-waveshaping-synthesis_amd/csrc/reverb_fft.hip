@@ -790,6 +790,8 @@ int nws_reverb_plan(int N, int ir_len_plus1, NwsReverbPlan* plan) {
     if (Lc / m == 125 && Lc % m == 0) n2 = m;
   const int n1 = n2 >= 32 ? Lc / n2 : 0;
   int dense_max = kDenseMaxN1;
+  // (the two NWS_REVERB_* switches are re-read per call on purpose: tests and tools/reverb_lengths.py flip them in-process; the
+  // plan is host-only and the Python engine caches it per length, so this is not on a per-forward path)
   if (const char* e = getenv("NWS_REVERB_DENSE_MAX")) dense_max = atoi(e);   // measurements only
   if (n2 >= 32 && (n1 == 125 || n1 <= dense_max)) {
     plan->L = Lc;

@@ -17,6 +17,7 @@
 #include <tuple>
 
 #include "../../include/nws_hip.h"
+#include "../../include/nws_hip_debug.h"
 
 namespace {
 

@@ -280,6 +280,11 @@ class Engine:
             check(L.nws_mixer_frags(w.mixer_w, w.mixer_b, ptr(frags), st), "nws_mixer_frags")
             keep.append(frags)
             w.mixer_frags = frags.data_ptr()
+            if not os.environ.get("NWS_EXCITER_NO_RANGE"):     # (A/B switch: every table lookup in the clamped form)
+                xb = torch.empty(_lib.N_SHAPERS, dtype=torch.float32, device=dev)
+                check(L.nws_exciter_bound(w.mixer_w, w.mixer_b, ptr(xb), st), "nws_exciter_bound")
+                keep.append(xb)
+                w.exciter_bound = xb.data_ptr()
             for name, mlp, out_rows, wf, bf, gf, lf in (
                     ("newt.mlp", m.newt.mlp, 256, w.newt_mlp_w, w.newt_mlp_b, w.newt_ln_g, w.newt_ln_b),
                     ("h_generator", m.h_generator, 129, w.hgen_w, w.hgen_b, w.hgen_ln_g, w.hgen_ln_b)):
@@ -449,7 +454,8 @@ class Engine:
         ir = self._w[1][-1]
         dev = self._w[2]
         plan, tables, plan_t = reverb_plan_and_tables(dev, n_samples, ir.numel() + 1)
-        spec = self._spectra.get(plan.L)
+        skey = (plan.L, plan.N1, plan.N2)      # stored in the transform's own (k1, k2) order: one spectrum per factorisation
+        spec = self._spectra.get(skey)
         if spec is None:
             with torch.cuda.device(dev):
                 spec = torch.empty(_lib.lib().nws_reverb_spectrum_bytes(C.byref(plan)) // 4, dtype=torch.float32, device=dev)
@@ -458,7 +464,7 @@ class Engine:
                 check(_lib.lib().nws_reverb_ir_spectrum(C.byref(plan), ptr(tables), ptr(ir), ir.numel(), ptr(spec), ptr(ws),
                                                         nbytes, stream_ptr(dev)), "nws_reverb_ir_spectrum")
                 torch.cuda.current_stream(dev).synchronize()
-            self._spectra[plan.L] = spec
+            self._spectra[skey] = spec
         return plan, tables, spec, plan_t
 
     # ---- stage launchers (public for the parity tests; each is one C-ABI call / one torch op) ------------------
@@ -653,9 +659,11 @@ class Engine:
             # the blocks must tile [0, B) with even sizes (two utterances share one transform; ForwardPipeline.row_blocks' rule):
             # anything else would leave rows of `out` unwritten or pair the wrong utterances
             nxt = 0
-            for row0, nrows in row_blocks:
-                if int(row0) != nxt or int(nrows) <= 0 or int(nrows) % 2:
-                    raise RuntimeError(f"row_blocks must tile [0, {B}) in order with even sizes, got {list(row_blocks)}")
+            for k, (row0, nrows) in enumerate(row_blocks):
+                # every block but the last has an even size (so that every row0 is even: nws_forward_reverb_rows' own rule; an odd
+                # last block pads its last pair like an odd batch does)
+                if int(row0) != nxt or int(nrows) <= 0 or (int(nrows) % 2 and k != len(row_blocks) - 1):
+                    raise RuntimeError(f"row_blocks must tile [0, {B}) in order, even sizes except the last, got {list(row_blocks)}")
                 nxt += int(nrows)
             if nxt != B:
                 raise RuntimeError(f"row_blocks cover {nxt} of {B} rows: {list(row_blocks)}")

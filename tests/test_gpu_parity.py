@@ -5,12 +5,13 @@ the end-to-end bar is BASELINE.json's: <= 1e-4 RMS against the reference CPU for
 F0 / control / checkpoint / RNG draws (golden vectors recorded from the real reference).
 """
 import math
+import os
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import load_npz, rms
+from conftest import ROOT, load_npz, rms
 from gpu_util import build_model, dev, maxabs, record
 
 pytestmark = pytest.mark.gpu
@@ -1306,3 +1307,31 @@ def test_forward_audio_validates_row_blocks(models):
             eng.forward_audio(f0, B, T, pu, nz, ws, row_blocks=bad)
     with pytest.raises(RuntimeError, match="row_blocks"):
         eng.forward_audio(f0, B, T, pu, nz, ws, row_blocks=[(0, 4), (4, 4)], wait_event=torch.cuda.Event())
+
+
+@pytest.mark.parametrize("inst", ["vn", "fl", "tpt"])
+def test_range_proven_lookups_equal_the_clamped_form_bit_for_bit(inst, monkeypatch):
+    """Round 5: where the staged FiLM rows and the worst-case exciter bound (NwsWeights.exciter_bound) prove that a tile's table
+    indices stay inside the table, the fused tail runs floor-free lookups (v_fract / v_cvt_u32).  They must be the SAME bits as
+    the clamped form of shaping.py:136-151 on every input: realistic F0, the timing script's torch.rand inputs, and FiLM
+    parameters blown up so that a good part of the indices leave the table (the proof then fails and the clamped form runs)."""
+    import nws_amd as nws
+
+    nws.ensure_default_config()
+    m = nws.NeuralWaveshaping.load_from_checkpoint(os.path.join(ROOT, "tests", "golden", f"weights_{inst}.npz")).cuda().eval()
+    m.newt = nws.FastNEWT(m.newt)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    B, T = 6, 120
+    cases = [(torch.rand(B, 1, T, device="cuda", generator=g), torch.rand(B, 2, T, device="cuda", generator=g)),
+             (100 + 800 * torch.rand(B, 1, T, device="cuda", generator=g), torch.randn(B, 2, T, device="cuda", generator=g)),
+             (100 + 800 * torch.rand(B, 1, T, device="cuda", generator=g), 6.0 * torch.randn(B, 2, T, device="cuda", generator=g))]
+    pu, nz = torch.rand(101, device="cuda", generator=g), torch.rand(128 * T - 1, device="cuda", generator=g)
+    with torch.no_grad():
+        proven = [m(f0, c, phase_u=pu, noise=nz).clone() for f0, c in cases]
+        assert m._engine.weights()[0].exciter_bound            # the bound table is in place
+        monkeypatch.setenv("NWS_EXCITER_NO_RANGE", "1")
+        m.invalidate_cache()
+        assert not m._engine.weights()[0].exciter_bound
+        clamped = [m(f0, c, phase_u=pu, noise=nz).clone() for f0, c in cases]
+    for a, b in zip(proven, clamped):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
