@@ -263,10 +263,16 @@ class PeerCopyAllGather:
 
     def __init__(self, rows: int, n_samples: int, device, nbuf: int = 2, group=None, dtype=torch.float32,
                  sync_signal: bool = False):
-        """sync_signal: the completion signal is a synchronous collective = launched on the CURRENT stream (torch.distributed
-        launches `async_op=False` collectives there), for callers that keep all exchanges on one stream of their own
-        (CompletionDrivenExchange): no hop to torch's NCCL stream and back, no work handle."""
+        """sync_signal (= host-ordered mode, for callers that issue every exchange from a helper thread on one stream of their
+        own: CompletionDrivenExchange): nothing in an exchange is ordered by a device-side wait on another queue - such a wait,
+        parked on a hardware queue, slows the dispatch of the queues next to it (LABBOOK round 5: +24-30 % on the pipelined step).
+        The pushes go straight onto the per-peer copy streams (the rows are final: the caller has seen their batch complete), the
+        issuing thread then waits ON THE HOST for its copies and for its own release events, and the completion signal is a
+        synchronous collective = launched on the CURRENT stream (torch.distributed launches `async_op=False` collectives there:
+        no hop to its NCCL stream and back, no work handle); the next exchange starts with a host-side wait for that signal."""
         self.sync_signal = bool(sync_signal)
+        self._pending_copies = []            # host-ordered mode: events behind this exchange's pushes
+        self._signalled = False              # host-ordered mode: a completion signal is in flight on the issuing stream
         if not dist.is_initialized():
             raise RuntimeError("PeerCopyAllGather needs an initialised process group (handle exchange)")
         self.group = group
@@ -312,6 +318,9 @@ class PeerCopyAllGather:
         if self._last_work is not None:      # the previous exchange is complete on every rank before new rows travel
             self._last_work.wait()
             self._last_work = None
+        if self.sync_signal and self._signalled and self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()      # (host side: the previous completion signal has landed)
+            self._signalled = False
 
     def release(self, slot: int):
         """The consumer is done with full[slot]: everything it enqueued on the current stream so far may still read it, anything
@@ -326,15 +335,22 @@ class PeerCopyAllGather:
         st = torch.cuda.current_stream(self.device)
         for s, ev in enumerate(self._released):      # this rank's reads of released slots precede its completion signal
             if ev is not None:
-                st.wait_event(ev)
+                if self.sync_signal:
+                    ev.synchronize()
+                else:
+                    st.wait_event(ev)
                 self._released[s] = None
+        for ev in self._pending_copies:              # host-ordered mode: this rank's pushes are complete before it signals
+            ev.synchronize()
+        self._pending_copies = []
         self._held[slot] = True
         if self.backend == "gloo":              # CPU-side test backend: no stream-ordered collectives
             st.synchronize()
             dist.barrier(group=self.group)
             return self.full[slot], None
-        if self.sync_signal:                    # on the current stream itself: later pushes from this stream are ordered behind it
+        if self.sync_signal:                    # on the current stream itself; the next exchange waits for it on the host (_claim)
             dist.all_reduce(self._flag, group=self.group, async_op=False)
+            self._signalled = True
             return self.full[slot], None
         work = dist.all_reduce(self._flag, group=self.group, async_op=True)   # ordered after the copies on this stream
         self._last_work = work
@@ -354,6 +370,17 @@ class PeerCopyAllGather:
         current stream continues after all of the copies"""
         n = src.shape[0]
         cur = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
+        if self.sync_signal and self._copy_streams is not None:
+            # host-ordered: no fork, no join - the copies start at once on their own streams, _signal waits for them on the host
+            for k in range(self.world):
+                p = (self.rank + k) % self.world
+                dst = self.remote[p][slot][lo:lo + n]
+                if p == self.rank and dst.data_ptr() == src.data_ptr():
+                    continue
+                with torch.cuda.stream(self._copy_streams[p]):
+                    dst.copy_(src, non_blocking=True)
+                    self._pending_copies.append(self._copy_streams[p].record_event())
+            return
         fork = cur.record_event() if self._copy_streams is not None else None
         joins = []
         for k in range(self.world):             # start with the right-hand neighbour: the ranks' pushes spread over the links

@@ -8,8 +8,12 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/ev/bench_dr
 python bench.py --no-cpu-baseline --exciter-opts 8 --legs 0 --pmc off > gpurun_out/ev/bench_hybrid_w_optin.json 2>/dev/null
 python bench.py --no-cpu-baseline --inputs realistic --legs 0 --pmc off > gpurun_out/ev/bench_realistic_inputs.json 2>/dev/null
 python bench.py --no-cpu-baseline --exact --steps 50 --legs 0 --pmc off > gpurun_out/ev/bench_exact_shapers.json 2>/dev/null
-NWS_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --pmc off --gather rccl > gpurun_out/ev/bench_world1_rccl.json 2>/dev/null
-NWS_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --pmc off --gather copy > gpurun_out/ev/bench_world1_copy.json 2>/dev/null
+NWS_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --pmc off --legs 0 --batch1-iters 0 --gather rccl > gpurun_out/ev/bench_world1_rccl.json 2>/dev/null
+NWS_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --pmc off --legs 0 --batch1-iters 0 --gather copy > gpurun_out/ev/bench_world1_copy.json 2>/dev/null
+# round 5: the N > 1 issue pattern at world size 1, same-box A/B (single / rccl / copy / sub-batches / the round-4 queued form)
+bash tools/world1_check.sh > gpurun_out/ev/world1_ab.txt 2>&1
+bash tools/scale_check.sh --dry-run --out gpurun_out/ev/scale_dry > gpurun_out/ev/scale_check_dry_run.txt 2>&1
+bash tools/range_check.sh > gpurun_out/ev/range_proven_ab.txt 2>&1
 VARIANTS=12,44,36,68 python tools/exciter_variants.py > gpurun_out/ev/exciter_variants.txt 2>&1
 python tools/gru_variants.py > gpurun_out/ev/gru_variants.txt 2>&1
 python scripts/time_buffer_sizes.py --use-fast-newt --checkpoint tests/golden/weights_vn.npz 2>/dev/null | grep '^buffer' > gpurun_out/ev/buffer_fast.txt
@@ -26,6 +30,6 @@ MODES=1,2,258,514,770,1282 python tools/mlp_variants.py 64 500 48 500 32 500 128
 python tools/mlp_timeline.py > gpurun_out/ev/mlp_timeline.txt 2>&1
 python tools/generic_profile.py > gpurun_out/ev/generic_path.txt 2>&1
 bash tools/generic_kernels.sh 64 500 > gpurun_out/ev/generic_kernels.txt 2>&1
-bash tools/collect_profiles.sh ${ROUND:-r04} > gpurun_out/ev/collect.log 2>&1
-ls gpurun_out/prof_${ROUND:-r04} | head -30
+bash tools/collect_profiles.sh ${ROUND:-r05} > gpurun_out/ev/collect.log 2>&1
+ls gpurun_out/prof_${ROUND:-r05} | head -30
 du -sh gpurun_out

@@ -2,7 +2,7 @@
 # then same-box A/B of the one-stream kernel time, the pipelined step and the realistic-input step
 export TMPDIR=/tmp
 mkdir -p gpurun_out/rg
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -p no:cacheprovider -k "range_proven or e2e or full_size or batch64 or hipgraph or lut or newt" > gpurun_out/rg/pytest.txt 2>&1; tail -3 gpurun_out/rg/pytest.txt
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -p no:cacheprovider -k "range_proven" > gpurun_out/rg/pytest.txt 2>&1; tail -1 gpurun_out/rg/pytest.txt
 Q="--no-cpu-baseline --pmc off --legs 0 --batch1-iters 0"
 for i in 1 2; do
   for nr in 1 ""; do
