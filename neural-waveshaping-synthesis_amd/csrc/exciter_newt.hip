@@ -1517,6 +1517,16 @@ int nws_exciter_newt_add(const NwsWeights* w, const float* f0, const float* f0_u
         static const size_t hot_pad = [] { const char* e = getenv("NWS_EXCITER_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
 #define NWS_HOT(O) exciter_newt_kernel<kModeLutPairsDiv6, 0, 2, O><<<g2, 512, base + hot_pad, st>>>( \
             *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out, nullptr, add_in, xcd_groups)
+        // (measurements, VERDICT r4 #4: NWS_EXCITER_HPB=1 launches the default kernel as 4-wave workgroups of one hop - three of them
+        // fit beside a 251-register recurrence wave on a SIMD where one 8-wave workgroup = two waves per SIMD does; alone it is
+        // LDS-bound at four workgroups = four waves per SIMD instead of six.  Same bits.)
+        static const bool one_hop = [] { const char* e = getenv("NWS_EXCITER_HPB"); return e && e[0] == '1'; }();
+        if (one_hop && opts == 0) {
+          const int xg1 = xcd_map && (long long)T * B >= 64 && (long long)T * B < (1ll << 31) ? T : 0;
+          const dim3 g1 = xg1 ? dim3((unsigned)(T * B), 1) : dim3(T, B);
+          exciter_newt_kernel<kModeLutPairsDiv6, 0, 1, kOptFilmMfma | kOptLowReg><<<g1, 256, base + hot_pad, st>>>(
+              *w, f0, f0_up, carry, phase_u, rand_phase, film, T, sample_rate, exciter_out, newt_out, nullptr, add_in, xg1);
+        } else
         if (opts & NWS_EXCITER_VALU_FILM) NWS_HOT(0);
         else if (opts & NWS_EXCITER_ONE_TERM) NWS_HOT(kOptFilmMfma | kOptOneTerm | kOptLowReg);
         else if (opts & NWS_EXCITER_HYBRID_W) { if (low_reg) NWS_HOT(kOptFilmMfma | kOptHybrid | kOptHybridW | kOptLowReg); else NWS_HOT(kOptFilmMfma | kOptHybrid | kOptHybridW); }
