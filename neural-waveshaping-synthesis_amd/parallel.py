@@ -170,6 +170,7 @@ class CompletionDrivenExchange:
         self._tickets = [None] * int(nslots)
         self.profile = None                 # a list: the worker appends (wait, issue, record) seconds per exchange (diagnosis)
         self._all = []
+        self._prune_at = 64
         self._q = queue.SimpleQueue()
         self._thread = threading.Thread(target=self._run, name="nws-exchange", daemon=True)
         self._thread.start()
@@ -206,8 +207,9 @@ class CompletionDrivenExchange:
         t = _Ticket()
         self._tickets[slot] = t
         self._all.append(t)
-        if len(self._all) > 4 * len(self._tickets) + 16:
-            self._all = [x for x in self._all if not x.issued.is_set()] + self._all[-len(self._tickets):]
+        if len(self._all) >= self._prune_at:         # forget issued tickets now and then (amortised: the bound doubles with the backlog)
+            self._all = [x for x in self._all if not x.issued.is_set() or x.exc is not None]
+            self._prune_at = max(64, 2 * len(self._all))
         self._q.put((t, ready, issue))
         return t
 
@@ -232,6 +234,7 @@ class CompletionDrivenExchange:
             t.issued.wait()
             self._check(t)
         self._all = []
+        self._prune_at = 64
         if self.cuda:
             self.stream.synchronize()
 
