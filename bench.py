@@ -1050,6 +1050,8 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wpath, T, a.cpu_seconds)
     if distributed:
+        if xchg is not None:
+            xchg.close()                # the helper thread is idle (every region drained it): join before the communicator goes
         dist.destroy_process_group()
     if rank == 0:
         try:   # RCCL prints its banner through C stdio: drain that first so that the JSON line is the last line of stdout
