@@ -25,6 +25,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 # sums are scalar by hand).
 KEEP_SLP = ("fir_noise.hip", "control_gru.hip")
 EXTRA_FLAGS = {src: ["-fno-slp-vectorize"] for src in SOURCES if src not in KEEP_SLP}
+# experiments: extra hipcc flags for every file (e.g. NWS_EXTRA_HIPCC_FLAGS="-DNWS_EXCITER_PRIO_MIX=1"); part of the build stamp
+FLAGS += [f for f in os.environ.get("NWS_EXTRA_HIPCC_FLAGS", "").split() if f]
 LLVM_BIN = "/opt/rocm/lib/llvm/bin"
 # kernels that contain the hazardous form on purpose (the probe that demonstrates it)
 SWIZZLE_ALLOW = ("pk_probe_kernel", "pk_probe2_kernel", "pk_probe_mixed_kernel")
