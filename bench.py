@@ -510,6 +510,15 @@ def main():
         else:       # one all_gather_into_tensor per block into the block-major gather buffer (parallel.gather_block_major)
             par.gather_block_major(full[i % nbuf], y, row0 // n, len(blocks), async_op=False)
 
+    # sub-batch exchange: one event per (gather buffer, row block), recorded by the library behind the block's reverb
+    blk_events = [[torch.cuda.Event() for _ in blocks] for _ in range(nbuf)] if blocks is not None else None
+
+    def issue_blocks(i, y, evs):
+        """worker thread: every row block of this step's waveforms, each as soon as the host has seen its reverb complete"""
+        for q, (row0, n) in enumerate(blocks):
+            evs[q].synchronize()
+            issue_block(i, y, row0, n, row0 + n == B)
+
     def post_behind(stream, slot_i, issue):
         """the exchange `issue` leaves once everything enqueued on `stream` so far is complete"""
         ev = torch.cuda.Event()
@@ -564,11 +573,10 @@ def main():
             # pattern as the single-GPU run, nothing but the exchange added
             if blocks is not None and do_gather:
                 # sub-batch exchange: block q leaves as soon as the host has seen ITS reverb complete, under the reverb of
-                # block q + 1 (rendered into a batch of its own: the list-of-views all_gather must not alias its input)
-                def on_block(row0, n, out, _i=i, _slot=slot_i, _au=au):
-                    post_behind(_au, _slot, lambda: issue_block(_i, out, row0, n, row0 + n == B))
-
-                pipe.submit(f0, control, generator=shared_gen, row_blocks=blocks, on_block=on_block)
+                # block q + 1.  ONE op call renders the audio half block by block and records the slot's own event behind each block
+                # (nws_forward_audio_blocks), ONE job goes to the helper thread (rendered into a batch of its own, not in place)
+                y = pipe.submit(f0, control, generator=shared_gen, row_blocks=blocks, block_events=blk_events[slot_i])
+                xchg.post(slot_i, None, lambda _i=i, _y=y, _evs=blk_events[slot_i]: issue_blocks(_i, _y, _evs))
                 return None
             # the batch is rendered straight into this rank's rows of the gather buffer (no local copy: the all-gather is
             # in place for RCCL, the peer pushes skip the local shard)
@@ -733,10 +741,9 @@ def main():
                     xchg.acquire(slot_i, au)
                     dst_c = peer.local_rows(slot_i) if peer is not None else full[slot_i][rank * B:(rank + 1) * B]
                 if blocks is not None:
-                    def on_block_c(row0, n, out, _i=i, _slot=slot_i, _au=au):
-                        post_behind(_au, _slot, lambda: issue_block(_i, out, row0, n, row0 + n == B))
-
-                    ys.append(pipe.submit(f0, control, phase_u=pu_c, noise=nz_c, row_blocks=blocks, on_block=on_block_c))
+                    y = pipe.submit(f0, control, phase_u=pu_c, noise=nz_c, row_blocks=blocks, block_events=blk_events[slot_i])
+                    xchg.post(slot_i, None, lambda _i=i, _y=y, _evs=blk_events[slot_i]: issue_blocks(_i, _y, _evs))
+                    ys.append(y)
                     continue
                 # rendered in place into the gather buffer, as the timed loop does (the rows are cloned for the comparison below
                 # before the slot is rendered into again: nbuf batches later)

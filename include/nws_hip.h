@@ -380,6 +380,15 @@ int nws_forward_audio_pre(const NwsWeights* w, const NwsForwardAux* aux, const f
                           size_t workspace_bytes, void* stream);
 int nws_forward_reverb_rows(const NwsForwardAux* aux, int B, int T, int row0, int nrows, float* out, void* workspace,
                             size_t workspace_bytes, void* stream);
+/* The two above in ONE call for a fixed list of row blocks: audio_pre, then for q = 0 .. nblocks - 1 the reverb of rows
+ * [row0[q], row0[q] + nrows[q]) followed by hipEventRecord(events[q], stream) when events and events[q] are non-NULL - a multi-GPU
+ * caller's helper thread waits on those events (host side) and pushes each sub-batch as it completes (bench.py --gather-chunks:
+ * one op call per step instead of 1 + nblocks, and no event record through the host language per block).  The blocks must tile
+ * [0, B) in order, even sizes except the last.  Same bits as nws_forward_audio. */
+int nws_forward_audio_blocks(const NwsWeights* w, const NwsForwardAux* aux, const float* f0, int B, int T, float sample_rate,
+                             const float* phase_u, const float* rand_phase, const float* noise, float* out, void* workspace,
+                             size_t workspace_bytes, void* stream, const int32_t* row0, const int32_t* nrows,
+                             void* const* events /* hipEvent_t[nblocks] or NULL */, int nblocks);
 
 /*
  * Perceptual-loudness feature, the step before the synthesis path:

@@ -139,6 +139,8 @@ _PROTOTYPES = {
     "nws_forward_audio_pre": (C.c_int, [C.POINTER(NwsWeights), C.POINTER(NwsForwardAux), _fp, C.c_int, C.c_int, C.c_float,
                                         _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
     "nws_forward_reverb_rows": (C.c_int, [C.POINTER(NwsForwardAux), C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_size_t, _fp]),
+    "nws_forward_audio_blocks": (C.c_int, [C.POINTER(NwsWeights), C.POINTER(NwsForwardAux), _fp, C.c_int, C.c_int, C.c_float, _fp, _fp, _fp, _fp,
+                                           _fp, C.c_size_t, _fp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.c_int]),
     "nws_loudness_dft_bytes": (C.c_size_t, [C.c_int]),
     "nws_loudness_dft_matrix": (C.c_int, [C.c_int, _fp, _fp]),
     "nws_loudness_frames": (C.c_int, [C.c_int, C.c_int]),

@@ -248,6 +248,30 @@ int nws_forward_reverb_rows(const NwsForwardAux* aux, int B, int T, int row0, in
                     left, stream);
 }
 
+int nws_forward_audio_blocks(const NwsWeights* w, const NwsForwardAux* aux, const float* f0, int B, int T, float sample_rate,
+                             const float* phase_u, const float* rand_phase, const float* noise, float* out, void* workspace,
+                             size_t workspace_bytes, void* stream, const int32_t* row0, const int32_t* nrows, void* const* events,
+                             int nblocks) {
+  if (!row0 || !nrows || nblocks <= 0 || !out) return NWS_ERR_BAD_ARG;
+  int next = 0;
+  for (int q = 0; q < nblocks; ++q) {      // in order, covering [0, B), even sizes except the last (two utterances share a transform)
+    if (row0[q] != next || nrows[q] <= 0 || ((nrows[q] & 1) && q != nblocks - 1)) return NWS_ERR_BAD_ARG;
+    next += nrows[q];
+  }
+  if (next != B) return NWS_ERR_BAD_ARG;
+  int rc = nws_forward_audio_pre(w, aux, f0, B, T, sample_rate, phase_u, rand_phase, noise, workspace, workspace_bytes, stream);
+  if (rc != NWS_OK) return rc;
+  for (int q = 0; q < nblocks; ++q) {
+    rc = nws_forward_reverb_rows(aux, B, T, row0[q], nrows[q], out, workspace, workspace_bytes, stream);
+    if (rc != NWS_OK) return rc;
+    if (events != nullptr && events[q] != nullptr) {
+      const hipError_t e = hipEventRecord((hipEvent_t)events[q], (hipStream_t)stream);
+      if (e != hipSuccess) return (int)e;
+    }
+  }
+  return NWS_OK;
+}
+
 int nws_profile_begin(int slots, unsigned stage_mask) {
   nws_profile_end();
   if (slots <= 0) return NWS_ERR_BAD_ARG;

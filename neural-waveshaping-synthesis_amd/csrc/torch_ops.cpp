@@ -15,6 +15,7 @@
 #include <torch/library.h>
 
 #include <tuple>
+#include <vector>
 
 #include "../../include/nws_hip.h"
 #include "../../include/nws_hip_debug.h"
@@ -211,6 +212,35 @@ void forward_reverb_rows(const Tensor& fir_design, const Tensor& plan, const Ten
   Launch L(out);
   nws_check(nws_forward_reverb_rows(&a.aux, (int)out.size(0), (int)T, (int)row0, (int)nrows, out.data_ptr<float>(), workspace.data_ptr(),
                                     (size_t)workspace.numel(), L.stream), "nws_forward_reverb_rows");
+}
+
+// the same two in one call for a fixed list of row blocks, an event recorded behind each block (sub-batch exchange: one op per step)
+void forward_audio_blocks(const Tensor& wdesc, const Tensor& f0, const Tensor& phase_u, const Tensor& rand_phase, const Tensor& noise,
+                          const Tensor& fir_design, const Tensor& plan, const Tensor& reverb_tables, const Tensor& reverb_spectrum,
+                          Tensor& workspace, double sample_rate, Tensor& out, at::IntArrayRef row0, at::IntArrayRef nrows,
+                          at::IntArrayRef events) {
+  const NwsWeights* w = weights_of(wdesc);
+  check_dev(f0, "f0");
+  TORCH_CHECK(f0.dim() == 3 && f0.size(1) == 1 && f0.size(2) >= 2, "f0: expected (B, 1, T>=2), got ", f0.sizes());
+  const int64_t B = f0.size(0), T = f0.size(2);
+  check_draws(phase_u, rand_phase, noise, T, f0);
+  check_dev(workspace, "workspace", at::kByte);
+  check_dev(out, "out");
+  check_same_device(f0, "f0", workspace, "workspace");
+  check_same_device(f0, "f0", out, "out");
+  TORCH_CHECK(out.dim() == 2 && out.size(0) == B && out.size(1) == T * NWS_HOP && out.is_contiguous(), "out: expected a contiguous (", B, ", ",
+              T * NWS_HOP, "), got ", out.sizes());
+  TORCH_CHECK(!row0.empty() && row0.size() == nrows.size() && (events.empty() || events.size() == row0.size()),
+              "forward_audio_blocks: row0 / nrows / events must have one entry per block");
+  std::vector<int32_t> r0(row0.begin(), row0.end()), nr(nrows.begin(), nrows.end());
+  std::vector<void*> ev(events.size());
+  for (size_t q = 0; q < events.size(); ++q) ev[q] = reinterpret_cast<void*>(static_cast<uintptr_t>(events[q]));
+  Aux a(fir_design, plan, reverb_tables, reverb_spectrum);
+  Launch L(f0);
+  nws_check(nws_forward_audio_blocks(w, &a.aux, f0.data_ptr<float>(), (int)B, (int)T, (float)sample_rate, phase_u.data_ptr<float>(),
+                                     rand_phase.data_ptr<float>(), noise.data_ptr<float>(), out.data_ptr<float>(), workspace.data_ptr(),
+                                     (size_t)workspace.numel(), L.stream, r0.data(), nr.data(), ev.empty() ? nullptr : ev.data(), (int)r0.size()),
+            "nws_forward_audio_blocks");
 }
 
 // ---- stages ------------------------------------------------------------------------------------------------------------
@@ -844,6 +874,9 @@ TORCH_LIBRARY(newt_hip, m) {
         "int record_event) -> Tensor", &forward_audio);
   m.def("forward_audio_pre(Tensor wdesc, Tensor f0, Tensor phase_u, Tensor rand_phase, Tensor noise, Tensor fir_design, Tensor plan, "
         "Tensor reverb_tables, Tensor reverb_spectrum, Tensor(a!) workspace, float sample_rate) -> ()", &forward_audio_pre);
+  m.def("forward_audio_blocks(Tensor wdesc, Tensor f0, Tensor phase_u, Tensor rand_phase, Tensor noise, Tensor fir_design, Tensor plan, "
+        "Tensor reverb_tables, Tensor reverb_spectrum, Tensor(a!) workspace, float sample_rate, Tensor(b!) out, int[] row0, int[] nrows, "
+        "int[] events) -> ()", &forward_audio_blocks);
   m.def("forward_reverb_rows(Tensor fir_design, Tensor plan, Tensor reverb_tables, Tensor reverb_spectrum, Tensor(a!) workspace, int T, "
         "int row0, int nrows, Tensor(b!) out) -> ()", &forward_reverb_rows);
   m.def("phase_carry(Tensor? f0, Tensor? f0_up) -> Tensor", &phase_carry);

@@ -643,7 +643,7 @@ class Engine:
                                                  ws.numel(), stream_ptr(dev)), "nws_forward_control")
 
     def forward_audio(self, f0, B, T, phase_u, noise, ws, out=None, wait_event=None, record_event=None, row_blocks=None,
-                      on_block=None):
+                      on_block=None, block_events=None):
         """frame MLPs .. reverb from the head of `ws` (forward_control must have completed in stream order / by event).
         wait_event / record_event: torch.cuda.Event hooks right before / after the oscillator kernel (nws_forward_audio_ev).
         row_blocks = [(row0, nrows), ...] (even row0, nrows >= 4): the reverb runs block by block and `on_block(row0, nrows,
@@ -669,6 +669,35 @@ class Engine:
                 raise RuntimeError(f"row_blocks cover {nxt} of {B} rows: {list(row_blocks)}")
             if wait_event is not None or record_event is not None:
                 raise RuntimeError("wait_event / record_event hook the single-call form; they cannot be combined with row_blocks")
+            if block_events is not None and on_block is None:
+                # ONE call: audio_pre + every block's reverb, block q's torch.cuda.Event recorded behind it by the library itself
+                # (nws_forward_audio_blocks; a helper thread waits on the events and pushes each sub-batch as it completes)
+                if len(block_events) != len(row_blocks):
+                    raise RuntimeError("block_events: one torch.cuda.Event per row block")
+                with torch.cuda.device(dev):
+                    if out is None:
+                        out = torch.empty((B, N), dtype=torch.float32, device=dev)
+                    for ev in block_events:         # (a never-recorded torch event has no handle yet: record() creates it lazily)
+                        if not ev.cuda_event:
+                            ev.record()
+                    r0 = [int(r) for r, _ in row_blocks]
+                    nr = [int(n) for _, n in row_blocks]
+                    evs = [int(ev.cuda_event) for ev in block_events]
+                    if o is not None:
+                        o.forward_audio_blocks(wdesc, f0, phase_u, self._w[1][-2], noise, self._fir_design, plan_t, tables, spec, ws, sr, out,
+                                               r0, nr, evs)
+                    else:
+                        aux = NwsForwardAux()
+                        aux.fir_design = ptr(self._fir_design)
+                        aux.plan = C.pointer(plan)
+                        aux.reverb_tables = ptr(tables)
+                        aux.reverb_spectrum = ptr(spec)
+                        n = len(r0)
+                        check(_lib.lib().nws_forward_audio_blocks(C.byref(w), C.byref(aux), ptr(f0), B, T, sr, ptr(phase_u), ptr(self._w[1][-2]),
+                                                                  ptr(noise), ptr(out), ptr(ws), ws.numel(), stream_ptr(dev),
+                                                                  (C.c_int32 * n)(*r0), (C.c_int32 * n)(*nr), (C.c_void_p * n)(*evs), n),
+                              "nws_forward_audio_blocks")
+                return out
             with torch.cuda.device(dev):
                 if out is None:
                     out = torch.empty((B, N), dtype=torch.float32, device=dev)

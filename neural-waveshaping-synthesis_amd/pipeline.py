@@ -142,7 +142,8 @@ class ForwardPipeline:
         n = B // chunks
         return [(q * n, n) for q in range(chunks)]
 
-    def submit(self, f0, control, *, phase_u=None, noise=None, out=None, row_blocks=None, on_block=None, generator=None):
+    def submit(self, f0, control, *, phase_u=None, noise=None, out=None, row_blocks=None, on_block=None, generator=None,
+               block_events=None):
         m = self.model
         f0 = _req(f0 if f0.is_contiguous() else f0.contiguous(), "f0")
         control = _req(control if control.is_contiguous() else control.contiguous(), "control")
@@ -184,7 +185,8 @@ class ForwardPipeline:
                                              record_event=slot.ev_exciter)
                 self._last_exciter = slot.ev_exciter
             else:
-                out = self.eng.forward_audio(f0, B, T, pu, nz, slot.ws, out=out, row_blocks=row_blocks, on_block=on_block)
+                out = self.eng.forward_audio(f0, B, T, pu, nz, slot.ws, out=out, row_blocks=row_blocks, on_block=on_block,
+                                             block_events=block_events)
             slot.ev_audio.record(au)
         slot.used = True
         slot.keep = (f0, control, pu, nz)        # inputs stay alive until the slot is reused

@@ -134,6 +134,12 @@ def test_reverb_row_blocks_equal_the_single_call():
     seen = []
     out = eng.forward_audio(f0, B, T, pu, nz, ws, row_blocks=[(0, 4), (4, 4), (8, 8)], on_block=lambda r0, n, o: seen.append((r0, n)))
     assert seen == [(0, 4), (4, 4), (8, 8)] and torch.equal(out, ref)
+    # the same blocks in ONE library call, the caller's event recorded behind each block (nws_forward_audio_blocks)
+    evs = [torch.cuda.Event() for _ in range(3)]
+    out3 = eng.forward_audio(f0, B, T, pu, nz, ws, row_blocks=[(0, 4), (4, 4), (8, 8)], block_events=evs)
+    for e in evs:
+        e.synchronize()
+    assert torch.equal(out3, ref)
     # an odd LAST block is fine (it pads its last pair like an odd batch does); an odd block in the middle is refused
     B2 = 7
     ws2 = eng.new_workspace(B2, T)
