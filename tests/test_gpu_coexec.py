@@ -104,3 +104,33 @@ def test_torch_rng_draws_unchanged_beside_mfma_load():
             got = draws()
             torch.cuda.synchronize()
             assert all(torch.equal(a, c) and torch.equal(b, d) for (a, b), (c, d) in zip(got, ref)), kind
+
+
+def test_every_pipeline_of_a_process_runs_on_one_placed_stream_set():
+    """pipeline.placed_streams (round 5): hardware queues land on the command processor's four pipes in first-use order, so the
+    pipeline's streams are created and first used ONCE per process and shape (exchange, audio 0, audio 1, control 0, control 1) and
+    every ForwardPipeline of that shape shares them - a second set would sit on whatever pipes the creation count has reached."""
+    import importlib
+
+    from gpu_util import build_model
+
+    pm = importlib.import_module("neural-waveshaping-synthesis_amd.pipeline")
+    m = build_model(True)
+    p1 = pm.ForwardPipeline(m, depth=4, audio_streams=2, control_streams=2)
+    p2 = pm.ForwardPipeline(m, depth=3, audio_streams=2, control_streams=2)
+    assert p1.exchange is p2.exchange and all(a is b for a, b in zip(p1.audio + p1.control, p2.audio + p2.control))
+    assert len({s.cuda_stream for s in [p1.exchange] + p1.audio + p1.control}) == 5          # five distinct HIP streams
+    assert all(s.priority == -1 for s in p1.control) and all(s.priority == 0 for s in p1.audio + [p1.exchange])
+    p3 = pm.ForwardPipeline(m, depth=4, audio_streams=2, control_streams=1)                  # another shape: its own set
+    assert p3.audio[0] is not p1.audio[0]
+    # two pipelines sharing the streams still return the plain forward's bits
+    g = torch.Generator(device="cuda").manual_seed(8)
+    f0 = 100 + 600 * torch.rand(4, 1, 40, device="cuda", generator=g)
+    c = torch.randn(4, 2, 40, device="cuda", generator=g)
+    pu, nz = torch.rand(101, device="cuda", generator=g), torch.rand(128 * 40 - 1, device="cuda", generator=g)
+    with torch.no_grad():
+        ref = m(f0, c, phase_u=pu, noise=nz)
+        ys = [p.submit(f0, c, phase_u=pu, noise=nz) for p in (p1, p2, p1, p2, p3)]
+        for p in (p1, p2, p3):
+            p.synchronize()
+    assert all(torch.equal(y, ref) for y in ys)
