@@ -471,14 +471,19 @@ def main():
     nbuf = max(len(pipe.slots), a.gather_slots) if (use_pipe and distributed) else (len(pipe.slots) if use_pipe else len(streams))
     full, peer = None, None
     gather_kind = a.gather if distributed else None
-    if distributed and (a.gather == "copy" or share_gpu):
-        # copy-engine all-gather: peer-mapped gather buffers, one device-to-device copy per peer (also the only form that
-        # works for two smoke-test ranks on ONE device, where RCCL refuses to initialise)
+    # (two smoke-test ranks on ONE device, where RCCL refuses to initialise: the peer-copy form, unless
+    # NWS_BENCH_SHARE_GPU_COLLECTIVE=1 asks for the collective form on gloo - the in-place all_gather_into_tensor of the RCCL branch,
+    # world size 2, host-staged by gloo)
+    share_collective = share_gpu and os.environ.get("NWS_BENCH_SHARE_GPU_COLLECTIVE") == "1" and a.gather == "rccl"
+    if distributed and (a.gather == "copy" or (share_gpu and not share_collective)):
+        # copy-engine all-gather: peer-mapped gather buffers, one device-to-device copy per peer
         peer = par.PeerCopyAllGather(B, N, dev, nbuf=nbuf, sync_signal=use_pipe)
         full = peer.full
         gather_kind = "copy"
     elif distributed:
         full = [torch.empty((B * world, N), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+        if share_collective:
+            gather_kind = "rccl branch on gloo"
 
     blocks = pmod.ForwardPipeline.row_blocks(B, a.gather_chunks) if (distributed and use_pipe) else None
     # N > 1 with the pipeline: every exchange is issued by a helper thread, on its own stream, once the HOST has seen its batch

@@ -156,9 +156,10 @@ def test_reverb_row_blocks_equal_the_single_call():
 
 def test_scale_check_dry_run_two_ranks_sharing_the_gpu(tmp_path):
     """tools/scale_check.sh (the one call that produces the 1 / 2 / 4 / 8-GPU table on a multi-GPU node) end to end on the
-    hardware available here: --gpus 1, then two ranks sharing cuda:0 for every exchange form (rccl falls back to the peer-copy
-    form there: RCCL refuses two ranks on one device) x whole batch / four sub-batches; every cell must produce its line with a
-    clean self-check."""
+    hardware available here: --gpus 1, then two ranks sharing cuda:0 for every exchange form (RCCL refuses two ranks on one
+    device: the rccl cells run the collective branch - in-place all_gather_into_tensor / block-major sub-batches from the helper
+    thread - on gloo) x whole batch / four sub-batches; every cell must produce its line with a clean self-check, i.e. every
+    rank found every other rank's rows, re-rendered by itself, bit for bit in its gather buffer."""
     r = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale_check.sh"), "--dry-run", "--out", str(tmp_path)], env=ENV,
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
@@ -169,6 +170,8 @@ def test_scale_check_dry_run_two_ranks_sharing_the_gpu(tmp_path):
         j = json.loads((tmp_path / c).read_text())
         sc = j["pipeline_selfcheck"]
         assert sc.get("mismatching_all_ranks", sc["mismatching"]) == 0
+        if c.startswith("g2_"):
+            assert sc["gathered_rows_match"] and j["exchange"]["kind"] == ("copy" if "_copy_" in c else "rccl branch on gloo")
 
 
 def test_world1_overhead_of_the_multi_gpu_issue_pattern():

@@ -4,7 +4,7 @@ one JSON line per cell under gpurun_out/scale/, then a table: samples/s, weak-sc
 exchange.overlap_efficiency, step over the plain single-GPU pattern - and the winning exchange form per GPU count.
 
     python tools/scale_check.py [--steps 200] [--gpus 1,2,4,8] [--out gpurun_out/scale]
-    python tools/scale_check.py --dry-run      # two ranks SHARING one GPU (gloo rendezvous, peer-copy exchange), tiny shapes:
+    python tools/scale_check.py --dry-run      # two ranks SHARING one GPU (gloo rendezvous; rccl cells = the collective branch on gloo), tiny shapes:
                                                # exercises every cell's code path where only one MI355X is available
 """
 import argparse
@@ -29,6 +29,7 @@ def run_cell(n, gather, chunks, steps, out_dir, dry, extra):
                "--master-port", str(port), os.path.join(ROOT, "bench.py"), *args]
         if dry:
             env["NWS_BENCH_SHARE_GPU"] = "1"
+            env["NWS_BENCH_SHARE_GPU_COLLECTIVE"] = "1"      # --gather rccl: the collective branch, on gloo (RCCL refuses two ranks on one device)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     with open(os.path.join(out_dir, name + ".log"), "w") as f:
