@@ -16,9 +16,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_cell(n, gather, chunks, steps, out_dir, dry, extra):
-    name = f"g{n}_{gather}_c{chunks}"
+def run_cell(n, gather, chunks, steps, out_dir, dry, extra, forced=False):
+    name = f"g{n}_{gather}_c{chunks}" + ("_forced" if forced else "")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if forced:      # the N > 1 issue pattern at world size 1 (real RCCL, nothing to send): what the exchange machinery costs by itself
+        env["NWS_BENCH_FORCE_DIST"] = "1"
     args = ["--gpus", str(n), "--steps", str(steps), "--warmup", "10", "--no-cpu-baseline", "--pmc", "off", "--legs", "0",
             "--batch1-iters", "0", "--gather", gather, "--gather-chunks", str(chunks), *extra]
     if n == 1:
@@ -68,6 +70,10 @@ def main():
             cells.append((n, gather, chunks, name, d))
             if n == 1 and d is not None:
                 base = d["value"]
+        if n == 1 and not a.dry_run:
+            for gather in ("rccl", "copy"):
+                name, d = run_cell(1, gather, 1, steps, a.out, False, extra, forced=True)
+                cells.append((1, gather, 1, name, d))
     print(f"{'cell':16s} {'ms/step':>9s} {'samples/s':>12s} {'efficiency':>10s} {'overlap':>8s} {'step/plain':>10s} {'rccl world':>10s} selfcheck")
     best = {}
     for n, gather, chunks, name, d in cells:
