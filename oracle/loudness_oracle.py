@@ -20,7 +20,10 @@ librosa==0.8.0).  Its published algorithm, restated here:
 Parity status: UNPINNED against librosa itself (absent, no network).  The STFT half is pinned against an independent
 implementation with the same documented semantics (torch.stft, center=True, reflect, periodic hann) in
 tests/test_oracle_loudness.py, against scipy.signal.stft (a second one), and the window against scipy.signal.get_window - the
-very call librosa makes, scipy being in the image; the dB half is a direct transcription of the formulas above.
+very call librosa makes, scipy being in the image; the dB half is a direct transcription of the formulas above.  Round 5: the WHOLE
+feature also agrees to 3e-9 (normalised units) with `transformers.audio_utils.spectrogram` + `amplitude_to_db` - a third-party numpy port
+of the two librosa calls that IS in the image (tests/test_oracle_loudness.py) - on tones, noise, a click in silence and silence.  Evidence,
+not a pin: librosa's own outputs have never been seen here.
 """
 import numpy as np
 
