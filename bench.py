@@ -700,8 +700,6 @@ def main():
                 join_streams()
                 return timed(k2, **kw)
 
-            if use_pipe and "plainfirst" in DIAG:
-                extra["plain_first_ms"] = region(plain=True)[0] / k2 * 1e3
             g_el, g_ranks = region(do_compute=False)
             c_el, c_ranks = region(do_gather=False)
             extra["exchange"] = {"kind": gather_kind, "chunks": len(blocks) if blocks else 1,

@@ -30,6 +30,8 @@ tests/test_gpu_coexec.py soaks exactly this configuration bit for bit.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -64,9 +66,9 @@ def placed_streams(dev, audio_streams: int = 2, control_streams: int = 2):
       * the two audio and two control streams must sit on FOUR DIFFERENT pipes: the next batch's recurrence queued on an audio
         stream's pipe waits for the oscillator kernel to finish dispatching (0.399 ms per step -> 0.47 / 0.53 with the second
         control stream on the first / second audio stream's pipe; period 4 in the number of queues created in between);
-      * a fifth queue (the exchange of the multi-GPU path) shares a pipe with one of the four whatever happens: beside a
-        control stream AND created before it, three small launches per step on it are free (x1.00-1.02); created after it, or
-        beside an audio stream, they cost 8-12 % of the step.
+      * a fifth queue (the exchange of the multi-GPU path) shares a pipe with one of the four whatever happens: beside an audio
+        stream three small launches per step on it cost 8-13 % of the step in every session; beside a control stream and created
+        BEFORE it they were free in every session (x1.00-1.02), created after it free in one session and +11 % in another.
     Hence the first-use order  exchange, audio 0, audio 1, control 0, control 1  (consecutive queues: the four on four pipes,
     the exchange queue ahead of control 1 on its pipe), and ONE set per process: every ForwardPipeline of the same shape runs
     on the same streams (a second set would land on whatever pipes the creation count has reached - bench legs that built
@@ -82,7 +84,22 @@ def placed_streams(dev, audio_streams: int = 2, control_streams: int = 2):
     audio = [torch.cuda.Stream(device=dev) for _ in range(audio_streams)]
     control = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(control_streams)]
     touch = torch.zeros(64, device=dev)
-    for st in [xs] + audio + control:          # first use, in this order, one at a time
+    order = [xs] + audio + control
+    probe = os.environ.get("NWS_STREAM_ORDER")     # measurements (tools/queue_order_probe.sh): another first-use order, e.g.
+    if probe:                                      # "a0,a1,c0,d,d,c1,x" - x exchange, aK / cK audio / control, d / h a dummy normal /
+        order, dummies = [], []                    # high-priority stream that is never used again; unnamed streams follow in the default order
+        for tok in probe.split(","):
+            if tok in ("d", "h"):
+                dummies.append(torch.cuda.Stream(device=dev, priority=-1 if tok == "h" else 0))
+                order.append(dummies[-1])
+            elif tok == "x":
+                order.append(xs)
+            elif tok[:1] in ("a", "c") and tok[1:].isdigit():
+                lst = audio if tok[0] == "a" else control
+                if int(tok[1:]) < len(lst):
+                    order.append(lst[int(tok[1:])])
+        order += [st for st in [xs] + audio + control if not any(st is o for o in order)]
+    for st in order:                           # first use, in this order, one at a time
         with torch.cuda.stream(st):
             touch.fill_(0.0)
         st.synchronize()
