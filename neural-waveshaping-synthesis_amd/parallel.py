@@ -213,8 +213,13 @@ class CompletionDrivenExchange:
         self._q.put((t, ready, issue))
         return t
 
-    @staticmethod
-    def _check(t):
+    TIMEOUT_S = 600.0       # a batch or an exchange that has not completed by then never will: fail loudly instead of hanging
+
+    @classmethod
+    def _check(cls, t):
+        if not t.issued.wait(timeout=cls.TIMEOUT_S):
+            raise RuntimeError(f"exchange worker: an exchange was not issued within {cls.TIMEOUT_S:.0f} s (its batch never completed, "
+                               f"or a collective is stuck waiting for a peer)")
         if t.exc is not None:
             raise RuntimeError("exchange worker failed") from t.exc
 
@@ -222,7 +227,6 @@ class CompletionDrivenExchange:
         t = self._tickets[slot]
         if t is None:
             return
-        t.issued.wait()
         self._check(t)
         if self.cuda and t.done is not None:
             (stream or torch.cuda.current_stream(self.device)).wait_event(t.done)
@@ -231,7 +235,6 @@ class CompletionDrivenExchange:
     def drain(self):
         """Every posted exchange issued AND complete (host-side)."""
         for t in self._all:
-            t.issued.wait()
             self._check(t)
         self._all = []
         self._prune_at = 64
