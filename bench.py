@@ -391,6 +391,8 @@ def time_leg(model, f0, control, steps, warmup, audio_streams, control_streams):
 
 def main():
     a = parse()
+    if os.environ.get("NWS_SWITCH"):      # diagnosis: the interpreter's thread switch interval (submitting thread vs exchange helper thread)
+        sys.setswitchinterval(float(os.environ["NWS_SWITCH"]))
     if a.pmc_child:
         pmc_child(a)
         return
@@ -404,6 +406,13 @@ def main():
     # NWS_BENCH_FORCE_DIST=1: run the N>1 code path (RCCL init, shared draws, all-gather) with world_size 1 -- the only way
     # to exercise it on real RCCL on a 1-GPU box.  Never set by the driver.
     force_dist = os.environ.get("NWS_BENCH_FORCE_DIST") == "1"
+    # NWS_BENCH_FAKE_PEERS=7 (rehearsal of the 8-rank queue population on ONE GPU, VERDICT r5 #1b; never set by the driver): forced
+    # world size 1 with `--gather copy`, every step's 16.4 MB shard pushed to that many LOCAL buffers on per-peer copy streams of
+    # their own - the stream count and issue pattern of --gpus 8, blit kernels standing in for the copy engines
+    fake_peers = int(os.environ.get("NWS_BENCH_FAKE_PEERS", "0"))
+    if fake_peers:
+        force_dist = True
+        a.gather = "copy"
     # NWS_BENCH_SHARE_GPU=1 (smoke-testing the N>1 code path on a 1-GPU box with TWO processes): every rank uses cuda:0 and
     # the collectives go through gloo (RCCL refuses two ranks on one device).  Never set by the driver.
     share_gpu = os.environ.get("NWS_BENCH_SHARE_GPU") == "1"
@@ -477,7 +486,13 @@ def main():
     share_collective = share_gpu and os.environ.get("NWS_BENCH_SHARE_GPU_COLLECTIVE") == "1" and a.gather == "rccl"
     if distributed and (a.gather == "copy" or (share_gpu and not share_collective)):
         # copy-engine all-gather: peer-mapped gather buffers, one device-to-device copy per peer
-        peer = par.PeerCopyAllGather(B, N, dev, nbuf=nbuf, sync_signal=use_pipe)
+        n_dest = world + (fake_peers if world == 1 else 0)
+        # the per-destination copy streams: hardware queues that do not share a pipe with an audio stream (pipeline.side_streams;
+        # NWS_BENCH_COPY_STREAMS=plain: fresh streams wherever they land, for the A/B)
+        placed_copy = use_pipe and n_dest > 1 and not share_gpu and os.environ.get("NWS_BENCH_COPY_STREAMS", "placed") == "placed"
+        peer = par.PeerCopyAllGather(B, N, dev, nbuf=nbuf, sync_signal=use_pipe, fake_peers=fake_peers if world == 1 else 0,
+                                     copy_streams=pmod.side_streams(dev, n_dest) if placed_copy else None,
+                                     fake_rows=int(os.environ.get("NWS_BENCH_FAKE_ROWS", "0")))
         full = peer.full
         gather_kind = "copy"
     elif distributed:
@@ -504,6 +519,7 @@ def main():
             peer.release(i % nbuf)
         else:
             par.gather_full(full[i % nbuf], y, async_op=False)        # sync op = launched on the current (exchange) stream
+        return y          # kept alive by the exchange's ticket until the slot is acquired again (CompletionDrivenExchange docstring)
 
     def issue_block(i, y, row0, n, last):
         """worker thread: rows [row0, row0 + n) of this step's waveforms to every rank"""
@@ -523,6 +539,7 @@ def main():
         for q, (row0, n) in enumerate(blocks):
             evs[q].synchronize()
             issue_block(i, y, row0, n, row0 + n == B)
+        return y          # rendered out of place from the audio stream's pool: the ticket keeps it alive until the exchange is over
 
     def post_behind(stream, slot_i, issue):
         """the exchange `issue` leaves once everything enqueued on `stream` so far is complete"""
@@ -634,7 +651,7 @@ def main():
         if pending is not None:
             pending.wait()
         if xchg is not None:
-            xchg.drain()                    # every exchange issued and complete
+            xchg.drain(peer.flush if peer is not None else None)                    # every exchange issued and complete
         join_streams()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0      # this rank's K steps, from the common start to its own last exchange
@@ -664,13 +681,17 @@ def main():
         if pending is not None:
             pending.wait()
         if xchg is not None:
-            xchg.drain()
+            xchg.drain(peer.flush if peer is not None else None)
         join_streams()
         torch.cuda.synchronize()
         # live HIP-event timing of the dominant kernel (and the GRU) on their launch streams, inside the timed region
         _lib.check(_lib.lib().nws_profile_begin(a.steps, (1 << 3) | (1 << 1)))
+        if peer is not None and peer.prof is not None:
+            peer.prof.clear()
         elapsed, per_rank = timed(a.steps)
         extra["host_issue_ms_per_step"] = round(host_issue["s_per_step"] * 1e3, 4)
+        if peer is not None and peer.prof:
+            extra["peer_gather_us"] = {k: round(v / max(1.0, peer.prof.get("n", 1.0)) * 1e6, 1) for k, v in peer.prof.items() if k != "n"}
         if xchg is not None and xchg.profile:
             pr = np.array(xchg.profile[-a.steps:]) * 1e6
             extra["exchange_worker_us"] = {"wait_p50": float(np.median(pr[:, 0])), "issue_p50": float(np.median(pr[:, 1])),
@@ -696,7 +717,7 @@ def main():
                 for j in range(8):
                     step(j, None, **kw)
                 if xchg is not None:
-                    xchg.drain()
+                    xchg.drain(peer.flush if peer is not None else None)
                 join_streams()
                 return timed(k2, **kw)
 
@@ -713,6 +734,7 @@ def main():
                                  "steps": k2, "bytes_gathered_per_rank_per_step": B * world * N * 4,
                                  "gather_ms_per_rank": [round(t / k2 * 1e3, 4) for t in g_ranks],
                                  "compute_only_ms_per_rank": [round(t / k2 * 1e3, 4) for t in c_ranks],
+                                 "fake_peers": (peer.fake_peers if peer is not None else 0),
                                  "rccl_world_size": dist.get_world_size(), "backend": dist.get_backend(),
                                  "device_of_rank": f"cuda:{local_rank}"}
             devs = [None] * world       # which device every rank of the job really ran on (one process per GPU)
@@ -755,7 +777,7 @@ def main():
                     ys.append(y.clone())
                 post_behind(au, slot_i, lambda _i=i, _y=y: issue_whole(_i, _y))
             if xchg is not None:
-                xchg.drain()
+                xchg.drain(peer.flush if peer is not None else None)
             pipe.synchronize()
             torch.cuda.synchronize()
             wrong = 0
@@ -1048,6 +1070,10 @@ def main():
                                    f"RNG draws on device{', all-gather of waveforms (' + str(gather_kind) + ')' if distributed else ''}",
                        "batch_per_gpu": B, "frames": T, "samples_per_utterance": N, "parallelism": f"batch-shard x{world}",
                        "exciter_opts": opts, "streams": len(streams),
+                       # where the pipeline's hardware queues sit on the command processor's pipes, as MEASURED before the first step
+                       # (pipeline.placed_streams): queue_offset = hardware queues this process had created before, mod 4
+                       "queue_offset": (pmod.placement_report(dev) or {}).get("queue_offset") if use_pipe else None,
+                       "placement": pmod.placement_report(dev) if use_pipe else None,
                        "issue": (f"ForwardPipeline: control half (carries + {a.gru} GRU) on {len(pipe.control)} side stream(s), "
                                  f"audio half on {len(streams)} streams, {len(pipe.slots)} workspaces in flight") if use_pipe
                        else f"whole forwards round-robin on {len(streams)} streams"},

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NWS_ABI_VERSION 5
+#define NWS_ABI_VERSION 6
 
 #define NWS_N_HARMONICS 101
 #define NWS_N_SHAPERS 64
@@ -509,6 +509,29 @@ int nws_forward_generic(const NwsGenericModel* m, const float* f0, const float* 
 int nws_profile_begin(int slots, unsigned stage_mask);
 int nws_profile_collect(float* ms_out /* host, slots*6 */, int* n_out /* host */);
 int nws_profile_end(void);
+
+/* Waveform exchange of the multi-GPU path, host side (ABI v6; SURVEY 8(e) - the reference has no collective code:
+ * gin/train/train_newt.gin:13 is its only trace of more than one GPU).  nws_peer_push: for i < n, one asynchronous device-to-device
+ * copy of `bytes` from src to dst[i] (a peer-mapped or local device pointer) on streams[i], then hipEventRecord(events[i],
+ * streams[i]) when events and events[i] are non-NULL - one call per step instead of n copies + n records through the host
+ * language.  nws_events_wait: hipEventSynchronize on every non-NULL event (HOST-side wait; the calling thread blocks). */
+int nws_peer_push(int n, void* const* dst, const void* src, size_t bytes, void* const* streams, void* const* events);
+int nws_events_wait(int n, void* const* events);
+/* hipStreamSynchronize on every stream (HOST-side wait): the pushes of the previous step are awaited this way - no event record
+ * per copy on the copy queues (every record is one more packet for the command processor beside the pipeline's own). */
+int nws_streams_wait(int n, void* const* streams);
+
+/* Which pipe of the command processor serves a stream's hardware queue (ABI v6; no reference counterpart: the reference enqueues
+ * everything on one stream, models/neural_waveshaping.py:74-90 - this serves the throughput mode of that forward,
+ * ForwardPipeline, whose five streams must sit on the pipes in a fixed pattern: DESIGN.md 5.2).
+ * Launches a grid of `groups` one-wave workgroups on `stream_hold` that each hold 64 000 B of LDS (two per CU: the grid is handed
+ * out in rounds of 512) and spin for `spin_us` microseconds, and right behind it ONE wave on `stream_touch` that stores the
+ * wall clock; synchronises both streams (a measurement, not a hot-path call) and returns in *frac_out
+ *     (touch time - first workgroup start) / (last workgroup start - first workgroup start):
+ * ~0 when the second queue was served while the first was dispatching (different pipes), >= ~1 when it had to wait for the
+ * whole grid to be handed out (same pipe, or one hardware queue shared by both streams); -1 when the grid was too small to
+ * be held (groups <= 512).  `scratch`: device memory, 32 bytes. */
+int nws_queue_probe(void* stream_hold, void* stream_touch, int groups, int spin_us, unsigned long long* scratch, float* frac_out /* host */);
 
 #ifdef __cplusplus
 }

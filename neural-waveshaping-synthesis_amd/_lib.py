@@ -11,7 +11,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnws_hip.so")
 
-ABI_VERSION = 5          # include/nws_hip.h NWS_ABI_VERSION
+PROBE_LIB_PATH = os.path.join(_HERE, "libnws_probe.so")     # include/nws_probe.h: the co-execution hazard probe (tools / tests only)
+
+ABI_VERSION = 6          # include/nws_hip.h NWS_ABI_VERSION
 EXCITER_VALU_FILM = 1    # NwsWeights.exciter_opts bits (include/nws_hip.h)
 EXCITER_ONE_TERM = 2
 EXCITER_HYBRID = 4
@@ -90,10 +92,11 @@ _PROTOTYPES = {
     "nws_sizeof": (C.c_size_t, [C.c_int]),
     "nws_error_string": (C.c_char_p, [C.c_int]),
     "nws_selftest_mfma": (C.c_int, [_fp, _fp]),
-    "nws_coexec_pk_probe": (C.c_int, [C.c_int, C.c_int, _fp, _fp]),
-    "nws_coexec_pk_probe2": (C.c_int, [C.c_int, C.c_int, _fp, _fp]),
-    "nws_coexec_pk_probe_mixed": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),
-    "nws_coexec_mfma_load": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "nws_peer_push": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), _fp, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "nws_events_wait": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "nws_streams_wait": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "nws_queue_probe": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp, C.POINTER(C.c_float)]),
+    "nws_debug_queue_busy": (C.c_int, [C.c_int, C.c_int, _fp, _fp]),
     "nws_sin": (C.c_int, [_fp, _fp, C.c_int64, _fp]),
     "nws_phase_carry": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp, _fp]),
     "nws_exciter_newt": (C.c_int, [C.POINTER(NwsWeights), _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_float,
@@ -190,11 +193,20 @@ _PROTOTYPES = {
     "nws_profile_end": (C.c_int, []),
 }
 
+_PROBE_PROTOTYPES = {
+    "nws_coexec_pk_probe": (C.c_int, [C.c_int, C.c_int, _fp, _fp]),
+    "nws_coexec_pk_probe2": (C.c_int, [C.c_int, C.c_int, _fp, _fp]),
+    "nws_coexec_pk_probe_mixed": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),
+    "nws_coexec_mfma_load": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, _fp]),
+}
+
 STAGE_NAMES = ("phase_carry", "control_gru", "frame_mlps", "exciter_newt", "fir_noise", "reverb")
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
+PROBE_SYMBOLS = tuple(_PROBE_PROTOTYPES)
 
 _lib = None
+_probe = None
 
 
 class NwsError(RuntimeError):
@@ -224,6 +236,21 @@ def lib():
                                f"binding {C.sizeof(struct)} B")
         _lib = handle
     return _lib
+
+
+def probe_lib():
+    """libnws_probe.so (include/nws_probe.h): the hazard probe kernels, for tools/ and tests/ - never needed by the product path."""
+    global _probe
+    if _probe is None:
+        if not os.path.exists(PROBE_LIB_PATH):
+            raise NwsError(f"{PROBE_LIB_PATH} not found: python neural-waveshaping-synthesis_amd/build.py builds it next to libnws_hip.so")
+        handle = C.CDLL(PROBE_LIB_PATH)
+        for name, (res, args) in _PROBE_PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _probe = handle
+    return _probe
 
 
 def check(rc: int, what: str = ""):

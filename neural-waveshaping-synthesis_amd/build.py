@@ -1,4 +1,6 @@
 """Build libnws_hip.so (gfx950) in-tree with hipcc.  No torch headers: the library is a plain C-ABI.
+Also libnws_probe.so: the MI355X co-execution hazard probe (csrc/coexec_probe.hip) - tools and tests only, kept OUT of the
+product library because its kernels contain, on purpose, the instruction form the build guard refuses everywhere else.
 
     python neural-waveshaping-synthesis_amd/build.py [--force]
 """
@@ -13,8 +15,10 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libnws_hip.so")
 OPS_LIB = os.path.join(HERE, "libnws_torch_ops.so")     # torch.ops.newt_hip.* over the C-ABI (csrc/torch_ops.cpp)
+PROBE_LIB = os.path.join(HERE, "libnws_probe.so")       # include/nws_probe.h: hazard probe, tools / tests only
 SOURCES = ["exciter_newt.hip", "control_gru.hip", "frame_mlps.hip", "fir_noise.hip", "reverb_fft.hip", "forward.hip",
-           "loudness.hip", "stages.hip", "generic.hip", "stream.hip", "coexec_probe.hip"]
+           "loudness.hip", "stages.hip", "generic.hip", "stream.hip", "queue_probe.hip", "exchange.hip"]
+PROBE_SOURCES = ["coexec_probe.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=default",
          "-Wall", "-Wno-unused-function", "-Wno-pass-failed", "-Rpass-analysis=kernel-resource-usage"]
 # -fno-slp-vectorize: the SLP vectoriser turns scalar fp32 code into packed instructions with operand swizzles of its own
@@ -24,11 +28,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 # receives the harmless low-broadcast form) and control_gru.hip (batched kernel; the per-utterance kernel's horizontal
 # sums are scalar by hand).
 KEEP_SLP = ("fir_noise.hip", "control_gru.hip")
-EXTRA_FLAGS = {src: ["-fno-slp-vectorize"] for src in SOURCES if src not in KEEP_SLP}
+EXTRA_FLAGS = {src: ["-fno-slp-vectorize"] for src in SOURCES + PROBE_SOURCES if src not in KEEP_SLP}
 # experiments: extra hipcc flags for every file (e.g. NWS_EXTRA_HIPCC_FLAGS="-DNWS_EXCITER_PRIO_MIX=1"); part of the build stamp
 FLAGS += [f for f in os.environ.get("NWS_EXTRA_HIPCC_FLAGS", "").split() if f]
 LLVM_BIN = "/opt/rocm/lib/llvm/bin"
-# kernels that contain the hazardous form on purpose (the probe that demonstrates it)
+# kernels that contain the hazardous form on purpose (the probe that demonstrates it): allowed in PROBE_SOURCES only - an object
+# of the product library is checked with an empty allow-list
 SWIZZLE_ALLOW = ("pk_probe_kernel", "pk_probe2_kernel", "pk_probe_mixed_kernel")
 
 
@@ -46,8 +51,8 @@ def _stamp():
         if os.path.isfile(p) and f != "torch_ops.cpp":
             h.update(f.encode())
             h.update(open(p, "rb").read())
-    h.update(open(os.path.join(HERE, "..", "include", "nws_hip.h"), "rb").read())
-    h.update(open(os.path.join(HERE, "..", "include", "nws_hip_debug.h"), "rb").read())
+    for hdr in ("nws_hip.h", "nws_hip_debug.h", "nws_probe.h"):
+        h.update(open(os.path.join(HERE, "..", "include", hdr), "rb").read())
     return h.hexdigest()
 
 
@@ -68,15 +73,17 @@ def device_disassembly(obj):
                               text=True).stdout
 
 
-def check_packed_swizzles(obj):
+def check_packed_swizzles(obj, allow=None):
     """MI355X co-execution hazard guard (LABBOOK.md '5.2', csrc/coexec_probe.hip).
 
     v_pk_{add,mul,fma}_f32 with op_sel[1] = 1 (low lane <- high half of src1) returns wrong values while another kernel
     runs K=16/32 f16 MFMAs on the same CU.  The check is wider than what was seen to fail: ANY vector instruction with
     op_sel[1] = 1 is refused (packed fp16, v_fma_mix* and scalar-register operands probed clean; no product kernel needs
     those forms either, so the guard stays simple).
-    Returns [(kernel, instruction), ...] for every occurrence outside the probe."""
+    `allow`: kernel-name substrings that may contain the form (default SWIZZLE_ALLOW; the product objects pass ()).
+    Returns [(kernel, instruction), ...] for every other occurrence."""
     import re
+    allow = SWIZZLE_ALLOW if allow is None else allow
     found, kernel = [], None
     for line in device_disassembly(obj).splitlines():
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
@@ -84,7 +91,7 @@ def check_packed_swizzles(obj):
             kernel = m.group(1)
             continue
         m = re.search(r"\b(v_\w+)\b.*?op_sel:\[\d,(\d)", line)
-        if m and m.group(2) == "1" and not any(a in (kernel or "") for a in SWIZZLE_ALLOW):
+        if m and m.group(2) == "1" and not any(a in (kernel or "") for a in allow):
             found.append((kernel, " ".join(line.split("//")[0].split())))
     return found
 
@@ -220,7 +227,8 @@ def build(force=False, verbose=True):
 def build_hip(force=False, verbose=True):
     stamp_file = LIB + ".stamp"
     stamp = _stamp()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+    if (not force and os.path.exists(LIB) and os.path.exists(PROBE_LIB) and os.path.exists(stamp_file)
+            and open(stamp_file).read() == stamp):
         return LIB
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
@@ -253,7 +261,7 @@ def build_hip(force=False, verbose=True):
         if over:
             lines = "\n".join(f"  {k}: {n} registers > {b} ({why})" for k, n, b, why in over)
             raise RuntimeError(f"{src}: kernels over their register budget (REGISTER_BUDGETS: workgroups per CU):\n{lines}")
-        swz = check_packed_swizzles(obj)
+        swz = check_packed_swizzles(obj, SWIZZLE_ALLOW if src in PROBE_SOURCES else ())
         if swz:
             lines = "\n".join(f"  {k}: {i}" for k, i in swz[:12])
             raise RuntimeError(f"{src}: packed fp32 instructions with a swizzled src1 low lane (co-execution hazard, see "
@@ -267,11 +275,12 @@ def build_hip(force=False, verbose=True):
             print("\n".join(rest), file=sys.stderr)
         return obj
 
-    with cf.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB], capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"link failed:\n{r.stderr}")
+    with cf.ThreadPoolExecutor(max_workers=len(SOURCES) + len(PROBE_SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES + PROBE_SOURCES))
+    for lib, these in ((LIB, objs[:len(SOURCES)]), (PROBE_LIB, objs[len(SOURCES):])):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *these, "-o", lib], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
     with open(stamp_file, "w") as f:
         f.write(stamp)
     if verbose:

@@ -15,6 +15,7 @@
 //   nws_coexec_mfma_load   a bare MFMA loop of the chosen flavour to run beside it on another stream.
 // tools/coexec_probe.py prints the matrix; tests/test_gpu_coexec.py keeps the probe honest and checks the product path.
 #include "nws_common.h"
+#include "../../include/nws_probe.h"
 
 namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

@@ -651,6 +651,11 @@ class Engine:
         next block's reverb runs.  Same bits as the single call."""
         w, _, dev, wdesc = self._wd()
         same_device(dev, f0=f0, phase_u=phase_u, noise=noise, workspace=ws, out=out)
+        if block_events is not None and (row_blocks is None or len(row_blocks) < 2 or on_block is not None):
+            # never silently ignored: synchronize() on a never-recorded event returns at once, and whoever waits on these events
+            # (a helper thread that pushes sub-batches to peers) would read rows the reverb has not written yet
+            raise RuntimeError("block_events are recorded by the one-call block path only: pass row_blocks of two or more blocks and "
+                               "no on_block callback")
         N = T * _lib.HOP
         plan, tables, spec, plan_t = self._reverb_aux(N)
         sr = self.osc_sample_rate()

@@ -11,6 +11,7 @@ CPU tests can drive this file with the oracle instead of the HIP engine.
 """
 from __future__ import annotations
 
+import os
 import queue
 import threading
 
@@ -60,7 +61,6 @@ def render_sharded(render_fn, f0, control, group=None, phase_u=None, noise=None,
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     B, _, T = f0.shape
-    hop_n = None
     lo, hi = shard_bounds(B, world, rank)
     if phase_u is None or noise is None:
         raise ValueError("render_sharded needs the shared draws (see shared_draws())")
@@ -79,7 +79,6 @@ def render_sharded(render_fn, f0, control, group=None, phase_u=None, noise=None,
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
     full = torch.cat([parts[r][: shard_bounds(B, world, r)[1] - shard_bounds(B, world, r)[0]] for r in range(world)], 0)
-    del hop_n
     return (full, None) if async_op else full
 
 
@@ -159,6 +158,18 @@ class CompletionDrivenExchange:
       * `drain()` at the end of a region.
     The submitting thread can run at most `nslots` batches ahead of the GPU (it has to: a gather buffer is only free once its
     exchange is out), which bounds the run-ahead exactly like the ring of workspaces of ForwardPipeline does.
+
+    Lifetime of what is sent: `issue()` RETURNS the tensors its exchange reads (the rendered rows); the ticket holds them until
+    `acquire()` of the same slot has made the rendering stream wait for the exchange's completion, or `drain()`.  Nothing else
+    keeps them alive - synchronous collectives of torch >= 2.8 and PeerCopyAllGather's host-ordered pushes run on the exchange /
+    copy streams without record_stream - so a tensor allocated from another stream's pool (a batch rendered out of place) would
+    otherwise be handed to a later batch by the caching allocator while its exchange is still in flight.
+
+    Failure: the FIRST exception of an `issue()` (or of waiting for its batch) poisons the worker.  Every later ticket completes
+    with that exception WITHOUT calling its `issue()` - this rank must not skip one collective and then issue the following
+    ones, which its peers would pair with their previous ones (same shapes: no error, silently wrong gather buffers) - `post()`
+    raises at once on the submitting thread, and so do `acquire()` / `drain()`.  The process is expected to exit on that error
+    (under torch.distributed.run the peers are then torn down instead of waiting in their next collective).
     Works without a GPU too (`device` cpu: no events, `issue` runs as soon as the worker gets to it) - the gloo tests."""
 
     def __init__(self, device, nslots: int, stream=None):
@@ -168,6 +179,7 @@ class CompletionDrivenExchange:
         self.cuda = self.device.type == "cuda"
         self.stream = (stream if stream is not None else torch.cuda.Stream(device=self.device)) if self.cuda else None
         self._tickets = [None] * int(nslots)
+        self._failed = None                 # the first exception of the worker: nothing is issued after it (class docstring)
         self.profile = None                 # a list: the worker appends (wait, issue, record) seconds per exchange (diagnosis)
         self._all = []
         self._prune_at = 64
@@ -186,6 +198,10 @@ class CompletionDrivenExchange:
             if item is None:
                 return
             t, ready, issue = item
+            if self._failed is not None:                # poisoned: complete the ticket with the first failure, issue nothing
+                t.exc = self._failed
+                t.issued.set()
+                continue
             try:
                 t0 = time.perf_counter()
                 if ready is not None:
@@ -197,13 +213,17 @@ class CompletionDrivenExchange:
                     t.done = self.stream.record_event()
                 if self.profile is not None:
                     self.profile.append((t1 - t0, t2 - t1, time.perf_counter() - t2))
-            except BaseException as e:                  # handed to the submitting thread by acquire() / drain()
+            except BaseException as e:                  # handed to the submitting thread by post() / acquire() / drain()
                 t.exc = e
+                self._failed = e
             t.issued.set()
 
     def post(self, slot: int, ready, issue):
         """`ready`: torch.cuda.Event recorded behind the kernels that write the rows (None: nothing to wait for);
-        `issue()`: enqueues the exchange on the current stream (called on the worker thread)."""
+        `issue()`: enqueues the exchange on the current stream (called on the worker thread) and returns what it reads (kept
+        alive by the ticket).  Raises at once when an earlier exchange has failed."""
+        if self._failed is not None:
+            raise RuntimeError("exchange worker failed earlier: no further exchange is issued") from self._failed
         t = _Ticket()
         self._tickets[slot] = t
         self._all.append(t)
@@ -230,16 +250,26 @@ class CompletionDrivenExchange:
         self._check(t)
         if self.cuda and t.done is not None:
             (stream or torch.cuda.current_stream(self.device)).wait_event(t.done)
+        t.keep = None                        # whatever renders into the slot next is ordered behind the exchange now
         self._tickets[slot] = None
 
-    def drain(self):
-        """Every posted exchange issued AND complete (host-side)."""
+    def drain(self, finalize=None):
+        """Every posted exchange issued AND complete (host-side).  `finalize()`: run on the worker thread behind everything posted so
+        far, before the wait (PeerCopyAllGather.flush of the host-ordered peer-copy form: the last exchange's completion signal)."""
+        if finalize is not None:
+            if self._failed is not None:
+                raise RuntimeError("exchange worker failed earlier: no further exchange is issued") from self._failed
+            t = _Ticket()
+            self._all.append(t)
+            self._q.put((t, None, finalize))
         for t in self._all:
             self._check(t)
-        self._all = []
-        self._prune_at = 64
         if self.cuda:
             self.stream.synchronize()
+        for t in self._all:
+            t.keep = None
+        self._all = []
+        self._prune_at = 64
 
     def close(self):
         self._q.put(None)
@@ -268,16 +298,29 @@ class PeerCopyAllGather:
     """
 
     def __init__(self, rows: int, n_samples: int, device, nbuf: int = 2, group=None, dtype=torch.float32,
-                 sync_signal: bool = False):
-        """sync_signal (= host-ordered mode, for callers that issue every exchange from a helper thread on one stream of their
+                 sync_signal: bool = False, fake_peers: int = 0, copy_streams=None, fake_rows: int = 0):
+        """fake_peers (rehearsals on fewer GPUs than the job will have, `NWS_BENCH_FAKE_PEERS` of bench.py): that many extra
+        destinations per push, each a LOCAL buffer on a copy stream of its own - the stream count and issue pattern of a world of
+        `world + fake_peers` ranks, with this device's blit kernels standing in for the copy engines and links of real peers.
+        copy_streams: one stream per destination (world + fake_peers) instead of fresh ones (a caller that places them).
+        sync_signal (= host-ordered mode, for callers that issue every exchange from a helper thread on one stream of their
         own: CompletionDrivenExchange): nothing in an exchange is ordered by a device-side wait on another queue - such a wait,
         parked on a hardware queue, slows the dispatch of the queues next to it (LABBOOK round 5: +24-30 % on the pipelined step).
         The pushes go straight onto the per-peer copy streams (the rows are final: the caller has seen their batch complete), the
         issuing thread then waits ON THE HOST for its copies and for its own release events, and the completion signal is a
         synchronous collective = launched on the CURRENT stream (torch.distributed launches `async_op=False` collectives there:
-        no hop to its NCCL stream and back, no work handle); the next exchange starts with a host-side wait for that signal."""
+        no hop to its NCCL stream and back, no work handle).
+        The exchanges of successive steps are PIPELINED (round 6): `gather(y, slot)` first completes step i - 1 - a host-side wait
+        on the copy streams (its pushes are a step old by now: satisfied waits, and no event record per copy), then its completion
+        signal - and then pushes step i's rows (ONE nws_peer_push call: n copies without the interpreter lock) and returns: the
+        copy engines work on step i while the pipeline renders step i + 1, and the helper thread never sits out a transfer.  (Round 5's form waited for every step's copies before it
+        signalled and before the next step's copies could start: with seven destinations the helper thread needed 0.44-0.54 ms
+        per 0.40 ms step and became the bottleneck, profiles/r06/fake_peers_ab.txt.)  Consequences for a consumer: full[slot] is
+        complete on every rank once `complete(slot)` (or `flush()`) has returned and the issuing stream has been waited for; a
+        slot must be released within nbuf - 2 steps."""
         self.sync_signal = bool(sync_signal)
-        self._pending_copies = []            # host-ordered mode: events behind this exchange's pushes
+        self._pending_copies = []            # host-ordered mode: events behind the pushes of the exchange being assembled
+        self._deferred = []                  # host-ordered mode: (slot, copy events) of exchanges pushed but not yet signalled
         self._signalled = False              # host-ordered mode: a completion signal is in flight on the issuing stream
         if not dist.is_initialized():
             raise RuntimeError("PeerCopyAllGather needs an initialised process group (handle exchange)")
@@ -308,10 +351,21 @@ class PeerCopyAllGather:
                     raise RuntimeError(f"rank {p} exported a gather buffer of {tuple(t.shape)} {t.dtype}")
                 opened.append(t)
             self.remote.append(opened)
+        self.fake_peers = int(fake_peers)
+        self.fake_rows = int(fake_rows)      # diagnosis: pushes carry this many rows only (the issue pattern without the data volume)
+        for _ in range(self.fake_peers):     # destinations that stand in for peers this job does not have
+            self.remote.append([torch.empty((self.world * self.rows, self.n), dtype=dtype, device=self.device) for _ in range(nbuf)])
+        self.npush = self.world + self.fake_peers
         self._flag = torch.zeros(1, dtype=torch.float32, device=self.device)
         # one copy stream per peer: the pushes of a step run side by side, each on its own point-to-point link
-        self._copy_streams = ([torch.cuda.Stream(device=self.device) for _ in range(self.world)]
-                              if self.device.type == "cuda" and self.world > 1 else None)
+        if copy_streams is not None and len(copy_streams) != self.npush:
+            raise ValueError(f"copy_streams: one per destination ({self.npush}), got {len(copy_streams)}")
+        self._copy_streams = (list(copy_streams) if copy_streams is not None else
+                              [torch.cuda.Stream(device=self.device) for _ in range(self.npush)]
+                              if self.device.type == "cuda" and self.npush > 1 else None)
+        self.prof = {} if os.environ.get("NWS_PEER_PROF") == "1" else None      # diagnosis: seconds per section of gather()
+        self._use_events = os.environ.get("NWS_PEER_EVENTS") == "1"      # A/B: an event per copy instead of a wait on the copy streams
+        self._events = {}                    # host-ordered mode: (slot, destination, first row) -> reusable torch.cuda.Event
         self._held = [False] * nbuf          # handed to the consumer, not yet released
         self._released = [None] * nbuf       # event of the consumer's last use of the slot
         self._last_work = None               # completion signal of the previous gather
@@ -325,8 +379,19 @@ class PeerCopyAllGather:
             self._last_work.wait()
             self._last_work = None
         if self.sync_signal and self._signalled and self.device.type == "cuda":
-            torch.cuda.current_stream(self.device).synchronize()      # (host side: the previous completion signal has landed)
+            # host side: the latest completion signal - of the exchange before last, enqueued a step ago - has landed (a stream
+            # synchronise, not one more event record per step on the exchange queue: x1.08 instead of x1.01 at world size 1)
+            if self.prof is not None:
+                import time
+                t0 = time.perf_counter()
+            torch.cuda.current_stream(self.device).synchronize()
+            if self.prof is not None:
+                self.prof["wait_signal"] = self.prof.get("wait_signal", 0.0) + time.perf_counter() - t0
             self._signalled = False
+        if self.sync_signal and not self._use_events:
+            # the previous exchange's pushes have had a step to land: wait for them on the copy streams themselves (no event record
+            # per copy: every record is one more packet for the command processor), signal, and only then start this step's pushes
+            self._complete_deferred(keep=0)
 
     def release(self, slot: int):
         """The consumer is done with full[slot]: everything it enqueued on the current stream so far may still read it, anything
@@ -338,29 +403,76 @@ class PeerCopyAllGather:
         self._held[slot] = False
 
     def _signal(self, slot: int):
+        if self.sync_signal:                         # host-ordered: this exchange's signal goes out in front of the NEXT one's pushes
+            self._held[slot] = True
+            self._deferred.append((slot, self._pending_copies))
+            self._pending_copies = []
+            if self._use_events:
+                self._complete_deferred(keep=1)
+            return self.full[slot], None
         st = torch.cuda.current_stream(self.device)
         for s, ev in enumerate(self._released):      # this rank's reads of released slots precede its completion signal
             if ev is not None:
-                if self.sync_signal:
-                    ev.synchronize()
-                else:
-                    st.wait_event(ev)
+                st.wait_event(ev)
                 self._released[s] = None
-        for ev in self._pending_copies:              # host-ordered mode: this rank's pushes are complete before it signals
-            ev.synchronize()
-        self._pending_copies = []
         self._held[slot] = True
         if self.backend == "gloo":              # CPU-side test backend: no stream-ordered collectives
             st.synchronize()
             dist.barrier(group=self.group)
             return self.full[slot], None
-        if self.sync_signal:                    # on the current stream itself; the next exchange waits for it on the host (_claim)
-            dist.all_reduce(self._flag, group=self.group, async_op=False)
-            self._signalled = True
-            return self.full[slot], None
         work = dist.all_reduce(self._flag, group=self.group, async_op=True)   # ordered after the copies on this stream
         self._last_work = work
         return self.full[slot], work
+
+    def _complete_deferred(self, keep: int):
+        """host-ordered mode: the completion signals of all but the `keep` newest pushed exchanges, oldest first.  Per exchange:
+        this rank's copies have landed (host-side wait), its released slots are no longer being read (host-side wait), then the
+        4-byte synchronous all-reduce on the current (exchange) stream."""
+        import time
+        while len(self._deferred) > keep:
+            slot, evs = self._deferred.pop(0)
+            t0 = time.perf_counter()
+            if evs:
+                import ctypes as C
+                from . import _lib
+                if self._use_events:
+                    handles = (C.c_void_p * len(evs))(*[int(ev.cuda_event) for ev in evs])
+                    _lib.check(_lib.lib().nws_events_wait(len(evs), handles), "nws_events_wait")
+                else:                               # `evs` holds the copy streams' handles: the pushes are the last thing on them
+                    handles = (C.c_void_p * len(evs))(*sorted(set(evs)))
+                    _lib.check(_lib.lib().nws_streams_wait(len(handles), handles), "nws_streams_wait")
+            t1 = time.perf_counter()
+            for s, ev in enumerate(self._released):
+                if ev is not None:
+                    ev.synchronize()
+                    self._released[s] = None
+            t2 = time.perf_counter()
+            if self.prof is not None:
+                self.prof["wait_copies"] = self.prof.get("wait_copies", 0.0) + t1 - t0
+                self.prof["wait_released"] = self.prof.get("wait_released", 0.0) + t2 - t1
+            if self.backend == "gloo":              # CPU-side test backend: a host barrier is the signal
+                dist.barrier(group=self.group)
+                continue
+            dist.all_reduce(self._flag, group=self.group, async_op=False)
+            if self.prof is not None:
+                self.prof["all_reduce_call"] = self.prof.get("all_reduce_call", 0.0) + time.perf_counter() - t2
+            self._signalled = True
+
+    def complete(self, slot: int):
+        """host-ordered mode: make sure the completion signal of the exchange into `slot` has been issued (everything up to and
+        including it); the consumer then orders its reads behind the issuing stream."""
+        for k, (s, _) in enumerate(self._deferred):
+            if s == slot:
+                self._complete_deferred(keep=len(self._deferred) - k - 1)
+                return
+
+    def flush(self):
+        """host-ordered mode: every pushed exchange signalled, and the last signal landed (host side).  Call it on the thread that
+        issues the exchanges, at the end of a region - every rank, like the exchanges themselves."""
+        self._complete_deferred(keep=0)
+        if self._signalled and self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+            self._signalled = False
 
     def local_rows(self, slot: int) -> torch.Tensor:
         """This rank's own rows of full[slot]: render into them (forward(..., out=...)) and `gather` has nothing to copy locally.
@@ -377,20 +489,36 @@ class PeerCopyAllGather:
         n = src.shape[0]
         cur = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
         if self.sync_signal and self._copy_streams is not None:
-            # host-ordered: no fork, no join - the copies start at once on their own streams, _signal waits for them on the host
-            for k in range(self.world):
-                p = (self.rank + k) % self.world
+            # host-ordered: no fork, no join - the copies start at once on their own streams (ONE call through the binding:
+            # nws_peer_push), _complete_deferred waits for them on the host a step later
+            import ctypes as C
+            from . import _lib
+            dsts, sts, evs = [], [], []
+            for k in range(self.npush):
+                p = (self.rank + k) % self.npush
                 dst = self.remote[p][slot][lo:lo + n]
                 if p == self.rank and dst.data_ptr() == src.data_ptr():
                     continue
-                with torch.cuda.stream(self._copy_streams[p]):
-                    dst.copy_(src, non_blocking=True)
-                    self._pending_copies.append(self._copy_streams[p].record_event())
+                dsts.append(dst.data_ptr())
+                sts.append(self._copy_streams[p].cuda_stream)
+                if self._use_events:
+                    evs.append(self._copy_event(slot, p, lo))
+            if dsts:
+                if not src.is_contiguous():
+                    raise ValueError("PeerCopyAllGather: the rows to push must be contiguous")
+                m = len(dsts)
+                nbytes = (min(self.fake_rows, n) if self.fake_rows else n) * src.shape[1] * src.element_size()
+                with torch.cuda.device(self.device):
+                    _lib.check(_lib.lib().nws_peer_push(m, (C.c_void_p * m)(*dsts), src.data_ptr(), nbytes,
+                                                        (C.c_void_p * m)(*sts),
+                                                        (C.c_void_p * m)(*[int(e.cuda_event) for e in evs]) if evs else None),
+                               "nws_peer_push")
+                self._pending_copies += evs if self._use_events else sts
             return
         fork = cur.record_event() if self._copy_streams is not None else None
         joins = []
-        for k in range(self.world):             # start with the right-hand neighbour: the ranks' pushes spread over the links
-            p = (self.rank + k) % self.world
+        for k in range(self.npush):             # start with the right-hand neighbour: the ranks' pushes spread over the links
+            p = (self.rank + k) % self.npush
             dst = self.remote[p][slot][lo:lo + n]
             if p == self.rank and dst.data_ptr() == src.data_ptr():
                 continue                        # rendered in place
@@ -404,6 +532,18 @@ class PeerCopyAllGather:
                 joins.append(st.record_event())
         for ev in joins:
             cur.wait_event(ev)
+
+    def _copy_event(self, slot: int, p: int, lo: int):
+        """the event behind the push of rows starting at `lo` of `slot` to destination p (created once, reused: nbuf exchanges
+        later its previous use has long been waited for)"""
+        key = (slot, p, lo)
+        ev = self._events.get(key)
+        if ev is None:
+            ev = torch.cuda.Event()
+            with torch.cuda.stream(self._copy_streams[p]):
+                ev.record()                  # a torch event has no handle before its first record
+            self._events[key] = ev
+        return ev
 
     def push_rows(self, y: torch.Tensor, slot: int, row0: int, nrows: int):
         """Sub-batch form: push rows [row0, row0 + nrows) of this rank's shard into every peer's buffer (ordered
@@ -419,6 +559,18 @@ class PeerCopyAllGather:
     def gather(self, y: torch.Tensor, slot: int):
         if y.shape != (self.rows, self.n) or not y.is_contiguous():
             raise ValueError(f"expected a contiguous {(self.rows, self.n)} shard, got {tuple(y.shape)}")
+        if self.prof is not None:
+            import time
+            t0 = time.perf_counter()
+            self._claim(slot)
+            t1 = time.perf_counter()
+            self._push(y, slot, self.rank * self.rows)
+            t2 = time.perf_counter()
+            r = self._signal(slot)
+            t3 = time.perf_counter()
+            for k, v in (("claim", t1 - t0), ("push", t2 - t1), ("signal", t3 - t2), ("n", 1)):
+                self.prof[k] = self.prof.get(k, 0.0) + v
+            return r
         self._claim(slot)
         self._push(y, slot, self.rank * self.rows)
         return self._signal(slot)

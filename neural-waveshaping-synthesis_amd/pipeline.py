@@ -52,46 +52,47 @@ class _Slot:
         self.keep = None
 
 
-_STREAM_SETS = {}
+_PLACED = {}             # device index -> _Placement: ONE measured stream set per process and device
+_BLOCKED = 0.30          # nws_queue_probe: touch stamps of queues served meanwhile sit at 0.01-0.06 of the hold grid's dispatch window, blocked ones at 0.45-1.05
 
 
-def placed_streams(dev, audio_streams: int = 2, control_streams: int = 2):
-    """(exchange stream, audio streams, control streams) of a device, created ONCE per process and shape and put on the command
-    processor's pipes in a fixed pattern.
+class _Placement:
+    """The pipeline's streams on one device and how they were found (`report`: what bench.py prints as config.placement)."""
+    __slots__ = ("exchange", "audio", "control", "spare", "report", "audio_anchors", "side")
 
-    Measured on MI355X (round 5, `tools/queue_order_probe.sh`, profiles/r05/queue_placement.txt): HIP creates a stream's
-    hardware queue at the stream's FIRST use, and the k-th hardware queue of a process (all priorities counted together) is
-    served by pipe k % 4 of the command processor.  A pipe dispatches one kernel at a time, and the oscillator kernel keeps its
-    pipe busy for its whole duration (16 000 workgroups are handed out as slots free up), so
-      * the two audio and two control streams must sit on FOUR DIFFERENT pipes: the next batch's recurrence queued on an audio
-        stream's pipe waits for the oscillator kernel to finish dispatching (0.399 ms per step -> 0.47 / 0.53 with the second
-        control stream on the first / second audio stream's pipe; period 4 in the number of queues created in between);
-      * a fifth queue (the exchange of the multi-GPU path) shares a pipe with one of the four whatever happens: beside an audio
-        stream three small launches per step on it cost 8-13 % of the step in every session; beside a control stream and created
-        BEFORE it they were free in every session (x1.00-1.02), created after it free in one session and +11 % in another.
-    Hence the first-use order  exchange, audio 0, audio 1, control 0, control 1  (consecutive queues: the four on four pipes,
-    the exchange queue ahead of control 1 on its pipe), and ONE set per process: every ForwardPipeline of the same shape runs
-    on the same streams (a second set would land on whatever pipes the creation count has reached - bench legs that built
-    their own pipelines used to run up to 15 % slower than the same code alone)."""
-    key = (torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device(), audio_streams,
-           control_streams)
-    got = _STREAM_SETS.get(key)
-    if got is not None:
-        return got
+
+def queue_probe(hold, touch, scratch, groups: int = 8192, spin_us: int = 10) -> float:
+    """nws_queue_probe (include/nws_hip.h): where the wall-clock stamp of ONE wave on `touch` falls inside the dispatch window of
+    a grid that `hold`'s hardware queue is busy handing out - ~0: served meanwhile; >= _BLOCKED: it waited (same pipe)."""
+    import ctypes as C
+    frac = C.c_float()
+    _lib.check(_lib.lib().nws_queue_probe(hold.cuda_stream, touch.cuda_stream, groups, spin_us, scratch.data_ptr(), C.byref(frac)),
+               "nws_queue_probe")
+    return float(frac.value)
+
+
+def _first_use(st, touch):
+    with torch.cuda.stream(st):            # HIP creates a stream's hardware queue at its first use
+        touch.fill_(0.0)
+    st.synchronize()
+
+
+def _place_in_fixed_order(dev, rep):
+    """Round 5's placement: no measurement, the streams first used in the order exchange, audio 0, audio 1, control 0, control 1 -
+    right only when exactly one hardware queue (the null stream's) exists so far.  `NWS_PLACEMENT=order` and the fallback."""
     xs = torch.cuda.Stream(device=dev)
-    # a side stream only pays off if its work is small next to the audio half: high priority keeps its few workgroups
-    # from queueing behind thousands of oscillator workgroups at dispatch
-    audio = [torch.cuda.Stream(device=dev) for _ in range(audio_streams)]
-    control = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(control_streams)]
+    audio = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    control = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(2)]
     touch = torch.zeros(64, device=dev)
     order = [xs] + audio + control
     probe = os.environ.get("NWS_STREAM_ORDER")     # measurements (tools/queue_order_probe.sh): another first-use order, e.g.
+    spare = []
     if probe:                                      # "a0,a1,c0,d,d,c1,x" - x exchange, aK / cK audio / control, d / h a dummy normal /
-        order, dummies = [], []                    # high-priority stream that is never used again; unnamed streams follow in the default order
+        order = []                                 # high-priority stream that is never used again; unnamed streams follow in the default order
         for tok in probe.split(","):
             if tok in ("d", "h"):
-                dummies.append(torch.cuda.Stream(device=dev, priority=-1 if tok == "h" else 0))
-                order.append(dummies[-1])
+                spare.append(torch.cuda.Stream(device=dev, priority=-1 if tok == "h" else 0))
+                order.append(spare[-1])
             elif tok == "x":
                 order.append(xs)
             elif tok[:1] in ("a", "c") and tok[1:].isdigit():
@@ -99,17 +100,245 @@ def placed_streams(dev, audio_streams: int = 2, control_streams: int = 2):
                 if int(tok[1:]) < len(lst):
                     order.append(lst[int(tok[1:])])
         order += [st for st in [xs] + audio + control if not any(st is o for o in order)]
-    for st in order:                           # first use, in this order, one at a time
-        with torch.cuda.stream(st):
-            touch.fill_(0.0)
-        st.synchronize()
-    _STREAM_SETS[key] = (xs, audio, control)
-    return _STREAM_SETS[key]
+        rep["first_use_order"] = probe
+    for st in order:
+        _first_use(st, touch)
+    return xs, audio, control, spare
+
+
+def _place_by_measurement(dev, rep):
+    """Find five streams whose hardware queues sit on the command processor's pipes as the pipeline needs them, whatever this
+    process created before: candidates are first used one at a time and CLASSIFIED with nws_queue_probe.
+
+    What the probe shows on MI355X (round 6, tools/queue_pipe_map.py, profiles/r06/queue_pipe_map.txt; every layout, every
+    repeat): the k-th hardware queue of a process falls into class k % 4, and a HIGH-priority queue whose grid is waiting for
+    slots blocks every NORMAL-priority queue of its class until the grid has been handed out - never one of another class.
+    (Normal on normal and high on high block only in some constellations: not used.)  That is the very relation that costs
+    the pipeline its 18-35 %: the recurrence (251 registers per wave: its workgroups wait for oscillator workgroups to drain)
+    sits on a high-priority control stream, and whatever shares its class - an audio stream's reverb, the next frame MLPs -
+    stands still meanwhile.
+
+    Candidates: four normal-priority streams, then four high-priority ones (consecutive queues: each kind covers all four
+    classes when queues are assigned round-robin; otherwise more candidates are drawn, up to the queue budget).  hold = every
+    high candidate, touch = the submitting stream and every normal candidate gives each candidate its class.  Then
+        control 0 = the high stream of the submitting stream's class (its stalls delay nothing but the next event record),
+        exchange + control 1 = a (normal, high) pair of a second class (the exchange queue created BEFORE the control stream it
+                       shares a pipe with: free in every session of profiles/r05/queue_placement.txt),
+        audio 0, audio 1 = the normal streams of the remaining two classes (each proven apart by the high stream that blocks it).
+    The unused candidates stay alive and idle (an idle queue costs nothing; a destroyed one would hand its slot to the next
+    stream of the process).  The choice is verified by a second pass over the chosen streams."""
+    cur = torch.cuda.current_stream(dev)
+    touch = torch.zeros(64, device=dev)
+    scratch = torch.zeros(4, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize(dev)
+    normals, highs = [], []
+    blocked = {}                 # (index of high, index of normal or -1 for the submitting stream) -> bool
+    probes = 0
+
+    def measure():
+        nonlocal probes
+        for hi, h in enumerate(highs):
+            for ni, n in [(-1, cur)] + list(enumerate(normals)):
+                if (hi, ni) not in blocked:
+                    blocked[(hi, ni)] = queue_probe(h, n, scratch) >= _BLOCKED
+                    probes += 1
+
+    def choose():
+        cls = {ni: [hi for hi in range(len(highs)) if blocked[(hi, ni)]] for ni in [-1] + list(range(len(normals)))}
+        for c0 in cls[-1]:                                         # control 0: blocks the submitting stream
+            for xi in range(len(normals)):                         # exchange: a normal stream of another class ...
+                if blocked[(c0, xi)]:
+                    continue
+                for c1 in cls[xi]:                                 # ... and control 1 the high stream that blocks it
+                    if c1 == c0 or blocked[(c1, -1)]:
+                        continue
+                    free = [ni for ni in range(len(normals)) if ni != xi and not blocked[(c0, ni)] and not blocked[(c1, ni)] and cls[ni]]
+                    for a0 in free:
+                        for a1 in free:
+                            # two audio streams proven apart: each is blocked by a high stream that leaves the other alone
+                            if a1 > a0 and any(not blocked[(h, a1)] for h in cls[a0]) and any(not blocked[(h, a0)] for h in cls[a1]):
+                                return c0, c1, xi, a0, a1
+        return None
+
+    got = None
+    for rnd in range(2):         # round-robin queues: the first round always succeeds (8 candidates); one more round otherwise
+        for _ in range(4):
+            normals.append(torch.cuda.Stream(device=dev))
+            _first_use(normals[-1], touch)
+        for _ in range(4):
+            highs.append(torch.cuda.Stream(device=dev, priority=-1))
+            _first_use(highs[-1], touch)
+        measure()
+        got = choose()
+        if got is not None:
+            break
+    rep.update(probes=probes, candidates=len(normals) + len(highs),
+               blocked=["".join("x" if blocked[(hi, ni)] else "." for ni in [-1] + list(range(len(normals)))) for hi in range(len(highs))])
+    if got is None:
+        rep["spare"] = normals + highs
+        return None
+    c0, c1, xi, a0, a1 = got
+    xs, audio, control = normals[xi], [normals[a0], normals[a1]], [highs[c0], highs[c1]]
+    # second pass over the chosen streams only (a fresh measurement of every relation the pipeline depends on)
+    want = {(0, "cur"): True, (0, "x"): False, (0, "a0"): False, (0, "a1"): False,
+            (1, "cur"): False, (1, "x"): True, (1, "a0"): False, (1, "a1"): False}
+    named = {"cur": cur, "x": xs, "a0": audio[0], "a1": audio[1]}
+    seen = {k: queue_probe(control[k[0]], named[k[1]], scratch) >= _BLOCKED for k in want}
+    rep["probes"] = probes + len(want)
+    rep["verified"] = seen == want
+    # which normal candidate shares the submitting stream's class tells how many queues the process had created before (mod 4)
+    with_cur = [ni for ni in range(len(normals)) if blocked[(c0, ni)]]
+    rep["queue_offset"] = (4 - (with_cur[0] + 1)) % 4 if with_cur else None
+    rep["chosen"] = {"exchange": f"n{xi}", "audio": [f"n{a0}", f"n{a1}"], "control": [f"h{c0}", f"h{c1}"]}
+    spare = [st for st in normals + highs if not any(st is u for u in [xs] + audio + control)]
+    # the idle high-priority candidates of the two audio classes: with them as `hold`, any later normal stream can be told
+    # apart from "beside an audio stream" (side_streams)
+    cls = lambda ni: [hi for hi in range(len(highs)) if blocked[(hi, ni)]]
+    rep["_audio_anchors"] = [highs[cls(a0)[0]], highs[cls(a1)[0]]]
+    return xs, audio, control, spare
+
+
+def placed_streams(dev, audio_streams: int = 2, control_streams: int = 2):
+    """(exchange stream, audio streams, control streams) of a device: ONE set per process and device, found by measurement.
+
+    Why placement matters (round 5, profiles/r05/queue_placement.txt): HIP creates a stream's hardware queue at the stream's
+    FIRST use, the k-th hardware queue of a process is served by pipe k % 4 of the command processor, and a pipe stays on a grid
+    for as long as workgroups of it wait for a slot.  The two audio and two control streams have to sit on FOUR DIFFERENT pipes
+    (the next batch's recurrence on an audio stream's pipe: 0.399 ms per step -> 0.47 / 0.53), the audio streams away from the
+    submitting stream's pipe (+12 %), the exchange queue of the multi-GPU path beside a control stream and created before it.
+    Round 5 got there by first-use ORDER, which is right only in a process that has created no other queue (three streams used
+    earlier: +12 %; a second pipeline shape first used in between: +18-35 %; all of it silent).  Now the queues are measured
+    (`_place_by_measurement`), so streams an integrator, a data loader or RCCL used before do not matter, and every
+    ForwardPipeline of the process - whatever its stream counts - runs on prefixes of the ONE set (one audio stream: audio 0; one
+    control stream: control 0).  More than two of a kind are refused (`streams=` of ForwardPipeline takes private ones).
+
+    `placement_report(dev)` returns what was found; a placement that could not be found or did not verify falls back to the
+    first-use order LOUDLY (a RuntimeWarning and `ok: False` in the report).  NWS_PLACEMENT=order skips the measurement.
+    Needs GPU_MAX_HW_QUEUES >= 12 in the environment before the HIP runtime starts (the package sets 16 at import when it is
+    imported first; HIP folds streams onto 4 hardware queues by default and the pipeline's five cannot be told apart then)."""
+    import time
+    import warnings
+    if audio_streams > 2 or control_streams > 2:
+        raise ValueError("the placed stream set holds two audio and two control streams (four pipes); pass private streams to "
+                         "ForwardPipeline(streams=...) for anything else")
+    d = torch.device(dev)
+    key = d.index if d.index is not None else torch.cuda.current_device()
+    pl = _PLACED.get(key)
+    if pl is None:
+        pl = _Placement()
+        t0 = time.perf_counter()
+        mode = os.environ.get("NWS_PLACEMENT", "probe")
+        hwq = os.environ.get("GPU_MAX_HW_QUEUES")
+        rep = {"mode": mode, "ok": True, "gpu_max_hw_queues": hwq}
+        if hwq is None or int(hwq) < 12:
+            warnings.warn(f"GPU_MAX_HW_QUEUES={hwq}: HIP shares hardware queues between streams beyond that count (default 4) and the "
+                          f"pipeline's five streams need queues of their own - export GPU_MAX_HW_QUEUES=16 before the first HIP call",
+                          RuntimeWarning, stacklevel=2)
+            rep["ok"] = False
+        elif int(hwq) > 20:
+            # measured (profiles/r06/fake_peers_ab.txt): with 25 hardware queues in one process every step of the pipeline took 10x
+            # as long (4.2 ms instead of 0.40) - the queues no longer all fit the command processor's slots and get multiplexed
+            warnings.warn(f"GPU_MAX_HW_QUEUES={hwq}: beyond ~24 hardware queues per process the command processor multiplexes them and "
+                          f"every kernel launch slows down by an order of magnitude; 16 is what this package is measured with",
+                          RuntimeWarning, stacklevel=2)
+        got, kept = None, []
+        with torch.cuda.device(key):
+            if mode != "order" and not os.environ.get("NWS_STREAM_ORDER"):
+                got = _place_by_measurement(d, rep)
+                kept = rep.pop("spare", [])            # candidates of a search that found nothing: kept alive, idle
+                if got is None or not rep.get("verified"):
+                    rep["ok"] = False
+                    warnings.warn(f"ForwardPipeline: no verified placement of the stream set on the command processor's pipes ({rep}); "
+                                  f"{'falling back to first-use order' if got is None else 'using the unverified choice'} - the step can "
+                                  f"be 12-35 % slower", RuntimeWarning, stacklevel=2)
+            if got is None:
+                rep["mode"] = "order" if (mode == "order" or os.environ.get("NWS_STREAM_ORDER")) else "order (fallback)"
+                got = _place_in_fixed_order(d, rep)
+                got = got[:3] + (got[3] + kept,)
+        pl.exchange, pl.audio, pl.control, pl.spare = got
+        pl.audio_anchors = rep.pop("_audio_anchors", None)
+        pl.side = []
+        rep["ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+        pl.report = rep
+        _PLACED[key] = pl
+    return pl.exchange, pl.audio[:audio_streams], pl.control[:control_streams]
+
+
+def side_streams(dev, n: int, max_candidates: int = 0):
+    """n normal-priority streams for work that runs BESIDE the pipeline (the per-peer copy streams of the multi-GPU exchange,
+    parallel.PeerCopyAllGather) whose hardware queues do not share a pipe with an audio stream: candidates are first used one at a
+    time and kept unless the idle high-priority stream of one of the two audio classes blocks them (nws_queue_probe; the
+    rejected ones stay alive and idle).  Three small launches per step on a queue beside an audio stream cost the pipelined step
+    8-13 % (profiles/r05/queue_placement.txt); seven copy streams created blindly put four of them there.
+    Every call hands out the same streams (first n of the device's list).  Without a measured placement (NWS_PLACEMENT=order, a
+    fallback) or when the queue budget runs out the remaining streams are plain new ones / the kept ones again, round-robin -
+    recorded in placement_report()['side']."""
+    d = torch.device(dev)
+    key = d.index if d.index is not None else torch.cuda.current_device()
+    placed_streams(d)
+    pl = _PLACED[key]
+    max_candidates = max_candidates or 2 * n + 2
+    rep = pl.report.setdefault("side", {"kept": 0, "rejected": 0, "plain": 0, "reused": 0})
+    with torch.cuda.device(key):
+        if len(pl.side) < n and pl.audio_anchors:
+            touch = torch.zeros(64, device=d)
+            scratch = torch.zeros(4, dtype=torch.int64, device=d)
+            torch.cuda.synchronize(d)
+            while len(pl.side) < n and rep["kept"] + rep["rejected"] < max_candidates:
+                st = torch.cuda.Stream(device=d)
+                _first_use(st, touch)
+                if any(queue_probe(h, st, scratch) >= _BLOCKED for h in pl.audio_anchors):
+                    pl.spare.append(st)
+                    rep["rejected"] += 1
+                else:
+                    pl.side.append(st)
+                    rep["kept"] += 1
+        if len(pl.side) < n:
+            if pl.side and pl.audio_anchors:        # budget exhausted: the kept ones again, round-robin (copies on one stream serialise)
+                k = len(pl.side)
+                rep["reused"] = n - k
+                return [pl.side[i % k] for i in range(n)]
+            while len(pl.side) < n:                 # no measured placement to go by
+                pl.side.append(torch.cuda.Stream(device=d))
+                rep["plain"] += 1
+    return pl.side[:n]
+
+
+def placement_report(dev=None):
+    """What placed_streams found on `dev` (None before the first pipeline): mode, ok, verified, queue_offset (hardware queues the
+    process had created before, mod 4), the blocked matrix (rows = high candidates, columns = submitting stream + normal candidates)."""
+    d = torch.device(dev if dev is not None else "cuda")
+    pl = _PLACED.get(d.index if d.index is not None else torch.cuda.current_device())
+    return dict(pl.report) if pl is not None else None
+
+
+def verify_placement(dev=None):
+    """Measure again, now, the relations the pipeline depends on (needs an idle GPU: it synchronises the streams it probes).
+    {relation: bool} and `ok`; raises if there is no placement yet."""
+    d = torch.device(dev if dev is not None else "cuda")
+    key = d.index if d.index is not None else torch.cuda.current_device()
+    pl = _PLACED[key]
+    with torch.cuda.device(key):
+        scratch = torch.zeros(4, dtype=torch.int64, device=d)
+        cur = torch.cuda.current_stream(d)
+        torch.cuda.synchronize(d)
+        named = {"cur": cur, "x": pl.exchange, "a0": pl.audio[0], "a1": pl.audio[1]}
+        want = {"c0 blocks cur": True, "c0 blocks x": False, "c0 blocks a0": False, "c0 blocks a1": False,
+                "c1 blocks cur": False, "c1 blocks x": True, "c1 blocks a0": False, "c1 blocks a1": False}
+        seen = {k: queue_probe(pl.control[int(k[1])], named[k.split()[-1]], scratch) >= _BLOCKED for k in want}
+    return {"ok": seen == want, "seen": seen, "want": want}
 
 
 class ForwardPipeline:
+    """Streams.  By default every pipeline of a process runs on the ONE measured stream set of its device (`placed_streams`:
+    at most two audio and two control streams; a pipeline that asks for one of a kind takes the first).  Pipelines of one
+    process therefore share queues - two models submitted alternately serialise where they meet on a stream; their results are
+    unaffected.  `streams=(exchange, [audio...], [control...])` gives a pipeline private streams instead (independent
+    pipelines, more than two streams of a kind): the caller then owns their placement on the command processor's pipes
+    (`placed_streams` explains what is at stake: up to +35 % per step) and `audio_streams` / `control_streams` are ignored."""
+
     def __init__(self, model, depth: int = 4, audio_streams: int = 2, control_streams: int = 1, batched_gru: bool = False,
-                 chain_exciters: bool = False):
+                 chain_exciters: bool = False, streams=None):
         if depth < 2 or audio_streams < 1 or control_streams < 1:
             raise ValueError("need depth >= 2 and at least one stream of each kind")
         self.model = model
@@ -118,7 +347,14 @@ class ForwardPipeline:
         self.dev = dev
         # streams placed on the command processor's pipes (placed_streams); `exchange` is for a multi-GPU caller's
         # parallel.CompletionDrivenExchange (unused otherwise: an idle queue costs nothing)
-        self.exchange, self.audio, self.control = placed_streams(dev, audio_streams, control_streams)
+        if streams is not None:
+            xs, au, co = streams
+            if not au or not co:
+                raise ValueError("streams=(exchange, audio streams, control streams) needs at least one stream of each kind")
+            self.exchange, self.audio, self.control = xs, list(au), list(co)
+            audio_streams = len(self.audio)
+        else:
+            self.exchange, self.audio, self.control = placed_streams(dev, audio_streams, control_streams)
         self.slots = [_Slot() for _ in range(depth)]
         self.batched_gru = batched_gru
         # The oscillator + waveshaper kernel saturates vector issue on every CU: two of them side by side (the audio halves
@@ -169,6 +405,11 @@ class ForwardPipeline:
         B, _, T = f0.shape
         if control.shape[0] != B or control.shape[2] != T or T < 2:
             raise RuntimeError("f0 and control disagree on batch / frames (or fewer than 2 frames)")
+        if block_events is not None and (self.chain_exciters or on_block is not None or row_blocks is None or len(row_blocks) < 2):
+            # the events would never be recorded, and synchronize() on a never-recorded event returns at once: a helper thread
+            # would push rows the reverb has not written yet
+            raise ValueError("block_events are recorded by the one-call block path only: they need row_blocks of two or more blocks, "
+                             "no on_block callback and chain_exciters off")
         self._prepare(B, T)
         i = self._n
         self._n += 1

@@ -26,10 +26,25 @@ def _declared_symbols(headers=("nws_hip.h", "nws_hip_debug.h")):
 
 
 def test_product_header_holds_no_diagnostic_entry_points():
-    """ABI v5: timing ablations and hazard probes live in include/nws_hip_debug.h, the product ABI in include/nws_hip.h"""
-    product, debug = _declared_symbols(("nws_hip.h",)), _declared_symbols(("nws_hip_debug.h",))
+    """Timing ablations live in include/nws_hip_debug.h, the hazard probes in include/nws_probe.h (a library of their own, ABI v6),
+    the product ABI in include/nws_hip.h"""
+    product, debug, probe = (_declared_symbols((h,)) for h in ("nws_hip.h", "nws_hip_debug.h", "nws_probe.h"))
     assert not [n for n in product if n.startswith(("nws_debug_", "nws_coexec_"))]
-    assert debug and all(n.startswith(("nws_debug_", "nws_coexec_")) for n in debug)
+    assert debug and all(n.startswith("nws_debug_") for n in debug)
+    assert probe and all(n.startswith("nws_coexec_") for n in probe)
+
+
+def test_probe_library_is_apart_from_the_product_library():
+    """VERDICT r5 hygiene (b): the product library holds no kernel on the build guard's allow-list - the hazard probe is
+    libnws_probe.so, which exports exactly what include/nws_probe.h declares and nothing of the product ABI."""
+    declared = _declared_symbols(("nws_probe.h",))
+    probe = C.CDLL(_lib.PROBE_LIB_PATH)
+    for name in declared:
+        assert hasattr(probe, name), name
+    assert sorted(_lib.PROBE_SYMBOLS) == declared
+    product = C.CDLL(_lib.LIB_PATH)
+    assert not any(hasattr(product, name) for name in declared)
+    assert not hasattr(probe, "nws_forward")
 
 
 def test_library_exports_every_declared_symbol():
@@ -44,7 +59,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_strings():
     L = _lib.lib()
-    assert L.nws_abi_version() == _lib.ABI_VERSION == 5
+    assert L.nws_abi_version() == _lib.ABI_VERSION == 6
     assert b"unsupported" in L.nws_error_string(-1)
     assert b"bad argument" in L.nws_error_string(-2)
     assert L.nws_error_string(0) == b"ok"
@@ -291,12 +306,13 @@ def test_build_guard_finds_swizzled_packed_forms():
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
     b.build(verbose=False)
+    assert "coexec_probe.hip" not in b.SOURCES and b.PROBE_SOURCES == ["coexec_probe.hip"]
     for src in b.SOURCES:
         obj = os.path.join(b.OBJ, src.replace(".hip", ".o"))
         assert os.path.exists(obj), obj
-        assert b.check_packed_swizzles(obj) == [], src
-    b.SWIZZLE_ALLOW = ()
-    found = b.check_packed_swizzles(os.path.join(b.OBJ, "coexec_probe.o"))
+        assert b.check_packed_swizzles(obj, ()) == [], src        # product objects: nothing is allowed
+    assert b.check_packed_swizzles(os.path.join(b.OBJ, "coexec_probe.o")) == []       # the probe: only its own three kernels
+    found = b.check_packed_swizzles(os.path.join(b.OBJ, "coexec_probe.o"), ())
     first = [i for k, i in found if "pk_probe_kernel" in k]
     assert len(first) == 4 and all("pk_probe" in k for k, _ in found), found      # the 4 hazardous fp32 forms of probe 1
 

@@ -204,3 +204,43 @@ def test_completion_driven_exchange_two_ranks(tmp_path):
             want = np.arange(b * n, dtype=np.float32).reshape(b, n) + 1000.0 * i + 100000.0 * r
             assert np.array_equal(got[0][i][r * b:(r + 1) * b], want), (i, r)
     assert all(np.load(tmp_path / f"e{r}.npy")[0] for r in range(world))
+
+
+def test_exchange_worker_is_poisoned_by_its_first_failure():
+    """after one issue() raises, this rank must not issue any later exchange - its peers would pair their
+    exchange i with this rank's i + 1 (same shapes: no error, silently wrong gather buffers).  Every later ticket completes with
+    the first failure without calling its issue(), post() raises on the submitting thread, acquire() / drain() raise too."""
+    import importlib
+    import threading
+
+    par = importlib.import_module("neural-waveshaping-synthesis_amd.parallel")
+    x = par.CompletionDrivenExchange(torch.device("cpu"), 4)
+    issued, gate = [], threading.Event()
+
+    def ok(i):
+        def f():
+            gate.wait(5)
+            issued.append(i)
+            return torch.zeros(1)
+        return f
+
+    def bad():
+        gate.wait(5)
+        raise ValueError("link down")
+
+    t0 = x.post(0, None, ok(0))
+    x.post(1, None, bad)
+    t2 = x.post(2, None, ok(2))         # queued before the failure is known: must complete WITHOUT being issued
+    gate.set()
+    assert t2.issued.wait(5)
+    assert issued == [0] and isinstance(t2.exc, ValueError) and t0.exc is None and t0.keep is not None
+    with pytest.raises(RuntimeError, match="failed earlier"):
+        x.post(3, None, ok(3))           # the submitting thread stops at once
+    x.acquire(0)                          # the exchange that went out before the failure is still good
+    assert t0.keep is None               # ... and what it read is let go once its slot has been acquired
+    with pytest.raises(RuntimeError, match="exchange worker failed"):
+        x.acquire(2)
+    with pytest.raises(RuntimeError, match="exchange worker failed"):
+        x.drain()
+    assert issued == [0]
+    x.close()

@@ -27,7 +27,7 @@ def run(blocks=4096, iters=2000, rounds=5, product_kernels=True):
     import torch
     import nws_amd
     _lib = nws_amd._lib
-    L = _lib.lib()
+    L = _lib.probe_lib()         # libnws_probe.so (include/nws_probe.h): the hazard kernels are not part of the product library
     s_probe, s_load = torch.cuda.Stream(), torch.cuda.Stream()
     report = torch.zeros(16, dtype=torch.int32, device="cuda")
     sink = torch.zeros(256, device="cuda")
