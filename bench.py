@@ -464,15 +464,23 @@ def main():
     N = 128 * T
     f0, control = make_inputs(a, dev, rank)
 
-    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, a.streams))]
+    # NWS_BENCH_PRE_STREAMS=k (tools/scale_check.py; never set by the driver): k streams created AND used before the pipeline exists -
+    # a process with a history of hardware queues; the measured placement (pipeline.placed_streams) has to absorb it
+    pre_streams = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get("NWS_BENCH_PRE_STREAMS", "0")))]
+    for ps in pre_streams:
+        with torch.cuda.stream(ps):
+            f0.add_(0.0)
+        ps.synchronize()
+    n_audio = max(1, a.streams)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_audio)] if not a.pipeline else []
     shared_gen = par.make_shared_generator(dev) if distributed else None   # same draws on every rank, no broadcast
     use_pipe = bool(a.pipeline)
     pipe = None
     if use_pipe:
         pmod = importlib.import_module("neural-waveshaping-synthesis_amd.pipeline")
         n_control = a.control_streams if a.control_streams > 0 else 2
-        pipe = pmod.ForwardPipeline(model, depth=a.depth if a.depth > 0 else len(streams) + 2,
-                                    audio_streams=len(streams), control_streams=n_control, batched_gru=a.gru == "batched",
+        pipe = pmod.ForwardPipeline(model, depth=a.depth if a.depth > 0 else n_audio + 2,
+                                    audio_streams=n_audio, control_streams=n_control, batched_gru=a.gru == "batched",
                                     chain_exciters=bool(a.chain_exciters))
         streams = pipe.audio
     # gather buffers: a ring of its own (not the workspace ring): a buffer is free again once its exchange is out, and the
