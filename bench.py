@@ -389,10 +389,32 @@ def time_leg(model, f0, control, steps, warmup, audio_streams, control_streams):
     return el / steps * 1e3
 
 
-def main():
+class Hooks:
+    """Where a diagnosis tool may reach into the run (tools/world1_diag.py subclasses this and calls main(hooks=...)); the bench
+    itself runs with the no-op defaults - no diagnosis switch lives in this file."""
+
+    def before_model(self, dev, distributed):
+        """after the process group (if any) is up, before the model and the pipeline exist"""
+
+    def after_setup(self, dev, xchg, peer):
+        """the pipeline, the exchange worker and the peer-copy object exist"""
+
+    def post_behind(self, xchg, slot_i, ev, issue):
+        """called instead of xchg.post(slot_i, ev, issue) when it returns True"""
+        return False
+
+    def around_timed(self):
+        """context manager around the enqueue loop of every timed region"""
+        import contextlib
+        return contextlib.nullcontext()
+
+    def extra(self, extra, steps, xchg, peer):
+        """add fields to the JSON line (rank 0, after the headline region)"""
+
+
+def main(hooks=None):
+    hooks = hooks or Hooks()
     a = parse()
-    if os.environ.get("NWS_SWITCH"):      # diagnosis: the interpreter's thread switch interval (submitting thread vs exchange helper thread)
-        sys.setswitchinterval(float(os.environ["NWS_SWITCH"]))
     if a.pmc_child:
         pmc_child(a)
         return
@@ -427,15 +449,6 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1 or force_dist
-    if os.environ.get("NWS_BENCH_INIT_PG_ONLY") == "1" and not distributed:
-        # diagnosis only: an initialised RCCL communicator beside the single-GPU issue pattern (what does its mere presence cost?)
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29512")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
-        dist.barrier()
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -447,6 +460,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
         assert dist.get_world_size() == world, (dist.get_world_size(), world)
+    hooks.before_model(dev, distributed)
     nws = importlib.import_module("neural-waveshaping-synthesis_amd")
     _lib = importlib.import_module("neural-waveshaping-synthesis_amd._lib")
     par = importlib.import_module("neural-waveshaping-synthesis_amd.parallel")
@@ -512,12 +526,7 @@ def main():
     # N > 1 with the pipeline: every exchange is issued by a helper thread, on its own stream, once the HOST has seen its batch
     # complete (no hardware queue parked on a cross-queue barrier: +30 % per step with nothing to send otherwise, LABBOOK round 5)
     xchg = par.CompletionDrivenExchange(dev, nbuf, stream=pipe.exchange) if (distributed and use_pipe) else None
-    DIAG = set(filter(None, os.environ.get("NWS_BENCH_DIAG", "").split(",")))     # diagnosis switches (tools/world1_diag.sh)
-    fake_side = torch.cuda.Stream(device=dev) if "queued" in DIAG else None
-
-    if xchg is not None and "wprof" in DIAG:
-        xchg.profile = []
-    tiny = [torch.zeros(64, device=dev) for _ in range(3)]
+    hooks.after_setup(dev, xchg, peer)
 
     def issue_whole(i, y):
         """worker thread, exchange stream current: this step's waveforms to every rank (the timed loop never reads the gathered
@@ -553,20 +562,7 @@ def main():
         """the exchange `issue` leaves once everything enqueued on `stream` so far is complete"""
         ev = torch.cuda.Event()
         ev.record(stream)
-        if "noexch" in DIAG:      # diagnosis: the mechanism alone (events, helper thread), nothing issued
-            xchg.post(slot_i, ev, lambda: None)
-            return
-        if "blit3" in DIAG:       # diagnosis: three tiny launches on the exchange stream in place of the collective
-            def blits():
-                tiny[0].fill_(0.0)
-                tiny[1].fill_(1.0)
-                tiny[2].copy_(tiny[0])
-            xchg.post(slot_i, ev, blits)
-            return
-        if "queued" in DIAG:      # diagnosis: the round-4 form, a device-side wait on a side queue (what costs +30 %)
-            fake_side.wait_event(ev)
-            with torch.cuda.stream(fake_side):
-                issue()
+        if hooks.post_behind(xchg, slot_i, ev, issue):
             return
         xchg.post(slot_i, ev, issue)
 
@@ -644,18 +640,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        prof = None
-        if os.environ.get("NWS_BENCH_CPROFILE") == "1":      # diagnosis: where the host's time per step goes
-            import cProfile
-            prof = cProfile.Profile()
-            prof.enable()
-        for i in range(n_steps):
-            pending = step(i, pending, **kw)
+        with hooks.around_timed():
+            for i in range(n_steps):
+                pending = step(i, pending, **kw)
         host_issue["s_per_step"] = (time.perf_counter() - t0) / max(1, n_steps)   # host time to ENQUEUE a step (no sync inside)
-        if prof is not None:
-            import pstats
-            prof.disable()
-            pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
         if pending is not None:
             pending.wait()
         if xchg is not None:
@@ -694,16 +682,9 @@ def main():
         torch.cuda.synchronize()
         # live HIP-event timing of the dominant kernel (and the GRU) on their launch streams, inside the timed region
         _lib.check(_lib.lib().nws_profile_begin(a.steps, (1 << 3) | (1 << 1)))
-        if peer is not None and peer.prof is not None:
-            peer.prof.clear()
         elapsed, per_rank = timed(a.steps)
         extra["host_issue_ms_per_step"] = round(host_issue["s_per_step"] * 1e3, 4)
-        if peer is not None and peer.prof:
-            extra["peer_gather_us"] = {k: round(v / max(1.0, peer.prof.get("n", 1.0)) * 1e6, 1) for k, v in peer.prof.items() if k != "n"}
-        if xchg is not None and xchg.profile:
-            pr = np.array(xchg.profile[-a.steps:]) * 1e6
-            extra["exchange_worker_us"] = {"wait_p50": float(np.median(pr[:, 0])), "issue_p50": float(np.median(pr[:, 1])),
-                                           "record_p50": float(np.median(pr[:, 2])), "issue_mean": float(pr[:, 1].mean())}
+        hooks.extra(extra, a.steps, xchg, peer)
         ms = (C.c_float * (a.steps * 6))()
         n = C.c_int(0)
         _lib.check(_lib.lib().nws_profile_collect(ms, C.byref(n)))

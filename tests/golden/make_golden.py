@@ -20,6 +20,8 @@ Fixtures written:
   g8_small / g8_odd / g8_oddlen .npz three NON-default gin configurations (random init, recorded weights + gin text): inputs, draws,
                                      stage taps, y_newt, y_fast   (`... make_golden.py generic` regenerates only these)
   g9_upsampling.npz   data/utils/upsampling.py: linear / cubic-spline / overlap-add interpolators (`... make_golden.py upsampling`)
+  g10_timing_script.npz  the literal model of scripts/time_forward_pass.py:27-43: UNMODIFIED random-init NeuralWaveshaping() under
+                         gin/models/newt.gin, torch.rand inputs at T = 500, exact and FastNEWT (`... make_golden.py timing`)
 (`python tests/golden/make_golden.py instruments` regenerates only the fl / tpt four.)
 The RNG draws made inside forward are recorded by wrapping torch.rand / torch.rand_like.
 """
@@ -393,7 +395,30 @@ def upsampling_vectors():
     print("g9_upsampling.npz", {k: v.shape for k, v in out.items() if k.startswith("c1_")})
 
 
+def timing_script_model():
+    """g10_timing_script.npz: what scripts/time_forward_pass.py really runs (BASELINE config 1) - `NeuralWaveshaping()` with no
+    checkpoint (:41), `model.newt = FastNEWT(model.newt)` (:43), `torch.rand` control / f0 (:27-40) - with fixed seeds: the random
+    initial weights, the inputs, the two recorded draws and the reference's outputs for both shapers."""
+    gin.clear_config()
+    gin.parse_config_file(os.path.join(REF, "gin/models/newt.gin"))
+    torch.manual_seed(41)
+    control = torch.rand(1, 2, 16000 * 4 // 128)                          # :27-33
+    f0 = torch.rand(1, 1, 16000 * 4 // 128)                               # :34-40
+    model = NeuralWaveshaping()                                           # :41
+    exact_newt = model.newt
+    model.eval()
+    y_newt, pu, nz = run(model, f0, control, 4141)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.newt = FastNEWT(exact_newt)                                     # :43
+    y_fast, pu2, nz2 = run(model, f0, control, 4141)
+    assert np.array_equal(pu, pu2) and np.array_equal(nz, nz2)
+    save("g10_timing_script.npz", **sd, __f0__=f0, __control__=control, __phase_u__=pu, __noise__=nz, __y_newt__=y_newt, __y_fast__=y_fast)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["timing"]:
+        timing_script_model()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "upsampling":
         upsampling_vectors()
         sys.exit(0)
@@ -405,3 +430,4 @@ if __name__ == "__main__":
         main()
         instruments()
         generic_configs()
+        timing_script_model()

@@ -131,3 +131,14 @@ def test_rng_draw_order_matches_reference(oracles, g1):
     torch.manual_seed(1234)
     y = exact(g1["f0"], g1["control"]).numpy()
     assert rms(y - g1["y_newt"]) <= 2e-6
+
+
+def test_g10_timing_script_model():
+    """BASELINE config 1 literally (scripts/time_forward_pass.py:27-43): UNMODIFIED random-init NeuralWaveshaping() under
+    gin/models/newt.gin, torch.rand inputs at T = 500, both shapers - recorded from the real reference with fixed seeds."""
+    z = load_npz("g10_timing_script.npz")
+    w = {k: v for k, v in z.items() if not k.startswith("__")}
+    g = {"f0": z["__f0__"], "control": z["__control__"], "phase_u": z["__phase_u__"], "noise": z["__noise__"],
+         "y_newt": z["__y_newt__"], "y_fast": z["__y_fast__"]}
+    assert g["f0"].shape == (1, 1, 500) and float(g["f0"].max()) < 1.0 and g["y_newt"].shape == (1, 64000)
+    _check_e2e((OracleNEWT(w, fast=False), OracleNEWT(w, fast=True, lut_python_loop=False)), g, g, tol=5e-6)

@@ -19,6 +19,10 @@ def main():
         shapes = [(int(sys.argv[i]), int(sys.argv[i + 1])) for i in range(1, len(sys.argv) - 1, 2)]
     L = _lib.lib()
     MODES = tuple(int(x) for x in os.environ.get("MODES", "1,2").split(","))
+    # only the product kernel families are compared (1 tile kernels, 2 wave-resident frames): an ablation mode's output is
+    # meaningless by construction and used to print `nan` into the one correctness column of profiles/r0x/mlp_variants.txt
+    if not set(MODES) <= {1, 2}:
+        raise SystemExit("MODES: 1 (tile kernels) and / or 2 (wave-resident frames); timing ablations live in tools/mlp_timeline.py")
     for B, T in shapes:
         gru = torch.tanh(torch.randn(B, T, 128, device="cuda"))
         res = {}

@@ -15,7 +15,7 @@ done
 XORDERS=${XORDERS:-"x,a0,a1,c0,c1 a0,a1,c0,c1,x a0,a1,c0,c1,d,x a0,a1,c0,c1,d,d,x a0,a1,c0,c1,d,d,d,x"}
 for o in $XORDERS; do
   i=$((i+1)); n=$(printf "%02d" $i)
-  NWS_STREAM_ORDER=$o NWS_BENCH_DIAG=blit3 NWS_BENCH_FORCE_DIST=1 timeout 120 python bench.py $Q --gather rccl > gpurun_out/qo/${n}_blit3_${o//,/-}.json 2>/dev/null
+  NWS_STREAM_ORDER=$o NWS_BENCH_DIAG=blit3 NWS_BENCH_FORCE_DIST=1 timeout 120 python tools/world1_diag.py $Q --gather rccl > gpurun_out/qo/${n}_blit3_${o//,/-}.json 2>/dev/null
 done
 python - <<'PY'
 import json, glob, os

@@ -1,4 +1,4 @@
-# What the N > 1 issue pattern at world size 1 is made of (NWS_BENCH_DIAG switches of bench.py), same box:
+# What the N > 1 issue pattern at world size 1 is made of (NWS_BENCH_DIAG switches of tools/world1_diag.py = bench.py's main() with diagnosis hooks), same box:
 #   (none)   the product pattern: completion-driven exchange on the placed exchange stream
 #   noexch   the mechanism alone (events, helper thread), nothing issued
 #   blit3    three tiny launches per step on the exchange stream in place of the collective
@@ -12,7 +12,7 @@ i=0
 for g in rccl copy; do
   for d in wprof wprof,noexch wprof,blit3 queued; do
     i=$((i+1)); n=$(printf "%02d" $i)_${g}_${d//,/_}
-    NWS_BENCH_DIAG=$d NWS_BENCH_FORCE_DIST=1 timeout 120 python bench.py $Q --gather $g > gpurun_out/w1d/$n.json 2> gpurun_out/w1d/$n.err
+    NWS_BENCH_DIAG=$d NWS_BENCH_FORCE_DIST=1 timeout 120 python tools/world1_diag.py $Q --gather $g > gpurun_out/w1d/$n.json 2> gpurun_out/w1d/$n.err
   done
 done
 python - <<'PY'
