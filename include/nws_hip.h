@@ -38,6 +38,7 @@ extern "C" {
 #define NWS_FIR_HALF 128     /* taps handed from the frame MLPs to the noise kernel per frame: h[128 .. 255] (see nws_frame_mlps) */
 #define NWS_SHAPER_WIDTH 8
 #define NWS_FILM_CH 256      /* 4 * N_SHAPERS */
+#define NWS_FILM_REC_BYTES 1536 /* per-frame FiLM fragment record: 3 parameter types x 64 shapers x {bf16 t0, t1, t2, 0} (csrc/exciter_newt.hip) */
 
 enum {
   NWS_OK = 0,

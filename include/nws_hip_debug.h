@@ -18,10 +18,20 @@ int nws_debug_frame_mlps_kernel(int mode);
 int nws_debug_frame_mlps_probe(void* buf /* device, 4096 B: cycle timeline written by mode 2 + (6 << 8) */);
 
 /* Diagnostics only: ablation variants of the fused kernel for timing (1 no sin, 2 no LUT gather, 3 no shaper tail,
- * 4 no MFMA; 0 = product kernel).  Outputs of variants != 0 are meaningless. */
+ * 4 no MFMA; 0 = product kernel; 5 / 6 prologue only; 10 + OPT bits: compile-time options of the two-hop kernel - 44 the product
+ * kernel, 108 the same with the FiLM rows as fragment records by LDS-DMA).  Outputs of variants 1-6 are meaningless. */
 int nws_debug_exciter_newt(int variant, const NwsWeights* w, const float* f0, const double* carry, const float* phase_u,
                            const float* rand_phase, const float* film, int B, int T, float sample_rate,
                            float* newt_out, void* stream);
+
+/* Diagnostics only (tools/film_dma_ab.py; round 6, measured as nothing: profiles/r06/film_dma_ab.txt): per-frame FiLM fragment records
+ * for variants 6 (prologue only) and 108 (whole kernel) of nws_debug_exciter_newt, which take them in place of `film` and bring them
+ * to LDS by LDS-DMA instead of splitting the fp32 rows in the kernel.  film (B, T, 256) frame-major rows [g_idx | b_idx | g_norm |
+ * b_norm] -> frags_out = B T records of NWS_FILM_REC_BYTES (3 parameter types x 64 shapers x {bf16 t0, t1, t2, 0}: the value in
+ * table units / times newt.mixer.weight as three bf16 terms, exact for any fp32) followed by B T aux entries of 16 bytes
+ * {sum_s newt.mixer.weight[s] b_norm[s], 0, 64-bit range-proof mask}. */
+int nws_debug_film_frags(const NwsWeights* w, const float* film, int B, int T, void* frags_out /* device, B T (NWS_FILM_REC_BYTES + 16) bytes */,
+                         void* stream);
 
 /* Diagnostics only: timing ablations of control_gru_kernel (0 product; 1 half the LDS reads of h, 2 half the FMAs, 3 no
  * transcendentals in the gates, 4 no per-step barrier, 5 no LDS reads of h).  Outputs of variants != 0 are meaningless. */

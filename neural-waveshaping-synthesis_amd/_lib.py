@@ -127,6 +127,7 @@ _PROTOTYPES = {
     "nws_shaper_table": (C.c_int, [C.POINTER(NwsWeights), C.c_int, C.c_float, C.c_float, _fp, _fp]),
     "nws_mixer_frags": (C.c_int, [_fp, _fp, _fp, _fp]),
     "nws_exciter_bound": (C.c_int, [_fp, _fp, _fp, _fp]),
+    "nws_debug_film_frags": (C.c_int, [C.POINTER(NwsWeights), _fp, C.c_int, C.c_int, _fp, _fp]),
     "nws_shaper_turns": (C.c_int, [_fp, _fp, _fp]),
     "nws_lut_pairs": (C.c_int, [_fp, C.c_int, _fp, _fp]),
     "nws_shaper_apply": (C.c_int, [C.POINTER(NwsWeights), _fp, C.c_int64, C.c_int64, _fp, _fp]),

@@ -43,9 +43,16 @@ enum Opt {
   kOptOneTerm = 4,      // sines as ONE fp16 term in EVERY K-step (drops W_hi * v_lo: 2 MFMAs per product; 11-bit activations)
   kOptHybrid = 8,       // two-term sines in K-step 0 (mixer bias + harmonics 1..15), one term in K-steps 1..6
   kOptHybridW = 16,     // with kOptHybrid: the mixer WEIGHTS of harmonics 16..101 as one fp16 term too (1 MFMA per product)
-  kOptLowReg = 32       // with kOptFilmMfma: the tail keeps at most two FiLM tiles live (80 VGPRs: three 8-wave workgroups per CU)
+  kOptLowReg = 32,      // with kOptFilmMfma: the tail keeps at most two FiLM tiles live (80 VGPRs: three 8-wave workgroups per CU)
+  // with kOptFilmMfma | kOptLowReg, two hops per workgroup: the FiLM rows arrive as per-FRAME bf16x3 fragment records
+  // (NWS_FILM_REC_BYTES per frame, film_frag_record below) and go to LDS by the LDS-DMA path - no staging arithmetic in this
+  // kernel.  Round 6, VERDICT r5 #3: built, 3.6e-9 RMS from the product kernel, and MEASURED AS NOTHING - prologue-only launch
+  // 35.8 -> 34.4 us, whole kernel 257.4 -> 255.0 us (profiles/r06/film_dma_ab.txt): the prologue-only launch is the 448 MB of
+  // mixer-fragment table that 16 000 workgroups pull from L2 (13 TB/s), not the staging arithmetic.  Not on the product path
+  // (the records would cost the frame-MLP kernel 17 MB more per step); kept behind nws_debug_exciter_newt variants 6 / 108.
+  kOptFilmDma = 64
 };
-static_assert((kOptFilmMfma ^ kOptOneTerm ^ kOptHybrid ^ kOptHybridW ^ kOptLowReg) == 62, "Opt bits must be distinct");
+static_assert((kOptFilmMfma ^ kOptOneTerm ^ kOptHybrid ^ kOptHybridW ^ kOptLowReg ^ kOptFilmDma) == 126, "Opt bits must be distinct");
 enum Mode { kModeLut = 0, kModeExact = 1, kModeExciterOnly = 2, kModeLutPairs = 3, kModeLutPairsDiv6 = 4, kModeExactBank = 5,
             kModeExactBankNF = 6 };   // NF: no v_fract in front of the sines of the hidden and output layers (NWS_EXCITER_BANK_NOFRACT)
 __host__ __device__ constexpr bool is_bank(int mode) { return mode == kModeExactBank || mode == kModeExactBankNF; }
@@ -380,6 +387,22 @@ __device__ __forceinline__ LutParams make_lut_params(const NwsWeights& w) {
   return P;
 }
 
+// Per-frame FiLM fragment record (kOptFilmDma): for type ty in {0 index gain, 1 index bias, 2 output gain} and shaper s, 8 bytes
+// at (ty * 64 + s) * 8 = the value as THREE bf16 terms by truncation {t0, t1, t2, 0} (8 + 8 + 8 bits: exact for any fp32),
+//   ty 0: (size / 6) g_idx        ty 1: (size / 6) (b_idx - lut_min)        ty 2: newt.mixer.weight[s] g_norm
+// (the table-unit scaling and the folded 64 -> 1 mixer weight of the staging code above).  As the A operand of
+// v_mfma_f32_32x32x16_bf16, lane (shaper i, half h) holds the record of frame f + h in K slots 8 h + 0..3 (slots 8 h + 4..7 zero);
+// against B = {1 - w, 1 - w, 1 - w, 0, ...} in half 0 and {w, w, w, 0, ...} in half 1 (w = interpolation weight, a multiple of
+// 1 / 256 below 1: w and 1 - w are exact in bf16) the instruction returns (1 - w) p[f] + w p[f + 1]: F.upsample's own formula
+// (neural_waveshaping.py:75 semantics, shaping.py:69) for 32 shapers x 32 samples, from records that know nothing of their
+// neighbours - which is what would let the frame-MLP kernel write them.  Beside the records, 16 bytes per frame (film_frag_aux):
+// { sum_s newt.mixer.weight[s] b_norm[s] (float), 0, range-proof mask (64 bits: shaper s cannot leave the table at this frame) }.
+struct FilmAux {
+  float bsum, pad;
+  unsigned long long mask;
+};
+static_assert(sizeof(FilmAux) == 16, "FilmAux");
+
 // Mixer weights as two fp16 terms, W = W_hi + W_lo (22+ significant bits), in MFMA A-fragment order:
 // fragment (ks, m, h, i) = 8 halfs = W[32m + i][16ks + 8h .. +7]; lane (i, h) reads it with one ds_read_b128.
 struct ExcLds {
@@ -399,8 +422,11 @@ struct ExcLds {
     // fp32, fp32 exponent range), against the B operand {1, 1, 1, w, w, w, 0, 0} (w = interpolation weight, a multiple of
     // 1/256: exact in bf16) one v_mfma_f32_32x32x16_bf16 returns a + w d for 32 shapers x 32 samples.
     uint4 ffrag[3][3][2][32];
+    // kOptFilmDma: the fragment records of the workgroup's four frames (jb-1 .. jb+2, clamped), as they lie in memory
+    unsigned char frec[4][NWS_FILM_REC_BYTES];
   };
   float bsum[4];
+  unsigned long long fmask[4];   // kOptFilmDma: per-FRAME range-proof masks (a frame pair is proven where both frames are)
   // bit s of okmask[slot]: the table index of shaper s provably stays inside the table for every sample that interpolates
   // between the slot's two frames (staging, from NwsWeights.exciter_bound); 0 = unknown -> the clamped lookup
   unsigned long long okmask[3];
@@ -463,6 +489,43 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   v += dpp_f32<0x142, 0xa>(v);  // row_bcast15 -> rows 1 and 3
   v += dpp_f32<0x143, 0xc>(v);  // row_bcast31 -> rows 2 and 3
   return v;
+}
+
+__device__ __forceinline__ uint2 bf16x3(float v) {
+  auto top16 = [](float x) { return __builtin_bit_cast(unsigned, x) & 0xffff0000u; };
+  const unsigned t0 = top16(v);
+  const float r = v - __builtin_bit_cast(float, t0);
+  const unsigned t1 = top16(r);
+  const unsigned t2 = top16(r - __builtin_bit_cast(float, t1));
+  return uint2{(t0 >> 16) | t1, t2 >> 16};
+}
+
+// the record and aux entry of one frame from its fp32 FiLM row [g_idx | b_idx | g_norm | b_norm] (lane = shaper)
+__device__ __forceinline__ void film_frag_record(const NwsWeights& w, const float* __restrict__ row, int lane, unsigned char* __restrict__ rec,
+                                                 FilmAux* __restrict__ aux) {
+  const float c = (float)w.lut_size * (1.0f / 6.0f);
+  const float ow = w.newt_out_w[lane];
+  const float ga = row[lane] * c, ba = (row[kS + lane] - w.lut_min) * c, gn = ow * row[2 * kS + lane];
+  uint2* out = reinterpret_cast<uint2*>(rec);
+  out[lane] = bf16x3(ga);
+  out[kS + lane] = bf16x3(ba);
+  out[2 * kS + lane] = bf16x3(gn);
+  const float bs = wave_sum_to_lane63(ow * row[3 * kS + lane]);
+  // range proof at this frame (shaping.py:136-151 clamps `lower` into the table; inside it the clamp is the identity): idx = G x + B
+  // with |x| <= X[s]; one table cell of margin plus 2^-9 |G| X for every rounding between here and the lookup.  Between two
+  // frames idx is the convex combination of the frames' values for the same x, and so is the margin: a pair is proven where both
+  // frames are.  NaN-safe by construction: every comparison with a NaN operand is false (no fmin / fmax in the chain).
+  const float X = w.exciter_bound != nullptr ? w.exciter_bound[lane] : __builtin_inff();
+  const float r = fabsf(ga) * X;
+  const float e = 1.0f + r * (1.0f / 512.0f);
+  const unsigned long long m = __ballot((ba - r) >= e && (ba + r) <= (float)(w.lut_size - 1) - e);
+  if (lane == 63) *aux = FilmAux{bs, 0.0f, m};
+}
+
+__global__ __launch_bounds__(64) void film_frags_kernel(NwsWeights w, const float* __restrict__ film, unsigned char* __restrict__ recs,
+                                                        FilmAux* __restrict__ aux) {
+  const size_t f = blockIdx.x;
+  film_frag_record(w, film + f * NWS_FILM_CH, threadIdx.x, recs + f * NWS_FILM_REC_BYTES, aux + f);
 }
 
 // (Round 4, measured and dropped: mask-and-subtract instead - hi = bits & 0xFFFFE000, lo = v - hi, two v_cvt_pk - is two
@@ -528,7 +591,7 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
                                                            float* __restrict__ newt_out,
                                                            const float* __restrict__ bank = nullptr,
                                                            const float* __restrict__ add_in = nullptr,
-                                                           const int xcd_groups = 0) {
+                                                           const int xcd_groups = 0, const int xcd_aux = 0 /* kOptFilmDma: B T */) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   ExcLds& L = *reinterpret_cast<ExcLds*>(smem_raw);
   ShaperLds& SH = *reinterpret_cast<ShaperLds*>(smem_raw + ((sizeof(ExcLds) + 15) & ~size_t(15)));
@@ -617,6 +680,32 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
   // FiLM slots (one shaper per lane), bias sums, phase shifts and harmonic numbers, spread over the waves:
   //   4 waves: 0/1 slots 0/1, 2 bsum[0..1], 3 bsum[2] + shifts;   8 waves: 0..2 slots, 3..6 bsum[0..3], 7 shifts
   constexpr int kSlots = HPB + 1;
+  constexpr bool kFilmDma = (OPT & kOptFilmDma) != 0;
+  static_assert(!kFilmDma || (HPB == 2 && (OPT & kOptFilmMfma) && (OPT & kOptLowReg) && MODE == kModeLutPairsDiv6),
+                "kOptFilmDma: the default two-hop LUT kernel only");
+  if (kFilmDma) {
+    // the four frames' fragment records (`bank` carries their base here: records of all B T frames, then the aux entries): 6 KB =
+    // six 1 KB pieces, one per wave 0..5, straight to LDS.  A piece straddles records, and clamped frames at the utterance's
+    // ends break the contiguity: every lane finds its own 16 source bytes
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const unsigned char* recs = reinterpret_cast<const unsigned char*>(bank) + (size_t)b * T * NWS_FILM_REC_BYTES;
+    auto frame_of = [&](int q) {
+      const int f = jb - 1 + q;
+      return f < 0 ? 0 : (f > T - 1 ? T - 1 : f);
+    };
+    if (wave < 6) {
+      const int o = wave * 1024 + lane * 16;
+      const int q = (o >= NWS_FILM_REC_BYTES) + (o >= 2 * NWS_FILM_REC_BYTES) + (o >= 3 * NWS_FILM_REC_BYTES);
+      const unsigned char* src = recs + (size_t)frame_of(q) * NWS_FILM_REC_BYTES + (o - q * NWS_FILM_REC_BYTES);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&L.frec[0][0] + wave * 1024), 16, 0, 0);
+    } else if (wave == 6 && lane < 4) {
+      const FilmAux* aux = reinterpret_cast<const FilmAux*>(reinterpret_cast<const unsigned char*>(bank) + (size_t)xcd_aux * NWS_FILM_REC_BYTES);
+      const FilmAux a = aux[(size_t)b * T + frame_of(lane)];
+      L.bsum[lane] = a.bsum;
+      L.fmask[lane] = a.mask;
+    }
+  } else
   if (MODE != kModeExciterOnly) {
     const float* fb = film + (size_t)b * T * NWS_FILM_CH;
     auto frame_of = [&](int q) {
@@ -671,13 +760,15 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
           // is the identity).  idx = G x + B with G, B linear in the interpolation weight between the slot's two frames and
           // |x| <= X[s] whatever the oscillator does, so idx lies between the extremes taken at the two frames:
           // B_f -+ |G_f| X.  One table cell of margin on either side plus 2^-9 of |G| X covers every rounding between here and
-          // the tail (the three-term FiLM interpolation, the 22-bit - or, opted in, 11-bit - mixer products).  NaNs compare
-          // false: not proven.
+          // the tail (the three-term FiLM interpolation, the 22-bit - or, opted in, 11-bit - mixer products).  A NaN anywhere
+          // must end as "not proven": fminf / fmaxf DROP a NaN operand (a NaN gain or bias of the right frame alone would vanish
+          // from lo / hi), hence the explicit self-comparisons - a FiLM frame with a NaN always takes the clamped form.
           const float X = w.exciter_bound != nullptr ? w.exciter_bound[lane] : __builtin_inff();
           const float r_a = fabsf(ga) * X, r_b = fabsf(ga + gd) * X;
           const float e = 1.0f + fmaxf(r_a, r_b) * (1.0f / 512.0f);
           const float lo = fminf(ba - r_a, (ba + bd) - r_b), hi = fmaxf(ba + r_a, (ba + bd) + r_b);
-          const unsigned long long okm = __ballot(lo >= e && hi <= (float)(w.lut_size - 1) - e);
+          const float right = (ba + bd) + r_b;     // NaN iff the right frame's gain, bias or bound is
+          const unsigned long long okm = __ballot(lo >= e && hi <= (float)(w.lut_size - 1) - e && r_a == r_a && right == right);
           if (lane == 0) L.okmask[wave] = okm;
         }
       } else
@@ -968,15 +1059,31 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
     // accumulator layout of the exciter tile itself, so G[r], Bb[r], Gn[r] pair up with acc[r] register for register.
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     const unsigned w1b = __builtin_bit_cast(unsigned, lc.w1);   // a multiple of 1/256 in [0, 1): exact in bf16
-    const uint4 bop = half == 0 ? uint4{0x3f803f80u, 0x3f80u | (w1b & 0xffff0000u), (w1b >> 16) | (w1b & 0xffff0000u), 0u}
-                                : uint4{0u, 0u, 0u, 0u};       // K slots 8..15 unused: zero B, whatever A holds there
+    uint4 bop;
+    if (kFilmDma) {
+      // half 0 weighs the left frame's three terms with 1 - w, half 1 the right frame's with w (K slots 8 h + 0..2); 1 - w is
+      // a multiple of 1/256 in (0, 1] like w: exact in bf16
+      const unsigned wb = (half == 0 ? __builtin_bit_cast(unsigned, 1.0f - lc.w1) : w1b) >> 16;
+      bop = uint4{wb | (wb << 16), wb, 0u, 0u};
+    } else {
+      bop = half == 0 ? uint4{0x3f803f80u, 0x3f80u | (w1b & 0xffff0000u), (w1b >> 16) | (w1b & 0xffff0000u), 0u}
+                      : uint4{0u, 0u, 0u, 0u};       // K slots 8..15 unused: zero B, whatever A holds there
+    }
     const bf16x8 bfrag = __builtin_bit_cast(bf16x8, bop);
+    // A fragment of parameter type ty, M-tile m
+    auto ffrag_of = [&](const int ty, const int m) -> bf16x8 {
+      if (kFilmDma) {
+        const uint2 v = *reinterpret_cast<const uint2*>(&L.frec[0][0] + (q0 + half) * NWS_FILM_REC_BYTES + ((ty * 2 + m) * 32 + col) * 8);
+        return __builtin_bit_cast(bf16x8, uint4{v.x, v.y, 0u, 0u});
+      }
+      return __builtin_bit_cast(bf16x8, L.ffrag[q0][ty][m][col]);
+    };
     float part = 0.0f;
     unsigned ok_tile[2] = {0u, 0u};   // bit k of ok_tile[m]: shaper 32 m + k proven in range for this wave's samples
     if (OPT & kOptLowReg) {
       const int q0u = __builtin_amdgcn_readfirstlane(q0);
       if (__all(q0 == q0u)) {           // (a wave's 32 samples share their frame pair; anything else takes the clamped form)
-        const unsigned long long okm = L.okmask[q0u];
+        const unsigned long long okm = kFilmDma ? (L.fmask[q0u] & L.fmask[q0u + 1]) : L.okmask[q0u];
         ok_tile[0] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)okm);
         ok_tile[1] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(okm >> 32));
       }
@@ -1022,13 +1129,13 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
         constexpr int m = decltype(m_tag)::value;
         f32x16& acc = m == 0 ? acc0 : acc1;
         {
-          const f32x16 G = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, L.ffrag[q0][0][m][col]), bfrag, f32x16{}, 0, 0, 0);
-          const f32x16 Bb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, L.ffrag[q0][1][m][col]), bfrag, f32x16{}, 0, 0, 0);
+          const f32x16 G = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ffrag_of(0, m), bfrag, f32x16{}, 0, 0, 0);
+          const f32x16 Bb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ffrag_of(1, m), bfrag, f32x16{}, 0, 0, 0);
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] = fmaf(G[r], acc[r], Bb[r]);   // FiLM in table units (bias and origin folded at staging)
         }
         __builtin_amdgcn_sched_barrier(0);
-        const f32x16 Gn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, L.ffrag[q0][2][m][col]), bfrag, f32x16{}, 0, 0, 0);
+        const f32x16 Gn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ffrag_of(2, m), bfrag, f32x16{}, 0, 0, 0);
         // the tile's sixteen lookups per lane in one of two forms, chosen by ONE wave-uniform branch
         if (ok_tile[m] == 0xffffffffu) lookups(m_tag, std::true_type{}, acc, Gn);
         else lookups(m_tag, std::false_type{}, acc, Gn);
@@ -1434,6 +1541,16 @@ int nws_mixer_frags(const float* mixer_w, const float* mixer_b, void* frags_out,
   return NWS_OK;
 }
 
+int nws_debug_film_frags(const NwsWeights* w, const float* film, int B, int T, void* frags_out, void* stream) {
+  if (!w || !film || !frags_out || B <= 0 || T <= 0 || !w->newt_out_w || w->lut_size < 2) return NWS_ERR_BAD_ARG;
+  const size_t frames = (size_t)B * T;
+  if (frames >= (1ull << 31)) return NWS_ERR_UNSUPPORTED;
+  unsigned char* recs = static_cast<unsigned char*>(frags_out);
+  film_frags_kernel<<<(unsigned)frames, 64, 0, (hipStream_t)stream>>>(*w, film, recs, reinterpret_cast<FilmAux*>(recs + frames * NWS_FILM_REC_BYTES));
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
 int nws_exciter_bound(const float* mixer_w, const float* mixer_b, float* bound_out, void* stream) {
   if (!mixer_w || !mixer_b || !bound_out) return NWS_ERR_BAD_ARG;
   exciter_bound_kernel<<<kS, 64, 0, (hipStream_t)stream>>>(mixer_w, mixer_b, bound_out);
@@ -1573,8 +1690,14 @@ int nws_debug_exciter_newt(int variant, const NwsWeights* w, const float* f0, co
   exciter_newt_kernel<kModeLutPairsDiv6, 0, 2, O><<<dim3((T + 1) / 2, B), 512, base, st>>>(*w, f0, nullptr, carry, phase_u, \
                                                             rand_phase, film, T, sample_rate, nullptr, newt_out)
   if (variant == 5) {   // prologue only, product configuration
-    exciter_newt_kernel<kModeLutPairsDiv6, 5, 2, kOptFilmMfma | kOptHybrid | kOptHybridW><<<dim3((T + 1) / 2, B), 512, base, st>>>(
+    exciter_newt_kernel<kModeLutPairsDiv6, 5, 2, kOptFilmMfma | kOptLowReg><<<dim3((T + 1) / 2, B), 512, base, st>>>(
         *w, f0, nullptr, carry, phase_u, rand_phase, film, T, sample_rate, nullptr, newt_out);
+    NWS_CHECK_LAUNCH();
+    return NWS_OK;
+  }
+  if (variant == 6) {   // prologue only, fragment records by LDS-DMA (`film` = the records + aux entries of nws_debug_film_frags here)
+    exciter_newt_kernel<kModeLutPairsDiv6, 5, 2, kOptFilmMfma | kOptLowReg | kOptFilmDma><<<dim3((T + 1) / 2, B), 512, base, st>>>(
+        *w, f0, nullptr, carry, phase_u, rand_phase, film, T, sample_rate, nullptr, newt_out, film, nullptr, 0, B * T);
     NWS_CHECK_LAUNCH();
     return NWS_OK;
   }
@@ -1585,6 +1708,10 @@ int nws_debug_exciter_newt(int variant, const NwsWeights* w, const float* f0, co
       case 26: NWS_OPT_LAUNCH(26); break;
       case 34: NWS_OPT_LAUNCH(34); break;   // kOptFilmMfma | kOptLowReg: the default kernel
       case 58: NWS_OPT_LAUNCH(58); break;   // ... | kOptHybrid | kOptHybridW | kOptLowReg: the opt-in hybrid-W kernel
+      case 98:                              // kOptFilmMfma | kOptLowReg | kOptFilmDma (`film` = records + aux entries of nws_debug_film_frags)
+        exciter_newt_kernel<kModeLutPairsDiv6, 0, 2, 98><<<dim3((T + 1) / 2, B), 512, base, st>>>(
+            *w, f0, nullptr, carry, phase_u, rand_phase, film, T, sample_rate, nullptr, newt_out, film, nullptr, 0, B * T);
+        break;
       default: return NWS_ERR_BAD_ARG;
     }
     NWS_CHECK_LAUNCH();

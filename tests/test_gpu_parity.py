@@ -1378,3 +1378,34 @@ def test_range_proven_lookups_equal_the_clamped_form_bit_for_bit(inst, monkeypat
         clamped = [m(f0, c, phase_u=pu, noise=nz).clone() for f0, c in cases]
     for a, b in zip(proven, clamped):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_film_rows_as_fragment_records_by_lds_dma_equal_the_product_kernel():
+    """Round 6 experiment kept alive (kOptFilmDma, profiles/r06/film_dma_ab.txt: measured as nothing, not on the product path): the
+    oscillator kernel fed per-frame bf16x3 fragment records by LDS-DMA, F.upsample as (1 - w) p[f] + w p[f + 1] on the matrix pipe,
+    per-frame range-proof masks - against the product kernel on the same inputs (odd T: a dead second hop; both utterance edges)."""
+    import ctypes as C
+    import nws_amd as nws
+    _lib = nws._lib
+    m = build_model(True)
+    eng = m._engine
+    w, _, _ = eng.weights()
+    for B, T in ((3, 37), (2, 500)):
+        g = torch.Generator(device="cuda").manual_seed(B)
+        f0 = (80 + 900 * torch.rand(B, T, device="cuda", generator=g)).contiguous()
+        control = torch.randn(B, 2, T, device="cuda", generator=g)
+        carry = eng.phase_carry(f0=f0)
+        _, film, _, _ = eng.frame_mlps(eng.control_gru(control))
+        pu = torch.rand(101, device="cuda", generator=g)
+        frags = torch.empty(B * T * (1536 + 16), dtype=torch.uint8, device="cuda")
+        _lib.check(_lib.lib().nws_debug_film_frags(C.byref(w), film.data_ptr(), B, T, frags.data_ptr(), _lib.stream_ptr()))
+        outs = {}
+        for v, src in ((44, film), (108, frags)):
+            outs[v] = torch.zeros(B, 128 * T, device="cuda")
+            _lib.check(_lib.lib().nws_debug_exciter_newt(v, C.byref(w), f0.data_ptr(), carry.data_ptr(), pu.data_ptr(), eng.rand_phase().data_ptr(),
+                                                         src.data_ptr(), B, T, 16000.0, outs[v].data_ptr(), _lib.stream_ptr()))
+        _, ref = eng.exciter_newt(f0, None, carry, pu, film)
+        assert torch.equal(outs[44], ref)                       # variant 44 IS the product kernel
+        d = float((outs[108] - ref).abs().max())
+        record(f"film_dma_variant_B{B}_T{T}", maxabs=d, signal_rms=float(ref.pow(2).mean().sqrt()))
+        assert d <= 2e-7, d
