@@ -197,7 +197,7 @@ def cpu_baseline(weights_path, T, budget_s):
 
 def load_pmc():
     """Per-kernel counters of the round's committed rocprofv3 --pmc passes (tools/collect_profiles.sh + tools/pmc_digest.py)."""
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd, "pmc_kernels.json")
         if os.path.exists(path):
             try:

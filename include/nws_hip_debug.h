@@ -13,7 +13,9 @@ extern "C" {
 #endif
 
 /* Measurements / tests: which frame-MLP kernel nws_frame_mlps launches - 0 automatic (wave-resident frames from 8192 frames up,
- * tile kernels below; env NWS_MLP_KERNEL=tiles|frames), 1 the tile kernels, 2 wave-resident frames at any size. */
+ * tile kernels below; env NWS_MLP_KERNEL=tiles|frames), 1 the tile kernels, 2 wave-resident frames at any size.  mode 2 + (A << 8):
+ * timing ablation A of the wave-resident kernel (1 no LayerNorm, 2 no MFMAs, 3 no weight reads, 5 no split, 6 cycle timeline,
+ * 7 / 8 only the newt.mlp / only the h_generator workgroups); outputs of ablations are meaningless or partial. */
 int nws_debug_frame_mlps_kernel(int mode);
 int nws_debug_frame_mlps_probe(void* buf /* device, 4096 B: cycle timeline written by mode 2 + (6 << 8) */);
 

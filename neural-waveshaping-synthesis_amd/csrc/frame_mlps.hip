@@ -997,7 +997,7 @@ template <bool TAPS, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void frame_mlps_wr_kernel(NwsWeights w, const float* __restrict__ gru_out, int F, int T,
                                                                  float* __restrict__ emb_out, float* __restrict__ film_out,
                                                                  float* __restrict__ H_out, float* __restrict__ fir_out,
-                                                                 const int xcd_blocks = 0) {
+                                                                 const int xcd_blocks = 0, const int only_path = -1) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   WrLds& L = *reinterpret_cast<WrLds*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1009,6 +1009,7 @@ __global__ __launch_bounds__(512, 2) void frame_mlps_wr_kernel(NwsWeights w, con
   const int fb = xcd_blocks > 0 ? (int)(blockIdx.x >> 4) * 8 + (int)(blockIdx.x & 7) : (int)blockIdx.x;
   const int path = xcd_blocks > 0 ? (int)((blockIdx.x >> 3) & 1) : (int)blockIdx.y;   // 0: proj + newt.mlp -> film; 1: proj + h_generator -> H -> fir
   if (xcd_blocks > 0 && fb >= xcd_blocks) return;
+  if (only_path >= 0 && path != only_path) return;   // measurements (tools/mlp_paths_ab.py): one path's workgroups alone
   const int half = lane >> 5, col = lane & 31;
   const int f0 = fb * kWrFrames + 32 * wave;         // first frame of this wave
   const int frame = f0 + col;                        // this lane's frame (standard orientation)
@@ -1360,6 +1361,8 @@ int nws_frame_mlps(const NwsWeights* w, const float* gru_out, const float* fir_d
       auto fn = abl == 1 ? frame_mlps_wr_kernel<false, 1> : abl == 2 ? frame_mlps_wr_kernel<false, 2> : abl == 3 ? frame_mlps_wr_kernel<false, 3> : frame_mlps_wr_kernel<false, 5>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WrLds));
       fn<<<gridw, 512, sizeof(WrLds), (hipStream_t)stream>>>(*w, gru_out, (int)F, T, nullptr, film_out, nullptr, fir_out, xcd_blocks);
+    } else if (abl == 7 || abl == 8) {   // one path's workgroups alone (the other path's outputs are not written)
+      frame_mlps_wr_kernel<false><<<gridw, 512, sizeof(WrLds), (hipStream_t)stream>>>(*w, gru_out, (int)F, T, nullptr, film_out, nullptr, fir_out, xcd_blocks, abl - 7);
     } else if (!emb_out && !H_out)
       frame_mlps_wr_kernel<false><<<gridw, 512, sizeof(WrLds), (hipStream_t)stream>>>(*w, gru_out, (int)F, T, nullptr, film_out, nullptr, fir_out, xcd_blocks);
     else

@@ -26,10 +26,17 @@ for b in 1 16; do
 done
 # round 4: the reverb at every length, the two frame-MLP kernel families (+ ablations, cycle timeline), the runtime-size path
 python tools/reverb_lengths.py > gpurun_out/ev/reverb_lengths.txt 2>&1
-MODES=1,2,258,514,770,1282 python tools/mlp_variants.py 64 500 48 500 32 500 128 500 > gpurun_out/ev/mlp_variants.txt 2>&1
+MODES=1,2 python tools/mlp_variants.py 64 500 48 500 32 500 128 500 > gpurun_out/ev/mlp_variants.txt 2>&1
 python tools/mlp_timeline.py > gpurun_out/ev/mlp_timeline.txt 2>&1
 python tools/generic_profile.py > gpurun_out/ev/generic_path.txt 2>&1
 bash tools/generic_kernels.sh 64 500 > gpurun_out/ev/generic_kernels.txt 2>&1
-bash tools/collect_profiles.sh ${ROUND:-r05} > gpurun_out/ev/collect.log 2>&1
-ls gpurun_out/prof_${ROUND:-r05} | head -30
+# round 6: queue placement by measurement, the 8-rank queue population on one GPU, CU pressure, the two measured-as-nothing kernel items
+python tools/queue_pipe_map.py --layout nnnnhhhh --repeat 2 > gpurun_out/ev/queue_pipe_map_final.txt 2>&1
+bash tools/placement_ab.sh > /dev/null 2>&1; cp gpurun_out/placement_ab.txt gpurun_out/ev/placement_ab.txt
+bash tools/fake_peers_ab.sh > /dev/null 2>&1; cp gpurun_out/fake_peers_ab.txt gpurun_out/ev/fake_peers_ab.txt
+python tools/cu_pressure.py > gpurun_out/ev/cu_pressure.txt 2>&1
+python tools/film_dma_ab.py > gpurun_out/ev/film_dma_ab.txt 2>&1
+python tools/mlp_paths_ab.py > gpurun_out/ev/mlp_paths_ab.txt 2>&1
+bash tools/collect_profiles.sh ${ROUND:-r06} > gpurun_out/ev/collect.log 2>&1
+ls gpurun_out/prof_${ROUND:-r06} | head -30
 du -sh gpurun_out

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy what tools/evidence_run.sh left under gpurun_out/ (merged back from the GPU box) into profiles/<round>/ (tracked).
-R=${1:-r05}
+R=${1:-r06}
 D=profiles/$R
 mkdir -p "$D"
 for f in bench_default bench_hybrid_w_optin bench_realistic_inputs bench_exact_shapers bench_world1_rccl bench_world1_copy bench_driver_k20; do
@@ -15,6 +15,6 @@ grep -E "passed|failed" gpurun_out/ev/pytest_gpu.txt | tail -1 > "$D/pytest_gpu_
 cat gpurun_out/ev/buffer_fast.txt gpurun_out/ev/buffer_exact.txt gpurun_out/ev/streaming_stateful.txt > "$D/buffer_sizes_summary.txt"
 cp gpurun_out/ev/streaming.jsonl "$D/streaming_stateful.jsonl"
 python tools/buffer_sizes_digest.py gpurun_out/ev/buffer_fast.txt gpurun_out/ev/buffer_exact.txt > "$D/buffer_sizes.csv"
-for f in reverb_lengths mlp_variants mlp_timeline generic_path generic_kernels world1_ab scale_check_dry_run range_proven_ab; do
+for f in reverb_lengths mlp_variants mlp_timeline generic_path generic_kernels world1_ab scale_check_dry_run range_proven_ab queue_pipe_map_final placement_ab fake_peers_ab cu_pressure; do
   [ -f gpurun_out/ev/$f.txt ] && grep -v "amdgpu.ids" gpurun_out/ev/$f.txt > "$D/$f.txt"
 done
