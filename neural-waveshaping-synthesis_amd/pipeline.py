@@ -61,7 +61,7 @@ class _Placement:
     __slots__ = ("exchange", "audio", "control", "spare", "report", "audio_anchors", "side")
 
 
-def queue_probe(hold, touch, scratch, groups: int = 8192, spin_us: int = 10) -> float:
+def queue_probe(hold, touch, scratch, groups: int = 16384, spin_us: int = 10) -> float:
     """nws_queue_probe (include/nws_hip.h): where the wall-clock stamp of ONE wave on `touch` falls inside the dispatch window of
     a grid that `hold`'s hardware queue is busy handing out - ~0: served meanwhile; >= _BLOCKED: it waited (same pipe)."""
     import ctypes as C
@@ -69,6 +69,16 @@ def queue_probe(hold, touch, scratch, groups: int = 8192, spin_us: int = 10) -> 
     _lib.check(_lib.lib().nws_queue_probe(hold.cuda_stream, touch.cuda_stream, groups, spin_us, scratch.data_ptr(), C.byref(frac)),
                "nws_queue_probe")
     return float(frac.value)
+
+
+def _blocks(hold, touch, scratch, tries: int = 3) -> bool:
+    """Does `hold`'s queue, while its grid waits for slots, keep `touch`'s queue from being served?  A touch that got in early
+    is proof that it does not; a late one may also be the HOST's doing (the two launches of a probe a scheduling quantum apart:
+    the touch then arrives after the grid has gone) - so "blocked" needs `tries` late stamps in a row."""
+    for _ in range(tries):
+        if queue_probe(hold, touch, scratch) < _BLOCKED:
+            return False
+    return True
 
 
 def _first_use(st, touch):
@@ -140,7 +150,7 @@ def _place_by_measurement(dev, rep):
         for hi, h in enumerate(highs):
             for ni, n in [(-1, cur)] + list(enumerate(normals)):
                 if (hi, ni) not in blocked:
-                    blocked[(hi, ni)] = queue_probe(h, n, scratch) >= _BLOCKED
+                    blocked[(hi, ni)] = _blocks(h, n, scratch)
                     probes += 1
 
     def choose():
@@ -183,7 +193,7 @@ def _place_by_measurement(dev, rep):
     want = {(0, "cur"): True, (0, "x"): False, (0, "a0"): False, (0, "a1"): False,
             (1, "cur"): False, (1, "x"): True, (1, "a0"): False, (1, "a1"): False}
     named = {"cur": cur, "x": xs, "a0": audio[0], "a1": audio[1]}
-    seen = {k: queue_probe(control[k[0]], named[k[1]], scratch) >= _BLOCKED for k in want}
+    seen = {k: _blocks(control[k[0]], named[k[1]], scratch) for k in want}
     rep["probes"] = probes + len(want)
     rep["verified"] = seen == want
     # which normal candidate shares the submitting stream's class tells how many queues the process had created before (mod 4)
@@ -287,7 +297,7 @@ def side_streams(dev, n: int, max_candidates: int = 0):
             while len(pl.side) < n and rep["kept"] + rep["rejected"] < max_candidates:
                 st = torch.cuda.Stream(device=d)
                 _first_use(st, touch)
-                if any(queue_probe(h, st, scratch) >= _BLOCKED for h in pl.audio_anchors):
+                if any(_blocks(h, st, scratch) for h in pl.audio_anchors):
                     pl.spare.append(st)
                     rep["rejected"] += 1
                 else:
@@ -325,7 +335,7 @@ def verify_placement(dev=None):
         named = {"cur": cur, "x": pl.exchange, "a0": pl.audio[0], "a1": pl.audio[1]}
         want = {"c0 blocks cur": True, "c0 blocks x": False, "c0 blocks a0": False, "c0 blocks a1": False,
                 "c1 blocks cur": False, "c1 blocks x": True, "c1 blocks a0": False, "c1 blocks a1": False}
-        seen = {k: queue_probe(pl.control[int(k[1])], named[k.split()[-1]], scratch) >= _BLOCKED for k in want}
+        seen = {k: _blocks(pl.control[int(k[1])], named[k.split()[-1]], scratch) for k in want}
     return {"ok": seen == want, "seen": seen, "want": want}
 
 

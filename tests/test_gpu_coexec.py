@@ -129,7 +129,9 @@ def test_every_pipeline_of_a_process_runs_on_one_placed_stream_set():
     p4 = pm.ForwardPipeline(m, depth=3, streams=mine)                                        # private streams: the caller's business
     assert p4.audio[0] is mine[1][0] and p4.control[0] is mine[2][0] and p4.audio[0] is not p1.audio[0]
     rep = pm.placement_report("cuda")
-    assert rep["mode"] == "probe" and rep["ok"] and rep["verified"] and rep["queue_offset"] in (0, 1, 2, 3), rep
+    # (queue_offset is informational: None when no normal candidate shares the submitting stream's pipe - streams the earlier tests of
+    # this process created and dropped hand their hardware queues to later streams, so candidates need not arrive round-robin)
+    assert rep["mode"] == "probe" and rep["ok"] and rep["verified"] and rep["queue_offset"] in (None, 0, 1, 2, 3), rep
     # two pipelines sharing the streams (and a private one) still return the plain forward's bits
     g = torch.Generator(device="cuda").manual_seed(8)
     f0 = 100 + 600 * torch.rand(4, 1, 40, device="cuda", generator=g)
@@ -166,7 +168,9 @@ def test_placement_does_not_depend_on_the_process_history():
     for k, r in got.items():
         p = r["placement"]
         assert p["mode"] == "probe" and p["ok"] and p["verified"] and r["recheck"], (k, r)
-        assert p["queue_offset"] == r["pre"] % 4, (k, p)
+        # every used stream shifts the offset found by one (relative to the run without any: the hardware queues of OTHER
+        # processes - this pytest process - count towards the pipes too)
+        assert (p["queue_offset"] - got["pre0"]["placement"]["queue_offset"]) % 4 == r["pre"] % 4, (k, p, got["pre0"]["placement"])
     best = min(r["ms_per_step"] for r in got.values())
     bad = _placement_case(env={"NWS_STREAM_ORDER": "x,a0,a1,c0,d,c1"})
     record("placement_histories", ms_per_step={k: r["ms_per_step"] for k, r in got.items()}, misplaced_ms_per_step=bad["ms_per_step"])

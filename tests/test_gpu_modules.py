@@ -32,7 +32,7 @@ def test_backend_is_the_op_layer_unless_ctypes_was_asked_for():
     if os.environ.get("NWS_BACKEND") == "ctypes":
         assert o is None
     else:
-        assert o is torch.ops.newt_hip and int(o.abi_version()) == 5
+        assert o is torch.ops.newt_hip and int(o.abi_version()) == 6
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             o.sine(torch.zeros(4))
         with pytest.raises(RuntimeError, match="multiple of 128"):
