@@ -21,6 +21,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 DIAG = set(filter(None, os.environ.get("NWS_BENCH_DIAG", "").split(",")))
+if os.environ.get("NWS_PEER_PROF") == "1":
+    DIAG.add("peerprof")
 if "peerprof" in DIAG:
     os.environ["NWS_PEER_PROF"] = "1"
 
