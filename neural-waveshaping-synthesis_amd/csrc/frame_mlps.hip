@@ -1360,7 +1360,7 @@ int nws_frame_mlps(const NwsWeights* w, const float* gru_out, const float* fir_d
     } else if (abl == 1 || abl == 2 || abl == 3 || abl == 5) {
       auto fn = abl == 1 ? frame_mlps_wr_kernel<false, 1> : abl == 2 ? frame_mlps_wr_kernel<false, 2> : abl == 3 ? frame_mlps_wr_kernel<false, 3> : frame_mlps_wr_kernel<false, 5>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WrLds));
-      fn<<<gridw, 512, sizeof(WrLds), (hipStream_t)stream>>>(*w, gru_out, (int)F, T, nullptr, film_out, nullptr, fir_out, xcd_blocks);
+      fn<<<gridw, 512, sizeof(WrLds), (hipStream_t)stream>>>(*w, gru_out, (int)F, T, nullptr, film_out, nullptr, fir_out, xcd_blocks, -1);
     } else if (abl == 7 || abl == 8) {   // one path's workgroups alone (the other path's outputs are not written)
       frame_mlps_wr_kernel<false><<<gridw, 512, sizeof(WrLds), (hipStream_t)stream>>>(*w, gru_out, (int)F, T, nullptr, film_out, nullptr, fir_out, xcd_blocks, abl - 7);
     } else if (!emb_out && !H_out)
