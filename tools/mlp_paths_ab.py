@@ -2,9 +2,9 @@
 per frame block running both paths, proj computed once.)  Each path is a chain of six dependent phases (weight chunk -> MFMA burst ->
 LayerNorm / split); newt.mlp and h_generator of a frame block run on two DIFFERENT CUs at the same time (250 workgroups on 256 CUs,
 one 150 KB workgroup per CU).  Timed here, one stream, same box: both paths (the product), each path's workgroups alone (the other
-path's workgroups leave at once), and both at half / double the batch.  If the product takes about the LONGER of the two single-path
-launches, the paths overlap completely and a fused workgroup - eleven phases in a row on HALF the CUs - can only be slower: proj is one
-phase of six, the chain is what the kernel's time is.  -> profiles/r06/mlp_paths_ab.txt"""
+path's workgroups leave at once), and both at half / double the batch.  A fused workgroup is the single-path launch's workgroup count
+with eleven phases in a row instead of six: single-path time x 11 / 6 against the product's time says whether it could win.
+-> profiles/r06/mlp_paths_ab.txt"""
 import os
 import sys
 
