@@ -533,7 +533,7 @@ def main(hooks=None):
         rows, so a peer-copy slot is released at once)"""
         if peer is not None:
             peer.gather(y, i % nbuf)
-            peer.release(i % nbuf)
+            peer.release(i % nbuf, used=False)     # nothing reads the gathered rows here: no event to record (time-neutral, measured)
         else:
             par.gather_full(full[i % nbuf], y, async_op=False)        # sync op = launched on the current (exchange) stream
         return y          # kept alive by the exchange's ticket until the slot is acquired again (CompletionDrivenExchange docstring)

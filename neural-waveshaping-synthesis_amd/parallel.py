@@ -393,10 +393,11 @@ class PeerCopyAllGather:
             # per copy: every record is one more packet for the command processor), signal, and only then start this step's pushes
             self._complete_deferred(keep=0)
 
-    def release(self, slot: int):
+    def release(self, slot: int, used: bool = True):
         """The consumer is done with full[slot]: everything it enqueued on the current stream so far may still read it, anything
-        later must not."""
-        if self.device.type == "cuda":
+        later must not.  used=False: the consumer enqueued NOTHING that reads the slot (a benchmark loop that only times the exchange):
+        no event is recorded - every record is one more packet on the issuing queue."""
+        if self.device.type == "cuda" and used:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             self._released[slot] = ev

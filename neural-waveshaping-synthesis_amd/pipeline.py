@@ -427,6 +427,8 @@ class ForwardPipeline:
         cs = self.control[i % len(self.control)]
         au = self.audio[i % len(self.audio)]
         batched = bool(self.batched_gru)
+        # (measured, round 6: without this record + the two waits - inputs known to be resident - the step is the same, 0.3999 / 0.3983 /
+        # 0.3995 against 0.4002 / 0.3981 / 0.4048: the hand-over stays unconditional)
         ready = torch.cuda.current_stream(self.dev).record_event()
         with torch.cuda.stream(cs):
             cs.wait_event(ready)
