@@ -58,7 +58,7 @@ _BLOCKED = 0.30          # nws_queue_probe: touch stamps of queues served meanwh
 
 class _Placement:
     """The pipeline's streams on one device and how they were found (`report`: what bench.py prints as config.placement)."""
-    __slots__ = ("exchange", "audio", "control", "spare", "report", "audio_anchors", "side")
+    __slots__ = ("exchange", "audio", "control", "spare", "report", "audio_anchors", "side", "cur")
 
 
 def queue_probe(hold, touch, scratch, groups: int = 16384, spin_us: int = 10) -> float:
@@ -268,6 +268,7 @@ def placed_streams(dev, audio_streams: int = 2, control_streams: int = 2):
         pl.exchange, pl.audio, pl.control, pl.spare = got
         pl.audio_anchors = rep.pop("_audio_anchors", None)
         pl.side = []
+        pl.cur = torch.cuda.current_stream(d)         # the submitting stream the set was placed around
         rep["ms"] = round((time.perf_counter() - t0) * 1e3, 2)
         pl.report = rep
         _PLACED[key] = pl
@@ -330,9 +331,8 @@ def verify_placement(dev=None):
     pl = _PLACED[key]
     with torch.cuda.device(key):
         scratch = torch.zeros(4, dtype=torch.int64, device=d)
-        cur = torch.cuda.current_stream(d)
         torch.cuda.synchronize(d)
-        named = {"cur": cur, "x": pl.exchange, "a0": pl.audio[0], "a1": pl.audio[1]}
+        named = {"cur": pl.cur, "x": pl.exchange, "a0": pl.audio[0], "a1": pl.audio[1]}
         want = {"c0 blocks cur": True, "c0 blocks x": False, "c0 blocks a0": False, "c0 blocks a1": False,
                 "c1 blocks cur": False, "c1 blocks x": True, "c1 blocks a0": False, "c1 blocks a1": False}
         seen = {k: _blocks(pl.control[int(k[1])], named[k.split()[-1]], scratch) for k in want}
