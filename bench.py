@@ -95,9 +95,8 @@ def parse():
                     help="1: ForwardPipeline (control half = carries + GRU of batch i+1 on a side stream under the audio "
                          "half of batch i, --streams audio streams); 0: whole forwards round-robin on --streams streams")
     ap.add_argument("--control-streams", type=int, default=0,
-                    help="side streams for the control half; 0 = auto: two on one GPU (two recurrences in flight: 0.407 -> 0.401 "
-                         "ms/step for the timing-script inputs, 0.383 -> 0.349 for realistic ones, where the GRU is the longer "
-                         "half), one beside RCCL's own streams (two measured slower there: 0.62 vs 0.48 ms/step in round 1)")
+                    help="side streams for the control half; 0 = two (one control stream carries recurrence + its wait for compute units, "
+                         "~0.44 ms per batch, and bounds the step: 0.443-0.449 against 0.401-0.403 ms with two, round 6)")
     ap.add_argument("--chain-exciters", type=int, default=0,
                     help="1: the oscillator kernels of neighbouring batches (two audio streams) run one after the other, the other "
                          "kernels overlap them (ForwardPipeline chain_exciters; measured: no difference, 0.3919 vs 0.3932 ms/step)")

@@ -15,9 +15,11 @@ and their results are exactly those of `model(f0, control)`; only the issue orde
 Inputs must be valid in the submitting thread's current stream at submit() time (an event is recorded there and the
 internal streams wait for it).
 
-Control streams.  One is the default.  When the audio half is short (realistic F0: the oscillator skips the harmonics above
-Nyquist, 0.19 instead of 0.31 ms) the GRU of the next batch becomes the longer half and `control_streams=2` lets two of them
-overlap: 0.392 -> 0.364 ms per batch on one GPU; next to RCCL's own streams it was slower (0.45 vs 0.39), hence not the default.
+Control streams.  Two are the default (round 6; it used to be one).  The recurrence runs 0.22 ms and, beside an oscillator kernel,
+waits up to as long again for compute units to drain before all of its workgroups are placed: ONE control stream carries a chain of
+~0.44 ms per batch and becomes the bottleneck of a 0.40 ms step (measured on the placed queues: 0.443-0.449 ms per step with one control
+stream whichever pipe it sits on, 0.401-0.403 with two; realistic F0: 0.392 against 0.317).  With two, consecutive batches' control halves
+overlap.
 
 Audio streams.  `audio_streams=2` alternates the audio halves over two streams (another ~6 %: the tail of batch i - noise,
 reverb - overlaps the head of batch i+1).  That configuration exposed a hardware hazard on MI355X which the build now guards
@@ -347,7 +349,7 @@ class ForwardPipeline:
     pipelines, more than two streams of a kind): the caller then owns their placement on the command processor's pipes
     (`placed_streams` explains what is at stake: up to +35 % per step) and `audio_streams` / `control_streams` are ignored."""
 
-    def __init__(self, model, depth: int = 4, audio_streams: int = 2, control_streams: int = 1, batched_gru: bool = False,
+    def __init__(self, model, depth: int = 4, audio_streams: int = 2, control_streams: int = 2, batched_gru: bool = False,
                  chain_exciters: bool = False, streams=None):
         if depth < 2 or audio_streams < 1 or control_streams < 1:
             raise ValueError("need depth >= 2 and at least one stream of each kind")
