@@ -47,7 +47,7 @@ enum Opt {
   // with kOptFilmMfma | kOptLowReg, two hops per workgroup: the FiLM rows arrive as per-FRAME bf16x3 fragment records
   // (NWS_FILM_REC_BYTES per frame, film_frag_record below) and go to LDS by the LDS-DMA path - no staging arithmetic in this
   // kernel.  Round 6, VERDICT r5 #3: built, 3.6e-9 RMS from the product kernel, and MEASURED AS NOTHING - prologue-only launch
-  // 35.8 -> 34.4 us, whole kernel 257.4 -> 255.0 us (profiles/r06/film_dma_ab.txt): per workgroup the prologue-only launch is one
+  // 36.8 -> 34.7 us, whole kernel 266.8 -> 263.6 us (profiles/r06/film_dma_ab.txt; another box: 35.8 -> 34.4, 257.4 -> 255.0): per workgroup the prologue-only launch is one
   // memory round trip and one barrier (16 000 workgroups / 768 slots = 21 rounds x 1.6 us), not the staging arithmetic (~100 of a
   // wave's ~800 vector instructions on three of eight waves), and in the real kernel the CU's other two workgroups work meanwhile.
   // Not on the product path (the records would cost the frame-MLP kernel 17 MB more stores per step); kept behind
