@@ -256,7 +256,11 @@ def build_hip(force=False, verbose=True):
             else:
                 rest.append(line)
         if spilled:
-            raise RuntimeError(f"{src}: kernels using scratch memory (spills or stack): {spilled}")
+            # NWS_BUILD_ALLOW_SCRATCH=1: measurements of an experimental variant only (prints the list, never set by the package)
+            if os.environ.get("NWS_BUILD_ALLOW_SCRATCH") == "1":
+                print(f"{src}: kernels using scratch memory (allowed by NWS_BUILD_ALLOW_SCRATCH): {spilled}", file=sys.stderr)
+            else:
+                raise RuntimeError(f"{src}: kernels using scratch memory (spills or stack): {spilled}")
         over = check_register_budgets(r.stderr)
         if over:
             lines = "\n".join(f"  {k}: {n} registers > {b} ({why})" for k, n, b, why in over)
