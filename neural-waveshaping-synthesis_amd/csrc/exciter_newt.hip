@@ -15,9 +15,7 @@
 // indistinguishable from the exact-fp32 MFMA it replaced, at 1/5 of its matrix-pipe time, and unlike
 // the fp32 MFMA it overlaps with the VALU work.  The 64x32 accumulator tile then goes straight through
 // FiLM -> LUT (or sin-MLP) -> FiLM -> 64->1 mix in registers; one coalesced 128 B store per wave.
-#include <atomic>
 #include <cstdlib>
-#include <mutex>
 #include <type_traits>
 
 #include "nws_common.h"
@@ -34,9 +32,6 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #define NWS_LUT_GROUP 4
 #endif
 constexpr int kLutGroup = NWS_LUT_GROUP;   // table gathers in flight together in the fused tail (one memory round trip per group)
-#ifndef NWS_EXC_SCALAR_MINWAVES
-#define NWS_EXC_SCALAR_MINWAVES 6
-#endif
 constexpr int kTile = 128;                  // samples per workgroup (= control hop)
 constexpr float kTau = 6.283185307179586f;  // fl32(math.tau)
 constexpr float kPi = 3.141592653589793f;   // fl32(math.pi)
@@ -57,16 +52,9 @@ enum Opt {
   // wave's ~800 vector instructions on three of eight waves), and in the real kernel the CU's other two workgroups work meanwhile.
   // Not on the product path (the records would cost the frame-MLP kernel 17 MB more stores per step); kept behind
   // nws_debug_exciter_newt variants 6 / 108.
-  kOptFilmDma = 64,
-  // experiments of round 6 (nws_debug_exciter_newt variants 10 + OPT; see LABBOOK "Round 6, second half"):
-  kOptScalarChain = 128,   // sine arguments and their reduction as scalar fp32 instead of v_pk_*_f32 (packed fp32 does not overlap with the matrix pipe)
-  kOptSplitCvt = 256,      // lo = cvt_pk(v - float(hi)): v_cvt_f32_f16 x2 + v_sub x2 + v_cvt_pk instead of two v_fma_mix{lo,hi}_f16
-  kOptSplitMask = 512,     // hi = v & 0xffffe000 (truncation to 11 bits), lo = v - hi, two v_cvt_pk
-  // a second copy of the K loop for waves whose 101 harmonics are all below Nyquist and whose arguments all take the fast reduction
-  // (wave-uniform, decided once): no per-step live counts, masks, compares or wide-argument branch in it
-  kOptLiveFast = 1024
+  kOptFilmDma = 64
 };
-static_assert((kOptFilmMfma ^ kOptOneTerm ^ kOptHybrid ^ kOptHybridW ^ kOptLowReg ^ kOptFilmDma ^ kOptScalarChain ^ kOptSplitCvt ^ kOptSplitMask ^ kOptLiveFast) == 2046, "Opt bits must be distinct");
+static_assert((kOptFilmMfma ^ kOptOneTerm ^ kOptHybrid ^ kOptHybridW ^ kOptLowReg ^ kOptFilmDma) == 126, "Opt bits must be distinct");
 enum Mode { kModeLut = 0, kModeExact = 1, kModeExciterOnly = 2, kModeLutPairs = 3, kModeLutPairsDiv6 = 4, kModeExactBank = 5,
             kModeExactBankNF = 6 };   // NF: no v_fract in front of the sines of the hidden and output layers (NWS_EXCITER_BANK_NOFRACT)
 __host__ __device__ constexpr bool is_bank(int mode) { return mode == kModeExactBank || mode == kModeExactBankNF; }
@@ -445,8 +433,9 @@ struct ExcLds {
   // between the slot's two frames (staging, from NwsWeights.exciter_bound); 0 = unknown -> the clamped lookup
   unsigned long long okmask[3];
   // K slot c = 16ks + 8half + e: slot 0 is the mixer BIAS (its "sine" is the constant 1), slot c >= 1 is harmonic c
-  alignas(16) float shift[kKPad];   // (16-byte aligned: the K-steps read shift and kf as ds_read_b128 with immediate offsets)
-                                // phase shift of slot c (0 for slot 0 and the padding slots 102..111)
+  // (16-byte aligned: the K-steps read shift and kf as ds_read_b128 with immediate offsets; behind okmask[3] the pair sat at 8 mod 16 and every
+  // K-step spent four v_add_u32 on ds_read2_b64 addresses - no time in it, see LABBOOK 'Round 6, second half')
+  alignas(16) float shift[kKPad];   // phase shift of slot c (0 for slot 0 and the padding slots 102..111)
   float kf[kKPad];              // (float)c: harmonic numbers as packed-FMA operands, read instead of computed
 };
 
@@ -557,23 +546,6 @@ __device__ __forceinline__ f16x2 split_lo2(f16x2 hi, f32x2 v) {
   return __builtin_bit_cast(f16x2, lp);
 }
 
-// the experimental splits (kOptSplitCvt / kOptSplitMask): same hi + lo contract as cvt_pk + split_lo2
-template <int OPT>
-__device__ __forceinline__ void split_pair(f32x2 v, f16x2& hi, f16x2& lo) {
-  if (OPT & kOptSplitMask) {
-    const float hx = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v.x) & 0xffffe000u);
-    const float hy = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v.y) & 0xffffe000u);
-    hi = __builtin_convertvector(f32x2{hx, hy}, f16x2);
-    lo = __builtin_convertvector(f32x2{v.x - hx, v.y - hy}, f16x2);
-  } else if (OPT & kOptSplitCvt) {
-    hi = __builtin_convertvector(v, f16x2);
-    lo = __builtin_convertvector(f32x2{v.x - (float)hi.x, v.y - (float)hi.y}, f16x2);
-  } else {
-    hi = __builtin_convertvector(v, f16x2);
-    lo = split_lo2(hi, v);
-  }
-}
-
 // hot-loop form: n = rint(x C_hi), then t = fma(x, C_hi, -n) - the EXACT product minus an integer, rounded once: |t| <= 1/2,
 // so the rounding costs <= 3e-8 turns - and t += x C_lo.  Three packed instructions and two v_rndne_f32 per pair; the
 // v_fract form before it (p, its exact rounding error e, fract(p) + (x C_lo + e)) needed four and two v_fract_f32, and
@@ -604,7 +576,9 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 }
 
 // DBG != 0 instantiations exist only for nws_debug_exciter_newt (ablation timing; results are wrong by design):
-//   1: sin() replaced by its argument   2: LUT gather skipped   3: whole FiLM/shaper tail skipped   4: MFMAs skipped
+//   1: sin() replaced by its argument (scaled into the range proof's domain)   2: LUT gather skipped   3: whole FiLM/shaper tail skipped
+//   4: MFMAs skipped   5: prologue only   6: no global load in front of the barrier (7 / 8 / 9: no FiLM rows / no fragment DMA / no F0, carry,
+//   shifts): what the prologue's memory LATENCY costs the launch
 // second launch-bound = minimum waves per SIMD: without it hipcc hoists all 32 LUT gathers of the tail, takes 256
 // VGPRs and drops the kernel to 1 wave/SIMD (measured 2x slower); 4 waves/SIMD = 128 VGPRs, LDS allows 5 blocks/CU
 // HPB = hops (128-sample tiles) per workgroup = 4 HPB waves.  Two hops share one copy of the 28 KB fragment table and one
@@ -613,7 +587,7 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
 // (0.328 ms).  (Wrong results seen with that build under two overlapping audio streams were first blamed on the scratch;
 // the multi-stream problem turned out to be independent of it, see pipeline.py.  The build still rejects scratch.)
 template <int MODE, int DBG = 0, int HPB = 1, int OPT = 0>
-__global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) ? 4 : ((OPT & kOptLowReg) ? ((OPT & kOptScalarChain) ? NWS_EXC_SCALAR_MINWAVES : 6) : (OPT & kOptFilmMfma) ? 5 : (HPB == 2 ? 7 : 5)))) void exciter_newt_kernel(NwsWeights w, const float* __restrict__ f0,
+__global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) ? 4 : ((OPT & kOptLowReg) ? 6 : (OPT & kOptFilmMfma) ? 5 : (HPB == 2 ? 7 : 5)))) void exciter_newt_kernel(NwsWeights w, const float* __restrict__ f0,
                                                            const float* __restrict__ f0_up,
                                                            const double* __restrict__ carry,
                                                            const float* __restrict__ phase_u,
@@ -662,7 +636,7 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
   const int n = (hop_live ? j : jb) * kTile + w4 * 32 + col;
   const NwsLerp lc = nws_lerp_coeff(n, T);
   float f0_a, f0_b = 0.0f;
-  if (DBG == 6 || DBG == 9) {   // (timing) no memory in front of the barrier: what the prologue's LATENCY costs the launch (7 / 8 / 9: one source each)
+  if (DBG == 6 || DBG == 9) {
     f0_a = 0.3f + 1.0e-4f * (float)col;
     f0_b = 0.31f;
   } else
@@ -918,12 +892,11 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
     const f32x2 arg2 = kfp * ph2 + shp;
     return f32x2{nws_sin_wide(arg2.x), nws_sin_wide(arg2.y)};
   };
-  auto sines = [&](const int ks, auto first_tag, auto live_tag, f16x8& vhi, f16x8& vlo) {
+  auto sines = [&](const int ks, auto first_tag, f16x8& vhi, f16x8& vlo) {
     constexpr bool kFirst = decltype(first_tag)::value;
-    constexpr bool kLive = decltype(live_tag)::value;   // all harmonics live and small arguments, known at compile time in this copy
     const int kk0 = 16 * ks + 8 * half;
     const int rem = kmax + 1 - kk0;    // this lane's live slots in the step: e < rem  (slot c = kk0 + e is live iff c <= kmax)
-    const bool full = kLive || all_live || __all(rem >= 8);
+    const bool full = all_live || __all(rem >= 8);
     const float4 sh0 = *reinterpret_cast<const float4*>(&L.shift[kk0]);
     const float4 sh1 = *reinterpret_cast<const float4*>(&L.shift[kk0 + 4]);
     const float4 kf0 = *reinterpret_cast<const float4*>(&L.kf[kk0]);
@@ -931,25 +904,12 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
     const f32x2 sh2[4] = {{sh0.x, sh0.y}, {sh0.z, sh0.w}, {sh1.x, sh1.y}, {sh1.z, sh1.w}};
     const f32x2 kf2[4] = {{kf0.x, kf0.y}, {kf0.z, kf0.w}, {kf1.x, kf1.y}, {kf1.z, kf1.w}};
     f32x2 v2[4];
-    if (kSharedTurns && (kLive || small_args) && DBG != 1) {
+    if (kSharedTurns && small_args && DBG != 1) {
       // the lane's 8 consecutive harmonics: turns(k0 + e) = turns(k0) + e P + (shift differences, |.| < 1 turn), so
       // n_e = rint(x_0 C_hi) + rint(e P) is within 2 of every x_e C_hi: one rint per K-step instead of eight, the reduced
       // argument t_e = fma(x_e, C_hi, -n_e) + x_e C_lo is still the exact product minus an integer, now |t_e| < 2 (fp32
       // spacing 2.4e-7 turns at worst; v_sin_f32 takes +-256 turns).  Against the per-sine rint of sin_turns2_fract:
       // 0.2061 instead of 0.2212 ms (hybrid-W), 0.2713 instead of 0.2889 (two-term), outputs 5e-9 RMS apart (signal 2.9e-3)
-      if (OPT & kOptScalarChain) {
-        // the same chain as scalar fp32 (rounding for rounding: every packed instruction below is two independent scalar ones)
-        const float a0 = kf0.x * phase + sh0.x;
-        const float n0s = __builtin_rintf(a0 * 0.15915493667125702f);
-        auto red = [&](const float a, const float te) {
-          return __builtin_amdgcn_sinf(fmaf(a, 6.4206382432985265e-09f, fmaf(a, 0.15915493667125702f, -(n0s + te))));
-        };
-        v2[0] = f32x2{red(a0, turns_e[0].x), red(kf0.y * phase + sh0.y, turns_e[0].y)};
-        v2[1] = f32x2{red(kf0.z * phase + sh0.z, turns_e[1].x), red(kf0.w * phase + sh0.w, turns_e[1].y)};
-        __builtin_amdgcn_sched_barrier(0);
-        v2[2] = f32x2{red(kf1.x * phase + sh1.x, turns_e[2].x), red(kf1.y * phase + sh1.y, turns_e[2].y)};
-        v2[3] = f32x2{red(kf1.z * phase + sh1.z, turns_e[3].x), red(kf1.w * phase + sh1.w, turns_e[3].y)};
-      } else {
       const f32x2 c_hi = splat2(0.15915493667125702f), c_lo = splat2(6.4206382432985265e-09f);
       f32x2 a2[4];
 #pragma unroll
@@ -959,7 +919,6 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
       for (int p = 0; p < 4; ++p) {
         const f32x2 t = fma2(a2[p], c_lo, fma2(a2[p], c_hi, -(n0 + turns_e[p])));
         v2[p] = f32x2{__builtin_amdgcn_sinf(t.x), __builtin_amdgcn_sinf(t.y)};
-      }
       }
     } else {
 #pragma unroll
@@ -976,20 +935,15 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
     // v = hi + lo, both fp16 (lo = exact residual rounded to fp16): v_cvt_pk_f16_f32 for hi, one v_fma_mix{lo,hi}_f16 per lo
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      f16x2 h2, l2;
-      if (two_terms(ks)) split_pair<OPT>(v2[p], h2, l2);
-      else h2 = __builtin_convertvector(v2[p], f16x2);
+      const f16x2 h2 = __builtin_convertvector(v2[p], f16x2);
       vhi[2 * p] = h2.x;
       vhi[2 * p + 1] = h2.y;
       if (two_terms(ks)) {
+        const f16x2 l2 = split_lo2(h2, v2[p]);
         vlo[2 * p] = l2.x;
         vlo[2 * p + 1] = l2.y;
       }
     }
-    // the lo terms come out of INLINE ASM (split_lo2), which hipcc's hazard recogniser does not see through: a matrix instruction
-    // must not read them within two wait states of the write (build.py check_valu_mfma_hazard).  The default copy of the loop happens
-    // to be scheduled with other instructions in between; this makes it a guarantee for every copy, by a data dependence
-    if (two_terms(ks) && !(OPT & (kOptSplitCvt | kOptSplitMask)) && (OPT & kOptLiveFast)) asm volatile("s_nop 1" : "+v"(vlo));
   };
   auto mix = [&](const int ks, auto first_tag, const f16x8& vhi, const f16x8& vlo) {
     constexpr bool kFirst = decltype(first_tag)::value;
@@ -1010,26 +964,16 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
   };
   // K-step 6 = slots 96..103 (harmonics 96..101): ONE K=8 MFMA per term instead of a K=16 one whose upper half would be
   // padding - half the sines of a full step.  Lane (col, half) evaluates slots 96 + 4 half + 0..3.
-  auto last_step = [&](auto live_tag) {
-    constexpr bool kLive = decltype(live_tag)::value;
+  auto last_step = [&] {
     constexpr int ks = kKSteps - 1;
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     const int kk0 = 16 * ks + 4 * half;
     const int rem = kmax + 1 - kk0;
-    const bool full = kLive || all_live || __all(rem >= 4);
+    const bool full = all_live || __all(rem >= 4);
     const float4 sh = *reinterpret_cast<const float4*>(&L.shift[kk0]);
     const float4 kf = *reinterpret_cast<const float4*>(&L.kf[kk0]);
     f32x2 v2[2];
-    if (kSharedTurns && (kLive || small_args) && DBG != 1) {
-      if (OPT & kOptScalarChain) {
-        const float a0 = kf.x * phase + sh.x;
-        const float n0s = __builtin_rintf(a0 * 0.15915493667125702f);
-        auto red = [&](const float a, const float te) {
-          return __builtin_amdgcn_sinf(fmaf(a, 6.4206382432985265e-09f, fmaf(a, 0.15915493667125702f, -(n0s + te))));
-        };
-        v2[0] = f32x2{red(a0, turns_e[0].x), red(kf.y * phase + sh.y, turns_e[0].y)};
-        v2[1] = f32x2{red(kf.z * phase + sh.z, turns_e[1].x), red(kf.w * phase + sh.w, turns_e[1].y)};
-      } else {
+    if (kSharedTurns && small_args && DBG != 1) {
       const f32x2 c_hi = splat2(0.15915493667125702f), c_lo = splat2(6.4206382432985265e-09f);
       const f32x2 a2[2] = {f32x2{kf.x, kf.y} * ph2 + f32x2{sh.x, sh.y}, f32x2{kf.z, kf.w} * ph2 + f32x2{sh.z, sh.w}};
       const f32x2 n0 = splat2(__builtin_rintf(a2[0].x * 0.15915493667125702f));
@@ -1037,7 +981,6 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
       for (int p = 0; p < 2; ++p) {
         const f32x2 t = fma2(a2[p], c_lo, fma2(a2[p], c_hi, -(n0 + turns_e[p])));
         v2[p] = f32x2{__builtin_amdgcn_sinf(t.x), __builtin_amdgcn_sinf(t.y)};
-      }
       }
     } else {
       v2[0] = sine_pair(f32x2{kf.x, kf.y}, f32x2{sh.x, sh.y});
@@ -1053,17 +996,15 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
     f16x4 vhi, vlo;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      f16x2 h2, l2;
-      if (two_terms(ks)) split_pair<OPT>(v2[p], h2, l2);
-      else h2 = __builtin_convertvector(v2[p], f16x2);
+      const f16x2 h2 = __builtin_convertvector(v2[p], f16x2);
       vhi[2 * p] = h2.x;
       vhi[2 * p + 1] = h2.y;
       if (two_terms(ks)) {
+        const f16x2 l2 = split_lo2(h2, v2[p]);
         vlo[2 * p] = l2.x;
         vlo[2 * p + 1] = l2.y;
       }
     }
-    if (two_terms(ks) && !(OPT & (kOptSplitCvt | kOptSplitMask)) && (OPT & kOptLiveFast)) asm volatile("s_nop 1" : "+v"(vlo));
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const f16x4 ahi = *reinterpret_cast<const f16x4*>(&L.whi[(ks * 2 + m) * 64 + frag_lane]);   // first 8 bytes of the row
@@ -1080,27 +1021,24 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
   };
   // the first step always runs (it carries the bias); k*f0 only grows with k: once a step has no live lane, everything
   // above is masked too
-  auto run_ksteps = [&](auto live_tag) {
-    constexpr bool kLive = decltype(live_tag)::value;
+  {
     auto kstep = [&](const int ks, auto first_tag) {
       f16x8 vhi, vlo;
-      sines(ks, first_tag, live_tag, vhi, vlo);
+      sines(ks, first_tag, vhi, vlo);
       mix(ks, first_tag, vhi, vlo);
     };
     kstep(0, std::true_type{});
     bool more = true;
 #pragma unroll
     for (int ks = 1; ks < kKSteps - 1; ++ks) {
-      if (!kLive && !all_live && !__any(kmax + 1 - (16 * ks + 8 * half) > 0)) {
+      if (!all_live && !__any(kmax + 1 - (16 * ks + 8 * half) > 0)) {
         more = false;
         break;
       }
       kstep(ks, std::false_type{});
     }
-    if (kLive || (more && (all_live || __any(kmax + 1 - (16 * (kKSteps - 1) + 4 * half) > 0)))) last_step(live_tag);
-  };
-  if ((OPT & kOptLiveFast) && kSharedTurns && DBG == 0 && all_live && small_args) run_ksteps(std::true_type{});
-  else run_ksteps(std::false_type{});
+    if (more && (all_live || __any(kmax + 1 - (16 * (kKSteps - 1) + 4 * half) > 0))) last_step();
+  }
 
   // accumulator element r of M-tile m: shaper 32m + (r&3) + 8(r>>2) + 4*half, sample `col`
   if (exciter_out != nullptr) {
@@ -1360,515 +1298,6 @@ __global__ __launch_bounds__(256 * HPB, MODE == kModeExact ? 2 : (is_bank(MODE) 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Persistent form of the FastNEWT hot path (round 6).  Same arithmetic as exciter_newt_kernel<kModeLutPairsDiv6, 0, 2,
-// kOptFilmMfma | kOptLowReg [| hybrid bits]>, bit for bit; what changes is WHEN memory is asked for.  The grid-launched kernel
-// pays, per two-hop workgroup, three round trips to memory in front of its barrier (28 KB of mixer fragments by LDS-DMA, the FiLM
-// rows of four frames, this wave's F0 frames and carry; timing ablations nws_debug_exciter_newt 26..29: 17 us of a 266 us launch
-// at B = 64).  Here one workgroup per wave slot of the chip stays resident and takes (utterance, hop group) items off a counter:
-//   * mixer fragments, phase shifts, newt.mixer weights, exciter bounds: staged ONCE per workgroup;
-//   * FiLM rows of the NEXT item: four 1 KB LDS-DMA pieces issued behind the item's first barrier, raw rows in LDS, split into the
-//     bf16 x 3 fragments from LDS at the top of the next item (no memory latency in front of any barrier);
-//   * F0 frames and the 32-sample carry are wave-uniform (a wave's 32 samples interpolate between ONE frame pair): scalar loads
-//     into SGPRs an item ahead, no vector register held across the body;
-//   * items come off an atomic counter (ctr[0]; ctr[1] counts finished workgroups, the last one zeroes both for the next launch),
-//     so a compute unit that shares its SIMDs with a recurrence workgroup simply takes fewer items (the grid-launched kernel deals
-//     workgroups to the XCDs round-robin whatever they are busy with).  ctr == nullptr: static striding.
-// Two workgroup barriers per item: B1 between the K loop and the tail (fragments of this item staged, raw rows consumed, next
-// item known), B2 at the end (raw rows of the next item landed, this item's fragments dead).
-// ---------------------------------------------------------------------------------------------
-struct ExcPLds {
-  f16x8 whi[kKSteps * 2 * 2 * 32];
-  f16x8 wlo[kKSteps * 2 * 2 * 32];
-  uint4 ffrag[3][3][2][32];        // as ExcLds::ffrag
-  float raw[4][NWS_FILM_CH];       // FiLM rows of frames jb-1 .. jb+2 (clamped) of the item to be staged next, as they lie in memory
-  float bsum[4];
-  unsigned long long okmask[3];
-  int next2, pad;                  // the item after next, published by wave 7 in front of B2
-  alignas(16) float shift[kKPad];
-  float kf[kKPad];
-  alignas(16) float sc[8][4];      // per wave: {F0 frame i0, F0 frame i1, carry (two words)} of the NEXT item, by LDS-DMA
-  float ow[kS];                    // newt.mixer weight
-  float xb[kS];                    // NwsWeights.exciter_bound (inf when absent)
-};
-static_assert(sizeof(ExcPLds) <= 44032, "ExcPLds above 43 KB: three workgroups per CU need 3 x (this + 16 B) <= 160 KB with room to spare");
-
-// what the persistent kernel reads of NwsWeights (the whole struct by value is 116 dwords of kernel arguments that the loop would keep
-// re-loading or pin in scalar registers)
-struct PersistWeights {
-  const void* mixer_frags;
-  const float* lut_pairs;
-  const float* newt_out_w;
-  const float* newt_out_b;
-  const float* exciter_bound;
-  int lut_size;
-  float lut_min;
-};
-
-// PDBG (timing only, results wrong): bit 0 no barrier B1, bit 1 no barrier B2 (both force the clamped lookups: fragments may be torn)
-template <int OPT, int PDBG = 0>
-__global__ __launch_bounds__(512, 6) void exciter_newt_persist_kernel(const PersistWeights w, const float* __restrict__ f0, const double* __restrict__ carry,
-                                                                      const float* __restrict__ phase_u, const float* __restrict__ rand_phase,
-                                                                      const float* __restrict__ film, const int B, const int T, const float sample_rate,
-                                                                      float* __restrict__ newt_out, const float* __restrict__ add_in, int* __restrict__ ctr, const int stagger, const int cus) {
-  static_assert((OPT & kOptFilmMfma) && (OPT & kOptLowReg) && !(OPT & kOptFilmDma), "the persistent kernel is the product tail only");
-  // the three workgroups of a compute unit start `stagger` x 64 clocks apart (launch order: ids p, p + cus, p + 2 cus share a unit): launched
-  // together they would run their K loops (matrix pipe) and their tails (table gathers) in step, each phase alone on its pipe
-  for (int sl = (int)(blockIdx.x / (unsigned)cus) * stagger; sl > 0; sl -= 100) __builtin_amdgcn_s_sleep(100);
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  ExcPLds& L = *reinterpret_cast<ExcPLds*>(smem_raw);
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // the lane id, re-made where it is needed (volatile: hipcc must neither hoist it out of the item loop nor keep it across the body)
-  auto lane_id = [] {
-    int l;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-    return l;
-  };
-  const int w4 = wave & 3;
-  const int N = T * NWS_HOP;
-  const int groups = (T + 1) >> 1;
-  const int total = groups * B;
-  LutFast LF;
-  LF.pairs = reinterpret_cast<const char*>(w.lut_pairs);
-  LF.c_r = (float)w.lut_size * (1.0f / 6.0f);
-  LF.c_d = 6.0f / (float)w.lut_size;
-  LF.top = (float)(w.lut_size - 1);
-  LF.row_bytes = (unsigned)w.lut_size * 8u;
-  int lane = tid & 63, half = lane >> 5, col = lane & 31;
-
-  // ---- once per workgroup: mixer fragments (28 KB by LDS-DMA), phase shifts + harmonic numbers, output weights, exciter bounds ----
-  if (wave < ((OPT & kOptHybridW) ? 4 : 7)) {
-    const char* src = static_cast<const char*>(w.mixer_frags) + wave * 4096 + lane * 16;
-    char* dst = reinterpret_cast<char*>(L.whi) + wave * 4096;
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 1024, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 2048, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 3072, 0);
-  } else if (wave == 7) {
-    // _create_phase_shift (generators.py:54-56): fl(fl(u * rand_phase) - fl32(pi)) for harmonic c = slot c
-    auto shift_of = [&](int c) { return c >= 1 && c <= kK ? phase_u[c - 1] * rand_phase[c - 1] - kPi : 0.0f; };
-    L.shift[lane] = shift_of(lane);
-    L.kf[lane] = (float)lane;
-    if (lane < kKPad - 64) {
-      L.shift[64 + lane] = shift_of(64 + lane);
-      L.kf[64 + lane] = (float)(64 + lane);
-    }
-    L.ow[lane] = w.newt_out_w[lane];
-    L.xb[lane] = w.exciter_bound != nullptr ? w.exciter_bound[lane] : __builtin_inff();
-  }
-
-  // item -> (utterance, hop group); everything about an item is wave-uniform
-  auto frame_clamped = [&](int f) { return f < 0 ? 0 : (f > T - 1 ? T - 1 : f); };
-  // the four FiLM rows of item `it`, one 1 KB piece per wave 0..3 (row q = wave: frame jb - 1 + q, clamped)
-  auto issue_rows = [&](const int it) {
-    const int b = it / groups, jb = 2 * (it - b * groups);
-    const float* src = film + ((size_t)b * T + frame_clamped(jb - 1 + wave)) * NWS_FILM_CH + lane * 4;
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&L.raw[wave][0], 16, 0, 0);
-  };
-  // this wave's sample index inside item `it` (its second hop may lie past the end of an odd-length utterance: dead, see below)
-  auto sample_of = [&](const int it, int& b, int& jb, bool& live) {
-    b = it / groups;
-    jb = 2 * (it - b * groups);
-    const int j = jb + (wave >> 2);
-    live = j < T;
-    return (live ? j : jb) * kTile + w4 * 32 + col;
-  };
-  // F0 frames and carry of this wave's 32 samples: ONE frame pair and one 32-sample chunk per wave (nws_lerp_coeff: a wave's samples
-  // all lie in the first or in the second half of their hop).  Four dwords per wave, fetched an item ahead by LDS-DMA (lanes 0..3, 4 bytes
-  // each): tracked by the VM counter like the FiLM rows.  (Scalar loads were tried: they share the LGKM counter with the K loop's LDS reads and
-  // return out of order, so the first LDS wait behind them sat out their whole round trip - 1 - 1.7 us per item.)
-  auto issue_scalars = [&](const int it) {
-    int b, jb;
-    bool live;
-    const int n = sample_of(it, b, jb, live);
-    const NwsLerp c = nws_lerp_coeff(n, T);
-    const float* cw = reinterpret_cast<const float*>(carry + (size_t)b * (N / 32) + (n >> 5));
-    const float* x = f0 + (size_t)b * T;
-    const float* src = lane == 0 ? x + c.i0 : (lane == 1 ? x + c.i1 : cw + (lane - 2));
-    if (lane < 4) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&L.sc[wave][0], 4, 0, 0);
-  };
-
-  // items: the first two of a workgroup are static (id, id + grid), the others come off the counter TWO items ahead: wave 7 asks for item
-  // t + 2 at the top of item t and publishes the answer in front of the item's closing barrier - the atomic's round trip (~2 us) has a whole
-  // item to come back in, and the register it comes back in is the one the loop would otherwise spend on the thread id
-  int item = blockIdx.x;
-  int next = item + (int)gridDim.x;
-  if (wave < 4) issue_rows(item);
-  issue_scalars(item);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  for (;;) {
-    // everything per-lane is re-derived from ONE register per item: left to itself hipcc hoists the lane's LDS addresses, table offsets and
-    // fragment indices out of the loop and keeps them in ~20 registers the 80-register body does not have (-> scratch)
-    lane = lane_id();
-    half = lane >> 5;
-    col = lane & 31;
-    const int frag_lane = lane;   // = half * 32 + col
-    const unsigned lane_off_bytes = (unsigned)(4 * half * w.lut_size) * 8u;
-    // (the same for the scalar side: the 32 table-row bases of the tail are loop invariants that hipcc would hoist and then spill to lanes of a
-    // vector register; re-derived from an opaque copy of the table pointer they are two scalar adds each, where they are used)
-    const char* lut_rows = LF.pairs;
-    asm volatile("" : "+s"(lut_rows));
-    float sr_item = sample_rate;
-    asm volatile("" : "+s"(sr_item));
-    const float nyquist = sr_item * 0.5f;
-    int b, jb;
-    bool hop_live;
-    const int n = sample_of(item, b, jb, hop_live);
-    const NwsLerp lc = nws_lerp_coeff(n, T);
-
-    // ---- stage this item's FiLM fragments, range proofs and bias sums from the raw rows (LDS -> LDS) ----
-    if (wave < 3) {
-      const float ow = L.ow[lane];
-      // index FiLM pre-scaled to table units (see exciter_newt_kernel)
-      const float c = (float)w.lut_size * (1.0f / 6.0f);
-      float ga = 0.0f, gd = 0.0f, ba = 0.0f, bd = 0.0f;
-#pragma unroll
-      for (int ty = 0; ty < 3; ++ty) {
-        const float u0 = L.raw[wave][ty * kS + lane], u1 = L.raw[wave + 1][ty * kS + lane];
-        float a, d;
-        if (ty == 0) {
-          a = u0 * c;
-          d = (u1 - u0) * c;
-          ga = a;
-          gd = d;
-        } else if (ty == 1) {
-          a = (u0 - w.lut_min) * c;
-          d = (u1 - u0) * c;
-          ba = a;
-          bd = d;
-        } else {
-          a = ow * u0;
-          d = ow * u1 - a;
-        }
-        auto top16 = [](float v) { return __builtin_bit_cast(unsigned, v) & 0xffff0000u; };
-        const unsigned a0 = top16(a);
-        const float ra = a - __builtin_bit_cast(float, a0);
-        const unsigned a1 = top16(ra);
-        const unsigned a2 = top16(ra - __builtin_bit_cast(float, a1));
-        const unsigned d0 = top16(d);
-        const float rd = d - __builtin_bit_cast(float, d0);
-        const unsigned d1 = top16(rd);
-        const unsigned d2 = top16(rd - __builtin_bit_cast(float, d1));
-        L.ffrag[wave][ty][lane >> 5][lane & 31] = uint4{(a0 >> 16) | a1, (a2 >> 16) | d0, (d1 >> 16) | d2, 0u};
-      }
-      // range proof of this slot's lookups (see exciter_newt_kernel: NaN-safe, one table cell + 2^-9 |G| X of margin)
-      const float X = L.xb[lane];
-      const float r_a = fabsf(ga) * X, r_b = fabsf(ga + gd) * X;
-      const float e = 1.0f + fmaxf(r_a, r_b) * (1.0f / 512.0f);
-      const float lo = fminf(ba - r_a, (ba + bd) - r_b), hi = fmaxf(ba + r_a, (ba + bd) + r_b);
-      const float right = (ba + bd) + r_b;
-      const unsigned long long okm = __ballot(lo >= e && hi <= (float)(w.lut_size - 1) - e && r_a == r_a && right == right);
-      if (lane == 0) L.okmask[wave] = okm;
-    } else if (wave < 7) {
-      const float v = wave_sum_to_lane63(L.ow[lane] * L.raw[wave - 3][3 * kS + lane]);   // sum_s out_w[s] * b_norm[frame][s]
-      if (lane == 63) L.bsum[wave - 3] = v;
-    }
-    int ticket = 0;
-    if (wave == 7 && ctr != nullptr && lane == 0) ticket = 2 * (int)gridDim.x + atomicAdd(ctr, 1);
-
-    // this item's F0 frames and carry (landed before B2 of the previous item)
-    const float4 scv = *reinterpret_cast<const float4*>(&L.sc[wave][0]);
-    const float f0_a = scv.x, f0_b = scv.y;
-    const double carry_in = __builtin_bit_cast(double, uint2{__builtin_bit_cast(unsigned, scv.z), __builtin_bit_cast(unsigned, scv.w)});
-
-    // ---- per-sample phase: fp64 prefix sum -> fp32 rounding chain of the reference ----
-    // The fragment waves (0..2) stage ~120 vector instructions in front of B1, the others next to nothing: those run their phase arithmetic
-    // (as long) BEFORE the barrier, the fragment waves behind it - nobody waits for anybody's staging
-    float phase = 0.0f;
-    bool small_args = false, all_live = false;
-    int kmax = 0;
-    f32x2 turns_e[4] = {};
-    auto phase_of_item = [&] {
-      const float f0n = nws_lerp(f0_a, f0_b, lc.w0, lc.w1);
-      double cs = scan32_f64((double)f0n);
-      cs += carry_in;
-      const float csum = (float)cs;
-      const float tc = kTau * csum;
-      if (sample_rate == 16000.0f) {
-        const float q = tc * 6.25e-05f;
-        phase = fmaf(fmaf(-q, 16000.0f, tc), 6.25e-05f, q);
-      } else {
-        phase = __fdiv_rn(tc, sample_rate);
-      }
-      small_args = __all(fabsf(phase) * (float)kKPad + 4.0f < 6.0e6f);
-      all_live = __all((f0n * (float)kK) < nyquist);
-      if (all_live) {
-        kmax = kK;
-      } else if (!(f0n > 0.0f)) {
-        kmax = f0n == f0n ? kK : 0;
-      } else {
-        const float q = nyquist * __builtin_amdgcn_rcpf(f0n);
-        int kc = q > (float)kK ? kK : (int)q;
-        kc += (kc < kK && (f0n * (float)(kc + 1)) < nyquist) ? 1 : 0;
-        kc -= (kc > 0 && !((f0n * (float)kc) < nyquist)) ? 1 : 0;
-        kc -= (kc > 0 && !((f0n * (float)kc) < nyquist)) ? 1 : 0;
-        kmax = kc;
-      }
-      const float P = phase * 0.15915493667125702f;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) turns_e[p] = f32x2{__builtin_rintf((float)(2 * p) * P), __builtin_rintf((float)(2 * p + 1) * P)};
-    };
-    if (wave >= 3 && hop_live) phase_of_item();
-
-    // B1: fragments, masks and bias sums of this item staged; raw rows and scalars consumed; next item known.  The waves of a workgroup meet
-    // ONCE per item, like the grid-launched kernel's at its one barrier (a barrier between K loop and tail instead costs 13 %: it puts all
-    // eight waves into the same phase twice per item).  A RAW barrier behind an LDS-only wait: __syncthreads() is a fence and waits for every
-    // outstanding VECTOR MEMORY operation too - here wave 7's ticket, at B2 every wave's output store on its round trip to memory
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (next < total) {
-      if (wave < 4) issue_rows(next);
-      issue_scalars(next);
-    }
-    if (wave < 3 && hop_live) phase_of_item();
-
-    f32x16 acc0, acc1;
-    if (hop_live) {
-      const f32x2 ph2 = splat2(phase);
-      auto two_terms = [](const int ks) { return (OPT & kOptOneTerm) ? false : ((OPT & kOptHybrid) ? ks == 0 : true); };
-      auto two_wterms = [](const int ks) { return (OPT & kOptHybridW) ? ks == 0 : true; };
-      auto sine_pair = [&](const f32x2 kfp, const f32x2 shp) -> f32x2 {
-        if (small_args) return sin_turns2_fract(kfp * ph2 + shp);
-        const f32x2 arg2 = kfp * ph2 + shp;
-        return f32x2{nws_sin_wide(arg2.x), nws_sin_wide(arg2.y)};
-      };
-      auto sines = [&](const int ks, auto first_tag, auto live_tag, f16x8& vhi, f16x8& vlo) {
-        constexpr bool kFirst = decltype(first_tag)::value;
-        constexpr bool kLive = decltype(live_tag)::value;
-        const int kk0 = 16 * ks + 8 * half;
-        const int rem = kmax + 1 - kk0;
-        const bool full = kLive || all_live || __all(rem >= 8);
-        const float4 sh0 = *reinterpret_cast<const float4*>(&L.shift[kk0]);
-        const float4 sh1 = *reinterpret_cast<const float4*>(&L.shift[kk0 + 4]);
-        const float4 kf0 = *reinterpret_cast<const float4*>(&L.kf[kk0]);
-        const float4 kf1 = *reinterpret_cast<const float4*>(&L.kf[kk0 + 4]);
-        const f32x2 sh2[4] = {{sh0.x, sh0.y}, {sh0.z, sh0.w}, {sh1.x, sh1.y}, {sh1.z, sh1.w}};
-        const f32x2 kf2[4] = {{kf0.x, kf0.y}, {kf0.z, kf0.w}, {kf1.x, kf1.y}, {kf1.z, kf1.w}};
-        f32x2 v2[4];
-        if (kLive || small_args) {
-          const f32x2 c_hi = splat2(0.15915493667125702f), c_lo = splat2(6.4206382432985265e-09f);
-          f32x2 a2[4];
-#pragma unroll
-          for (int p = 0; p < 4; ++p) a2[p] = kf2[p] * ph2 + sh2[p];
-          const f32x2 n0 = splat2(__builtin_rintf(a2[0].x * 0.15915493667125702f));
-#pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            const f32x2 t = fma2(a2[p], c_lo, fma2(a2[p], c_hi, -(n0 + turns_e[p])));
-            v2[p] = f32x2{__builtin_amdgcn_sinf(t.x), __builtin_amdgcn_sinf(t.y)};
-          }
-        } else {
-#pragma unroll
-          for (int p = 0; p < 4; ++p) v2[p] = sine_pair(kf2[p], sh2[p]);
-        }
-        if (!full) {
-#pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            v2[p].x = 2 * p < rem ? v2[p].x : 0.0f;
-            v2[p].y = 2 * p + 1 < rem ? v2[p].y : 0.0f;
-          }
-        }
-        if (kFirst) v2[0].x = half == 0 ? 1.0f : v2[0].x;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          f16x2 h2, l2;
-          if (two_terms(ks)) split_pair<OPT>(v2[p], h2, l2);
-          else h2 = __builtin_convertvector(v2[p], f16x2);
-          vhi[2 * p] = h2.x;
-          vhi[2 * p + 1] = h2.y;
-          if (two_terms(ks)) {
-            vlo[2 * p] = l2.x;
-            vlo[2 * p + 1] = l2.y;
-          }
-        }
-        if (two_terms(ks) && !(OPT & (kOptSplitCvt | kOptSplitMask))) asm volatile("s_nop 1" : "+v"(vlo));   // inline-asm producer -> MFMA (see exciter_newt_kernel)
-      };
-      auto mix = [&](const int ks, auto first_tag, const f16x8& vhi, const f16x8& vlo) {
-        constexpr bool kFirst = decltype(first_tag)::value;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const f16x8 ahi = L.whi[(ks * 2 + m) * 64 + frag_lane];
-          f32x16& acc = m == 0 ? acc0 : acc1;
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, vhi, kFirst ? f32x16{} : acc, 0, 0, 0);
-          if (two_terms(ks)) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, vlo, acc, 0, 0, 0);
-          if (two_wterms(ks)) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(L.wlo[(ks * 2 + m) * 64 + frag_lane], vhi, acc, 0, 0, 0);
-        }
-      };
-      auto last_step = [&](auto live_tag) {
-        constexpr bool kLive = decltype(live_tag)::value;
-        constexpr int ks = kKSteps - 1;
-        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-        const int kk0 = 16 * ks + 4 * half;
-        const int rem = kmax + 1 - kk0;
-        const bool full = kLive || all_live || __all(rem >= 4);
-        const float4 sh = *reinterpret_cast<const float4*>(&L.shift[kk0]);
-        const float4 kf = *reinterpret_cast<const float4*>(&L.kf[kk0]);
-        f32x2 v2[2];
-        if (kLive || small_args) {
-          const f32x2 c_hi = splat2(0.15915493667125702f), c_lo = splat2(6.4206382432985265e-09f);
-          const f32x2 a2[2] = {f32x2{kf.x, kf.y} * ph2 + f32x2{sh.x, sh.y}, f32x2{kf.z, kf.w} * ph2 + f32x2{sh.z, sh.w}};
-          const f32x2 n0 = splat2(__builtin_rintf(a2[0].x * 0.15915493667125702f));
-#pragma unroll
-          for (int p = 0; p < 2; ++p) {
-            const f32x2 t = fma2(a2[p], c_lo, fma2(a2[p], c_hi, -(n0 + turns_e[p])));
-            v2[p] = f32x2{__builtin_amdgcn_sinf(t.x), __builtin_amdgcn_sinf(t.y)};
-          }
-        } else {
-          v2[0] = sine_pair(f32x2{kf.x, kf.y}, f32x2{sh.x, sh.y});
-          v2[1] = sine_pair(f32x2{kf.z, kf.w}, f32x2{sh.z, sh.w});
-        }
-        if (!full) {
-#pragma unroll
-          for (int p = 0; p < 2; ++p) {
-            v2[p].x = 2 * p < rem ? v2[p].x : 0.0f;
-            v2[p].y = 2 * p + 1 < rem ? v2[p].y : 0.0f;
-          }
-        }
-        f16x4 vhi, vlo;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          f16x2 h2, l2;
-          if (two_terms(ks)) split_pair<OPT>(v2[p], h2, l2);
-          else h2 = __builtin_convertvector(v2[p], f16x2);
-          vhi[2 * p] = h2.x;
-          vhi[2 * p + 1] = h2.y;
-          if (two_terms(ks)) {
-            vlo[2 * p] = l2.x;
-            vlo[2 * p + 1] = l2.y;
-          }
-        }
-        if (two_terms(ks) && !(OPT & (kOptSplitCvt | kOptSplitMask))) asm volatile("s_nop 1" : "+v"(vlo));
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const f16x4 ahi = *reinterpret_cast<const f16x4*>(&L.whi[(ks * 2 + m) * 64 + frag_lane]);
-          f32x16& acc = m == 0 ? acc0 : acc1;
-          acc = __builtin_amdgcn_mfma_f32_32x32x8f16(ahi, vhi, acc, 0, 0, 0);
-          if (two_terms(ks)) acc = __builtin_amdgcn_mfma_f32_32x32x8f16(ahi, vlo, acc, 0, 0, 0);
-          if (two_wterms(ks))
-            acc = __builtin_amdgcn_mfma_f32_32x32x8f16(*reinterpret_cast<const f16x4*>(&L.wlo[(ks * 2 + m) * 64 + frag_lane]), vhi, acc, 0, 0, 0);
-        }
-      };
-      auto run_ksteps = [&](auto live_tag) {
-        constexpr bool kLive = decltype(live_tag)::value;
-        auto kstep = [&](const int ks, auto first_tag) {
-          f16x8 vhi, vlo;
-          sines(ks, first_tag, live_tag, vhi, vlo);
-          mix(ks, first_tag, vhi, vlo);
-        };
-        kstep(0, std::true_type{});
-        bool more = true;
-#pragma unroll
-        for (int ks = 1; ks < kKSteps - 1; ++ks) {
-          if (!kLive && !all_live && !__any(kmax + 1 - (16 * ks + 8 * half) > 0)) {
-            more = false;
-            break;
-          }
-          kstep(ks, std::false_type{});
-        }
-        if (kLive || (more && (all_live || __any(kmax + 1 - (16 * (kKSteps - 1) + 4 * half) > 0)))) last_step(live_tag);
-      };
-      if ((OPT & kOptLiveFast) && all_live && small_args) run_ksteps(std::true_type{});
-      else run_ksteps(std::false_type{});
-    }
-
-    if (hop_live) {
-      // ---- FiLM -> table lookup -> FiLM -> 64->1 mix, all in registers (the 80-register tail of exciter_newt_kernel) ----
-      // (sample index and interpolation weight derived again rather than kept across the K loop: two registers the loop needs)
-      const int col_t = lane_id() & 31;
-      const int n_t = (jb + (wave >> 2)) * kTile + w4 * 32 + col_t;
-      const NwsLerp lt = nws_lerp_coeff(n_t, T);
-      const int q0 = __builtin_amdgcn_readfirstlane(lt.i0) - (jb - 1);   // (a wave's 32 samples share their frame pair)
-      const unsigned w1b = __builtin_bit_cast(unsigned, lt.w1);
-      const uint4 bop = half == 0 ? uint4{0x3f803f80u, 0x3f80u | (w1b & 0xffff0000u), (w1b >> 16) | (w1b & 0xffff0000u), 0u}
-                                  : uint4{0u, 0u, 0u, 0u};
-      const bf16x8 bfrag = __builtin_bit_cast(bf16x8, bop);
-      auto ffrag_of = [&](const int ty, const int m) -> bf16x8 { return __builtin_bit_cast(bf16x8, L.ffrag[q0][ty][m][col_t]); };
-      float part = 0.0f;
-      unsigned ok_tile[2];
-      {
-        const unsigned* okw = reinterpret_cast<const unsigned*>(&L.okmask[q0]);
-        ok_tile[0] = PDBG ? 0u : (unsigned)__builtin_amdgcn_readfirstlane((int)okw[0]);
-        ok_tile[1] = PDBG ? 0u : (unsigned)__builtin_amdgcn_readfirstlane((int)okw[1]);
-      }
-      auto lookups = [&](auto m_tag, auto proven_tag, const f32x16& acc, const f32x16& Gn) {
-        constexpr int m = decltype(m_tag)::value;
-        constexpr bool proven = decltype(proven_tag)::value;
-#pragma unroll
-        for (int g = 0; g < 16 / kLutGroup; ++g) {
-          float fr[kLutGroup];
-          float2 tv[kLutGroup];
-#pragma unroll
-          for (int e = 0; e < kLutGroup; ++e) {
-            const int r = kLutGroup * g + e;
-            const float idx = acc[r];
-            unsigned o;
-            if (proven) {
-              o = lane_off_bytes + ((unsigned)idx << 3);
-              fr[e] = __builtin_amdgcn_fractf(idx);
-            } else {
-              const float fl = __builtin_amdgcn_fmed3f(floorf(idx), 0.0f, LF.top);
-              o = lane_off_bytes + ((unsigned)(int)fl << 3);
-              fr[e] = idx - fl;
-            }
-            tv[e] = *reinterpret_cast<const float2*>(lut_rows + (size_t)(32 * m + (r & 3) + 8 * (r >> 2)) * LF.row_bytes + o);
-          }
-#pragma unroll
-          for (int e = 0; e < kLutGroup; ++e) part = fmaf(Gn[kLutGroup * g + e], fmaf(tv[e].y, fr[e], tv[e].x), part);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      };
-      auto tile = [&](auto m_tag) {
-        constexpr int m = decltype(m_tag)::value;
-        f32x16& acc = m == 0 ? acc0 : acc1;
-        {
-          const f32x16 G = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ffrag_of(0, m), bfrag, f32x16{}, 0, 0, 0);
-          const f32x16 Bb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ffrag_of(1, m), bfrag, f32x16{}, 0, 0, 0);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = fmaf(G[r], acc[r], Bb[r]);   // FiLM in table units
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const f32x16 Gn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ffrag_of(2, m), bfrag, f32x16{}, 0, 0, 0);
-        if (ok_tile[m] == 0xffffffffu) lookups(m_tag, std::true_type{}, acc, Gn);
-        else lookups(m_tag, std::false_type{}, acc, Gn);
-      };
-      tile(std::integral_constant<int, 0>{});
-      tile(std::integral_constant<int, 1>{});
-      const float bias_n = fmaf(lt.w1, L.bsum[q0 + 1] - L.bsum[q0], L.bsum[q0]);
-      // the other half's partial sum by v_permlane32_swap (lanes < 32 of r[1] = lanes >= 32 of `part`): __shfl_xor builds its address from
-      // the lane id, a loop invariant the persistent loop would keep in a register (or in scratch) across every item
-      const auto swp = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
-      const float total_v = part + __uint_as_float(swp[1]) + (bias_n + w.newt_out_b[0]);   // valid where it is stored: half 0
-      const float add_v = add_in != nullptr ? add_in[(size_t)b * N + n_t] : 0.0f;
-      // the next item's raw rows travel by LDS-DMA, which only the issuing wave's VM counter tracks; the wait stands IN FRONT of the output
-      // store (the counter retires in order and counts stores too: behind it every wave would sit out its store's round trip to memory)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (wave == 7 && ctr != nullptr && lane_id() == 0) L.next2 = ticket;
-      if (half == 0) newt_out[(size_t)b * N + n_t] = add_in != nullptr ? add_v + total_v : total_v;
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (wave == 7 && ctr != nullptr && lane_id() == 0) L.next2 = ticket;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // B2: raw rows of the next item landed; this item's fragments, masks and bias sums are dead; next2 published
-    if (next >= total) break;
-    item = next;
-    next = ctr != nullptr ? __builtin_amdgcn_readfirstlane(L.next2) : next + (int)gridDim.x;
-  }
-
-  // the last workgroup to finish re-arms the counters for the next launch (every workgroup's last atomicAdd on ctr[0] is behind it)
-  if (ctr != nullptr && wave == 0 && lane_id() == 0) {
-    __threadfence();
-    if (atomicAdd(ctr + 1, 1) == (int)gridDim.x - 1) {
-      atomicExch(ctr, 0);
-      atomicExch(ctr + 1, 0);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Stand-alone HarmonicOscillator.forward (models/modules/generators.py:58-66): (B, N) upsampled F0 -> (B, 101, N) sines
 // times the anti-alias mask.  Same phase arithmetic as the fused kernel (fp64 prefix sum from the 32-sample carries, the
 // reference's fp32 rounding chain, arguments fl(fl(k phase) + shift)); one thread per sample, 101 coalesced stores.
@@ -2085,62 +1514,6 @@ __global__ void selftest_mfma_kernel(int32_t* bad) {
 
 bool weights_ok(const NwsWeights* w) { return w != nullptr && w->mixer_w && w->mixer_b; }
 
-// ---- persistent oscillator kernel: work counters and launch ----
-// One pair of ints per launch in flight: {next item, finished workgroups}; the kernel's last workgroup zeroes its pair.  64 pairs per device, handed
-// out round-robin (two launches overlap at most - the pipeline's two audio streams - so a pair is long re-armed when its turn comes again).  The pool
-// is allocated at a device's first use OUTSIDE a stream capture; while a stream is being captured the kernel runs with static striding (a graph
-// replayed on two streams at once must not share a counter), and before the pool exists the grid-launched kernel runs.
-constexpr int kPersistPairs = 64;
-struct PersistPool {
-  int* ctr = nullptr;
-  int cus = 0;
-  std::atomic<unsigned> turn{0};
-};
-PersistPool g_persist[64];
-std::mutex g_persist_mutex;
-
-// returns the pool of the calling thread's device, or nullptr when it cannot be had now (capturing and not yet allocated, or an error)
-PersistPool* persist_pool(hipStream_t st, bool& capturing) {
-  int d = 0;
-  if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) return nullptr;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
-  PersistPool& P = g_persist[d];
-  if (P.cus > 0) return &P;
-  if (capturing) return nullptr;
-  std::lock_guard<std::mutex> g(g_persist_mutex);
-  if (P.cus > 0) return &P;
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, d) != hipSuccess || prop.multiProcessorCount <= 0) return nullptr;
-  int* p = nullptr;
-  if (hipMalloc(&p, sizeof(int) * 2 * kPersistPairs) != hipSuccess) return nullptr;
-  if (hipMemset(p, 0, sizeof(int) * 2 * kPersistPairs) != hipSuccess) return nullptr;
-  P.ctr = p;
-  P.cus = prop.multiProcessorCount;
-  return &P;
-}
-
-// The FastNEWT hot path as the persistent kernel.  Returns false when it does not apply (the caller launches the grid kernel).
-template <int OPT, int PDBG = 0>
-bool launch_persistent(const NwsWeights& w, const float* f0, const double* carry, const float* phase_u, const float* rand_phase, const float* film,
-                       const float* add_in, int B, int T, float sample_rate, float* newt_out, hipStream_t st, int force_static = 0) {
-  if (w.mixer_frags == nullptr || (long long)((T + 1) / 2) * B >= (1ll << 30)) return false;
-  bool capturing = false;
-  PersistPool* P = persist_pool(st, capturing);
-  if (P == nullptr) return false;
-  const int total = ((T + 1) / 2) * B;
-  const int slots = 3 * P->cus;                 // three 8-wave workgroups per compute unit (80 registers, 43 KB of LDS)
-  if (total <= slots) return false;             // nothing to persist for: every workgroup would take one item
-  int* ctr = (capturing || force_static) ? nullptr : P->ctr + 2 * (P->turn.fetch_add(1) % kPersistPairs);
-  static unsigned long long attr_done = 0;
-  if (nws_first_use_on_device(attr_done))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(exciter_newt_persist_kernel<OPT, PDBG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ExcPLds));
-  const PersistWeights pw{w.mixer_frags, w.lut_pairs, w.newt_out_w, w.newt_out_b, w.exciter_bound, w.lut_size, w.lut_min};
-  static const int stagger = [] { const char* e = getenv("NWS_EXCITER_PERSIST_STAGGER"); return e ? atoi(e) : 0; }();
-  exciter_newt_persist_kernel<OPT, PDBG><<<slots, 512, sizeof(ExcPLds), st>>>(pw, f0, carry, phase_u, rand_phase, film, B, T, sample_rate, newt_out, add_in, ctr, stagger, P->cus);
-  return true;
-}
-
 }  // namespace
 
 extern "C" {
@@ -2279,11 +1652,6 @@ int nws_exciter_newt_add(const NwsWeights* w, const float* f0, const float* f0_u
         // fit beside a 251-register recurrence wave on a SIMD where one 8-wave workgroup = two waves per SIMD does; alone it is
         // LDS-bound at four workgroups = four waves per SIMD instead of six.  Same bits.)
         static const bool one_hop = [] { const char* e = getenv("NWS_EXCITER_HPB"); return e && e[0] == '1'; }();
-        // the persistent form of the default kernel (round 6; NWS_EXCITER_PERSIST=0 keeps the grid launch, =2 static striding): same bits
-        static const int persist = [] { const char* e = getenv("NWS_EXCITER_PERSIST"); return e ? atoi(e) : 1; }();
-        if (persist && opts == 0 && low_reg && !one_hop && f0_up == nullptr && exciter_out == nullptr &&
-            launch_persistent<kOptFilmMfma | kOptLowReg | kOptLiveFast>(*w, f0, carry, phase_u, rand_phase, film, add_in, B, T, sample_rate, newt_out, st, persist == 2)) {
-        } else
         if (one_hop && opts == 0) {
           const int xg1 = xcd_map && (long long)T * B >= 64 && (long long)T * B < (1ll << 31) ? T : 0;
           const dim3 g1 = xg1 ? dim3((unsigned)(T * B), 1) : dim3(T, B);
@@ -2341,39 +1709,21 @@ int nws_debug_exciter_newt(int variant, const NwsWeights* w, const float* f0, co
     NWS_CHECK_LAUNCH();
     return NWS_OK;
   }
-  if (variant >= 52 && variant <= 54) {   // timing: the persistent kernel without its barrier B1 / B2 / both (torn fragments: results wrong)
-    bool ok;
-    if (variant == 52) ok = launch_persistent<kOptFilmMfma | kOptLowReg | kOptLiveFast, 1>(*w, f0, carry, phase_u, rand_phase, film, nullptr, B, T, sample_rate, newt_out, st);
-    else if (variant == 53) ok = launch_persistent<kOptFilmMfma | kOptLowReg | kOptLiveFast, 2>(*w, f0, carry, phase_u, rand_phase, film, nullptr, B, T, sample_rate, newt_out, st);
-    else ok = launch_persistent<kOptFilmMfma | kOptLowReg | kOptLiveFast, 3>(*w, f0, carry, phase_u, rand_phase, film, nullptr, B, T, sample_rate, newt_out, st);
-    if (!ok) return NWS_ERR_UNSUPPORTED;
-    NWS_CHECK_LAUNCH();
-    return NWS_OK;
-  }
-  if (variant == 50 || variant == 51) {   // the persistent kernel: 50 counter-driven, 51 static striding
-    if (!launch_persistent<kOptFilmMfma | kOptLowReg | kOptLiveFast>(*w, f0, carry, phase_u, rand_phase, film, nullptr, B, T, sample_rate, newt_out, st, variant == 51))
-      return NWS_ERR_UNSUPPORTED;
-    NWS_CHECK_LAUNCH();
-    return NWS_OK;
-  }
-  if (variant >= 26 && variant <= 29) {   // timing: the product kernel without the global loads in front of its barrier (26: none; 27 / 28 / 29: no FiLM rows / no fragment DMA / no F0, carry, shifts)
+  if ((variant >= 21 && variant <= 24) || (variant >= 26 && variant <= 29)) {
+    // timing ablations of the PRODUCT configuration (results wrong by design): 21 no sines, 22 no table gathers, 23 no tail, 24 no mixer MFMAs;
+    // 26 no global load in front of the barrier, 27 / 28 / 29 no FiLM rows / no fragment DMA / no F0, carry, shifts (tools/exciter_ablate_product.py)
 #define NWS_ABL(D) exciter_newt_kernel<kModeLutPairsDiv6, D, 2, kOptFilmMfma | kOptLowReg><<<dim3((T + 1) / 2, B), 512, base, st>>>( \
         *w, f0, nullptr, carry, phase_u, rand_phase, film, T, sample_rate, nullptr, newt_out)
-    if (variant == 26) NWS_ABL(6);
-    else if (variant == 27) NWS_ABL(7);
-    else if (variant == 28) NWS_ABL(8);
-    else NWS_ABL(9);
-#undef NWS_ABL
-    NWS_CHECK_LAUNCH();
-    return NWS_OK;
-  }
-  if (variant >= 21 && variant <= 24) {   // timing ablations of the PRODUCT configuration (results wrong by design): 21 no sines, 22 no table gathers, 23 no tail, 24 no MFMAs
-#define NWS_ABL(D) exciter_newt_kernel<kModeLutPairsDiv6, D, 2, kOptFilmMfma | kOptLowReg><<<dim3((T + 1) / 2, B), 512, base, st>>>( \
-        *w, f0, nullptr, carry, phase_u, rand_phase, film, T, sample_rate, nullptr, newt_out)
-    if (variant == 21) NWS_ABL(1);
-    else if (variant == 22) NWS_ABL(2);
-    else if (variant == 23) NWS_ABL(3);
-    else NWS_ABL(4);
+    switch (variant) {
+      case 21: NWS_ABL(1); break;
+      case 22: NWS_ABL(2); break;
+      case 23: NWS_ABL(3); break;
+      case 24: NWS_ABL(4); break;
+      case 26: NWS_ABL(6); break;
+      case 27: NWS_ABL(7); break;
+      case 28: NWS_ABL(8); break;
+      default: NWS_ABL(9); break;
+    }
 #undef NWS_ABL
     NWS_CHECK_LAUNCH();
     return NWS_OK;
@@ -2391,13 +1741,6 @@ int nws_debug_exciter_newt(int variant, const NwsWeights* w, const float* f0, co
       case 26: NWS_OPT_LAUNCH(26); break;
       case 34: NWS_OPT_LAUNCH(34); break;   // kOptFilmMfma | kOptLowReg: the default kernel
       case 58: NWS_OPT_LAUNCH(58); break;   // ... | kOptHybrid | kOptHybridW | kOptLowReg: the opt-in hybrid-W kernel
-      case 34 + 1024: NWS_OPT_LAUNCH(34 + 1024); break;        // experiments: all-live copy of the K loop
-      case 34 + 1024 + 256: NWS_OPT_LAUNCH(34 + 1024 + 256); break;
-      case 34 + 128: NWS_OPT_LAUNCH(34 + 128); break;          // experiments: scalar sine chain
-      case 34 + 256: NWS_OPT_LAUNCH(34 + 256); break;          //              split by convert-back
-      case 34 + 512: NWS_OPT_LAUNCH(34 + 512); break;          //              split by mask
-      case 34 + 128 + 256: NWS_OPT_LAUNCH(34 + 128 + 256); break;
-      case 34 + 128 + 512: NWS_OPT_LAUNCH(34 + 128 + 512); break;
       case 98:                              // kOptFilmMfma | kOptLowReg | kOptFilmDma (`film` = records + aux entries of nws_debug_film_frags)
         exciter_newt_kernel<kModeLutPairsDiv6, 0, 2, 98><<<dim3((T + 1) / 2, B), 512, base, st>>>(
             *w, f0, nullptr, carry, phase_u, rand_phase, film, T, sample_rate, nullptr, newt_out, film, nullptr, 0, B * T);

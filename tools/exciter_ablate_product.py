@@ -19,7 +19,7 @@ m.newt = nws.FastNEWT(m.newt)
 B, T = int(os.environ.get("B", 64)), int(os.environ.get("T", 500))
 eng = m._engine
 w, _, _ = eng.weights()
-names = {44: "product", 21: "no sines", 22: "no table gathers", 23: "no tail", 24: "no MFMAs", 5: "prologue only", 26: "no loads before the barrier", 27: "no FiLM-row loads", 28: "no fragment DMA", 29: "no F0 / carry / shift loads", 50: "persistent (counter)", 51: "persistent (static)"}
+names = {44: "product", 21: "no sines", 22: "no table gathers", 23: "no tail", 24: "no MFMAs", 5: "prologue only", 26: "no loads before the barrier", 27: "no FiLM-row loads", 28: "no fragment DMA", 29: "no F0 / carry / shift loads"}
 if os.environ.get("ONLY"):
     names = {int(v): names[int(v)] for v in os.environ["ONLY"].split(",")}
 for kind in os.environ.get("KINDS", "rand,real").split(","):
