@@ -980,9 +980,9 @@ def main(hooks=None):
         # Headline roofline object: ALGORITHMIC first.  achieved = SURVEY 8(d)'s 14 969 flop/sample x the samples one launch
         # processes / the kernel's live average duration (HIP events on its launch stream inside the timed region); peak = the
         # dense fp16 MFMA peak, the pipe 86 % of that work (the 101 -> 64 contraction) runs on.  WHY the fraction is what it
-        # is rides along: the kernel is bound by VALU issue (sines, their fp16 split, table index math: every vector instruction
-        # occupies its SIMD's issue port for 2-8 cycles and an MFMA hides at most ~1/3 of its own duration under them,
-        # tools/ubench/valu_rate.hip), not by the matrix pipe or HBM.
+        # is rides along: the launch is POWER-limited (profiles/r06/exciter_ablations.txt: kernel cycles / duration = 1.9-2.1 GHz
+        # where its own timing ablations and the other kernels run at 2.3-2.5; without its mixer MFMAs -25 % cycles AND +26 % clock), its
+        # vector pipe ~0.8 busy at that clock (sines, their fp16 split, table index math) - not bound by the matrix pipe's rate or by HBM.
         algo_bytes = hbm_algorithmic_bytes(B, T)
         traffic = (dom.get("hbm") or {}).get("traffic")
         # The denominator is the kernel's ISOLATED duration (one stream, nothing beside it: HIP events around it on its launch stream,
@@ -1000,7 +1000,10 @@ def main(hooks=None):
                     if st.get("exciter_newt") else "live (no isolated measurement in this run)",
                     "frac_per_step": flops / (ms_per_step * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
                     "kernel_ms_live": k_ms, "frac_live": flops / (k_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS if k_ms == k_ms and k_ms > 0 else None,
-                    "limiter": "valu_issue",
+                    "limiter": "power",
+                    "clock_ghz": ((pmc or {}).get("kernels", {}).get("exciter_newt_kernel", {}) or {}).get("clock_ghz_during_pass"),
+                    "clock_ghz_other_kernels": {kn: round(kv["clock_ghz_during_pass"], 3) for kn, kv in ((pmc or {}).get("kernels", {}) or {}).items()
+                                                if kn in ("control_gru_kernel", "frame_mlps_wr_kernel") and kv.get("clock_ghz_during_pass")},
                     "valu_issue": dict(vi, frac_live=(vi["achieved"] * iso_ms / k_ms / (N_SIMD * MAX_CLOCK_GHZ))
                                        if (k_ms == k_ms and k_ms > 0) else None) if vi else None,
                     "mfma_f16_executed": dom.get("mfma_f16_executed"), "hbm": dom.get("hbm"),
@@ -1010,8 +1013,10 @@ def main(hooks=None):
                             "kernel_ms, the kernel's isolated one-stream duration (the rocprofv3 summary under profiles/ reproduces it); "
                             "frac_per_step = the same flop over ms_per_step; kernel_ms_live / frac_live = its average inside the pipelined "
                             "timed region, where it shares the chip with the neighbouring batch's kernels (longer than a step: not a "
-                            "roofline denominator); limiter: VALU issue (valu_issue.frac = VALU-busy SIMD-cycles per launch from the PMC "
-                            "pass / isolated duration / 1024 SIMDs x 2.4 GHz; frac_live over the live duration)"}
+                            "roofline denominator); limiter: power - clock_ghz = GRBM_GUI_ACTIVE cycles of the PMC pass / the isolated duration, "
+                            "against clock_ghz_other_kernels by the same arithmetic (profiles/r06/exciter_ablations.txt: the launch's timing "
+                            "ablations at 2.1-2.3 GHz); valu_issue.frac = VALU-busy SIMD-cycles per launch from the PMC pass / isolated "
+                            "duration / 1024 SIMDs x 2.4 GHz; frac_live over the live duration"}
         roofline_all = [dom]
         if st:
             roofline_all += [

@@ -19,9 +19,12 @@ extern "C" {
 int nws_debug_frame_mlps_kernel(int mode);
 int nws_debug_frame_mlps_probe(void* buf /* device, 4096 B: cycle timeline written by mode 2 + (6 << 8) */);
 
-/* Diagnostics only: ablation variants of the fused kernel for timing (1 no sin, 2 no LUT gather, 3 no shaper tail,
- * 4 no MFMA; 0 = product kernel; 5 / 6 prologue only; 10 + OPT bits: compile-time options of the two-hop kernel - 44 the product
- * kernel, 108 the same with the FiLM rows as fragment records by LDS-DMA).  Outputs of variants 1-6 are meaningless. */
+/* Diagnostics only: ablation variants of the fused kernel for timing.  0-4: the round-1 form (0 as is, 1 no sin, 2 no LUT gather, 3 no
+ * shaper tail, 4 no MFMA); 5 / 6 prologue only (product configuration / fragment records by LDS-DMA); 10 + OPT bits: compile-time options
+ * of the two-hop kernel - 44 the product kernel, 108 the same with the FiLM rows as fragment records by LDS-DMA; 21-24: the PRODUCT
+ * configuration without its sines / table gathers / tail / mixer MFMAs; 26-29: the product configuration without the global loads in front
+ * of its barrier (26 none of them; 27 / 28 / 29 no FiLM rows / no fragment DMA / no F0, carry, phase shifts) - tools/exciter_ablate.sh,
+ * profiles/r06/exciter_ablations.txt.  Outputs of variants 1-6 and 21-29 are meaningless. */
 int nws_debug_exciter_newt(int variant, const NwsWeights* w, const float* f0, const double* carry, const float* phase_u,
                            const float* rand_phase, const float* film, int B, int T, float sample_rate,
                            float* newt_out, void* stream);
