@@ -173,6 +173,11 @@ __device__ __forceinline__ float nws_add_scalar(float a, float b) {
   asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
+__device__ __forceinline__ float nws_fma_scalar(float a, float b, float c) {
+  float d;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 __device__ __forceinline__ float nws_sub_scalar(float a, float b) {
   float d;
   asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
@@ -241,3 +246,74 @@ __device__ __forceinline__ void nws_phase_carry_block(const float* __restrict__ 
 __device__ __forceinline__ float nws_swap_halves(float v) { return __shfl_xor(v, 32, 64); }
 
 __device__ __forceinline__ float nws_leaky_relu(float x) { return x > 0.0f ? x : 0.01f * x; }
+
+// ---------------------------------------------------------------------------------------------
+// Stateful streaming (stream.hip): the time-domain reverb of a hop as partial sums over 256 taps.  Shared with
+// control_gru.hip: in a hop of <= 256 emitted samples every part but the first reads reverb input of EARLIER hops only, so
+// those 124 partial sums per utterance run as extra workgroups of the hop's first launch (the recurrence) instead of as a
+// launch of their own behind the oscillator and noise kernels.
+// ---------------------------------------------------------------------------------------------
+#define NWS_STREAM_RING 65536   // reverb-input ring per utterance (>= 31 999 samples of history + the longest chunk)
+
+// pre-reverb value of emitted sample i of this step: oscillator branch [lo, hi) + noise branch (64 samples of residue first,
+// then this window's hops)
+struct NwsPreSrc {
+  const float* newt_w;
+  const float* noise_w;
+  const float* residue;
+  int Nw, lo, R0, noise_off;
+};
+__device__ __forceinline__ float nws_pre_value(const NwsPreSrc& P, int b, int i) {
+  const float nz = i < P.R0 ? P.residue[(size_t)b * 64 + i] : P.noise_w[(size_t)b * P.Nw + P.noise_off + i - P.R0];
+  return P.newt_w[(size_t)b * P.Nw + P.lo + i] + nz;
+}
+
+// sum_{i < 256} ir[256 p + i] * x[pos + j0 + tid - 1 - 256 p - i]  (tap m = 1 + 256 p + i, ir_[m] = ir[m-1]) for output
+// j0 + tid of utterance b.  x: the ring for samples of earlier steps, nws_pre_value() for this step's own (HIST: the caller
+// knows that the part reaches none of them and P is not read).  All 256 threads of the workgroup call it; xs: 512 floats,
+// hs: 256 floats of LDS, both 16-byte aligned.
+template <bool HIST>
+__device__ __forceinline__ float nws_stream_reverb_partial(const float* __restrict__ ring, const NwsPreSrc& P,
+                                                           const float* __restrict__ ir, int ir_len, int M, int b, int p, int j0,
+                                                           long long pos, int tid, float* xs, float* hs) {
+  const long long lo = pos + j0 - 256 - 256ll * p;         // xs[i] = x[lo + i], i < 512  (x before the stream's start is zero)
+  const float* rb = ring + (size_t)b * NWS_STREAM_RING;
+  for (int i = tid; i < 512; i += 256) {
+    const long long a = lo + i;
+    float v = 0.0f;
+    if (!HIST && a >= pos) v = a - pos < M ? nws_pre_value(P, b, (int)(a - pos)) : 0.0f;
+    else if (a >= 0 && a < pos) v = rb[a & (NWS_STREAM_RING - 1)];
+    xs[i] = v;
+  }
+  hs[tid] = 256 * p + tid < ir_len ? ir[256 * p + tid] : 0.0f;
+  __syncthreads();
+  // output j0 + tid: x index pos + j0 + tid - 1 - 256 p - i = lo + (tid + 255 - i)
+  float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll 8
+  for (int i = 0; i < 256; i += 4) {
+    const float4 h4 = *reinterpret_cast<const float4*>(&hs[i]);
+    // (scalar by construction: control_gru.hip keeps the SLP vectoriser, which packs the two chains into the swizzled
+    // v_pk_fma_f32 form the build refuses)
+    acc0 = nws_fma_scalar(h4.x, xs[tid + 255 - i], acc0);
+    acc1 = nws_fma_scalar(h4.y, xs[tid + 254 - i], acc1);
+    acc0 = nws_fma_scalar(h4.z, xs[tid + 253 - i], acc0);
+    acc1 = nws_fma_scalar(h4.w, xs[tid + 252 - i], acc1);
+  }
+  return nws_add_scalar(acc0, acc1);
+}
+
+// What the extra workgroups of the recurrence launch need (nws_control_gru_stream): parts 1 .. parts - 1 of every utterance.
+// The launch sits IN FRONT of the step's prep kernel, which is where the previous step's pending sample count is applied:
+// the position of this step's first sample is counters[0] + counters[2].
+struct NwsStreamReverbSide {
+  const float* ring;
+  const float* ir;
+  float* partial;               // [part][b][M]
+  const long long* counters;
+  int ir_len, M, B, parts;
+};
+
+// control_gru.hip: nws_control_gru_state with (side->parts - 1) * B extra workgroups (side may be NULL).  Internal to the library.
+extern "C" __attribute__((visibility("hidden"))) int nws_control_gru_stream(const NwsWeights* w, const float* control, int B, int C,
+                                                                            int T, const float* h0, float* gru_out, float* hT,
+                                                                            const NwsStreamReverbSide* side, void* stream);

@@ -11,11 +11,13 @@
 // workgroups per utterance (256 taps each) and reduced in a fixed order - 8.2 M MACs per utterance and hop instead of the
 // 64 000-point transform pair the overlap-add form paid every hop (round 2: p50 155 us, p99 379 us per 256-sample hop).
 // Chunks beyond 2048 samples take the four-step FFT of reverb_fft.hip on [history | new samples].
+#include <stdlib.h>
+
 #include "nws_common.h"
 
 namespace {
 
-constexpr int kRing = 65536;          // reverb-input ring per utterance (>= 31 999 history + the longest chunk)
+constexpr int kRing = NWS_STREAM_RING; // reverb-input ring per utterance (>= 31 999 history + the longest chunk)
 constexpr int kTapsPerPart = 256;
 constexpr int kMaxDirect = 2048;      // samples per step the time-domain reverb serves
 
@@ -148,18 +150,9 @@ __global__ __launch_bounds__(256) void stream_prep_kernel(const float* __restric
   if (!final && tid == 0) S[b] = cb[nch - 2];    // through the last emitted sample (128 Tw - 64)
 }
 
-// pre-reverb value of emitted sample i of this step: oscillator branch [lo, hi) + noise branch (64 samples of residue first,
-// then this window's hops)
-struct PreSrc {
-  const float* newt_w;
-  const float* noise_w;
-  const float* residue;
-  int Nw, lo, R0, noise_off;
-};
-__device__ __forceinline__ float pre_value(const PreSrc& P, int b, int i) {
-  const float nz = i < P.R0 ? P.residue[(size_t)b * 64 + i] : P.noise_w[(size_t)b * P.Nw + P.noise_off + i - P.R0];
-  return P.newt_w[(size_t)b * P.Nw + P.lo + i] + nz;
-}
+// pre-reverb value of emitted sample i of this step: nws_common.h (shared with the recurrence launch's extra workgroups)
+using PreSrc = NwsPreSrc;
+__device__ __forceinline__ float pre_value(const PreSrc& P, int b, int i) { return nws_pre_value(P, b, i); }
 
 // ---- combine (FFT path of long chunks only): pre-reverb signal -> linear buffer + the reverb-input ring -----------------
 __global__ __launch_bounds__(256) void stream_combine_kernel(PreSrc P, int M, float* __restrict__ pre, float* __restrict__ ring,
@@ -183,38 +176,28 @@ __global__ __launch_bounds__(256) void stream_reverb_partial_kernel(const float*
   __shared__ __attribute__((aligned(16))) float hs[256];
   const int p = blockIdx.x, j0 = blockIdx.y * 256, b = blockIdx.z;
   const int tid = threadIdx.x;
-  const long long pos = counters[0];
-  const long long lo = pos + j0 - 256 - 256ll * p;         // xs[i] = x[lo + i], i < 512  (x before the stream's start is zero)
-  const float* rb = ring + (size_t)b * kRing;
-  for (int i = tid; i < 512; i += 256) {
-    const long long a = lo + i;
-    float v = 0.0f;
-    if (a >= pos) v = a - pos < M ? pre_value(P, b, (int)(a - pos)) : 0.0f;
-    else if (a >= 0) v = rb[a & (kRing - 1)];
-    xs[i] = v;
-  }
-  hs[tid] = 256 * p + tid < ir_len ? ir[256 * p + tid] : 0.0f;
-  __syncthreads();
-  // output j0 + tid: x index pos + j0 + tid - 1 - 256 p - i = lo + (tid + 255 - i)
-  float acc0 = 0.0f, acc1 = 0.0f;
-#pragma unroll 8
-  for (int i = 0; i < 256; i += 4) {
-    const float4 h4 = *reinterpret_cast<const float4*>(&hs[i]);
-    acc0 = fmaf(h4.x, xs[tid + 255 - i], acc0);
-    acc1 = fmaf(h4.y, xs[tid + 254 - i], acc1);
-    acc0 = fmaf(h4.z, xs[tid + 253 - i], acc0);
-    acc1 = fmaf(h4.w, xs[tid + 252 - i], acc1);
-  }
-  if (j0 + tid < M) partial[((size_t)p * B + b) * M + j0 + tid] = acc0 + acc1;
+  const float v = nws_stream_reverb_partial<false>(ring, P, ir, ir_len, M, b, p, j0, counters[0], tid, xs, hs);
+  if (j0 + tid < M) partial[((size_t)p * B + b) * M + j0 + tid] = v;
 }
 
 // ---- reduce (fixed order) + dry signal + everything that closes the step: ring, noise residue, pending counters ----------
+// INLINE0 (hops of <= 256 samples: one block per utterance): parts 1 .. parts - 1 were summed by the extra workgroups of the
+// hop's FIRST launch (control_gru.hip) - they read earlier hops' reverb input only; part 0, the one that reaches this hop's own
+// samples, is summed here by the same code in the same order, so the result is bit-identical with the three-launch form
+template <bool INLINE0>
 __global__ __launch_bounds__(256) void stream_reverb_reduce_kernel(const float* __restrict__ partial, int parts, PreSrc P, int M, int B,
                                                                    int K, int final, int tail_from, float* __restrict__ out,
                                                                    float* __restrict__ pre_out, float* __restrict__ ring,
-                                                                   float* __restrict__ residue, long long* __restrict__ counters) {
+                                                                   float* __restrict__ residue, long long* __restrict__ counters,
+                                                                   const float* __restrict__ ir, int ir_len) {
   const int b = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
+  float part0 = 0.0f;
+  if (INLINE0) {
+    __shared__ __attribute__((aligned(16))) float xs[512];
+    __shared__ __attribute__((aligned(16))) float hs[256];
+    part0 = nws_stream_reverb_partial<false>(ring, P, ir, ir_len, M, b, 0, 0, counters[0], threadIdx.x, xs, hs);
+  }
   if (j < M) {
     const float dry = pre_value(P, b, j);
     // 125 independent loads: five fixed-order groups of 25 in flight at a time (one dependent load per iteration made this
@@ -224,11 +207,11 @@ __global__ __launch_bounds__(256) void stream_reverb_reduce_kernel(const float* 
     for (; p + 25 <= parts; p += 25) {
       float t[25];
 #pragma unroll
-      for (int q = 0; q < 25; ++q) t[q] = partial[((size_t)(p + q) * B + b) * M + j];
+      for (int q = 0; q < 25; ++q) t[q] = (INLINE0 && p + q == 0) ? part0 : partial[((size_t)(p + q) * B + b) * M + j];
 #pragma unroll
       for (int q = 0; q < 25; ++q) acc += t[q];
     }
-    for (; p < parts; ++p) acc += partial[((size_t)p * B + b) * M + j];
+    for (; p < parts; ++p) acc += (INLINE0 && p == 0) ? part0 : partial[((size_t)p * B + b) * M + j];
     out[(size_t)b * M + j] = dry + acc;
     pre_out[(size_t)b * M + j] = dry;
     ring[(size_t)b * kRing + ((counters[0] + j) & (kRing - 1))] = dry;
@@ -341,7 +324,16 @@ int nws_stream_step(const NwsWeights* w, const float* fir_design, const NwsRever
   if (M <= 0) return NWS_ERR_BAD_ARG;
   int rc;
   // 1. control encoder on the new frames (state carried)   2. frame MLPs
-  rc = nws_control_gru_state(w, control, B, C, K, first ? nullptr : F(L.h), F(L.gru_out), F(L.h_next), stream);
+  // a hop of <= 256 samples: the reverb's history parts (all but the first: earlier hops' reverb input only) ride on the
+  // recurrence launch as extra workgroups, off the hop's critical path (NWS_STREAM_SPLIT_REVERB=0: the three-launch form)
+  static const bool split_env = [] {
+    const char* e = getenv("NWS_STREAM_SPLIT_REVERB");
+    return e == nullptr || e[0] != '0';
+  }();
+  const bool split_reverb = split_env && M <= 256 && L.parts >= 2;
+  const NwsStreamReverbSide side{F(L.ring), ir, F(L.partial), counters, ir_len, M, B, L.parts};
+  rc = nws_control_gru_stream(w, control, B, C, K, first ? nullptr : F(L.h), F(L.gru_out), F(L.h_next), split_reverb ? &side : nullptr,
+                              stream);
   if (rc != NWS_OK) return rc;
   rc = nws_frame_mlps(w, F(L.gru_out), fir_design, B, K, nullptr, F(L.film_new), nullptr, F(L.fir_new), stream);
   if (rc != NWS_OK) return rc;
@@ -375,12 +367,17 @@ int nws_stream_step(const NwsWeights* w, const float* fir_design, const NwsRever
   const PreSrc P{F(L.newt_w), F(L.noise_w), F(L.residue), Nw, lo, R0, noise_off};
   float* pre = pre_out ? pre_out : F(L.pre);
   const int tail_from = noise_off + M - R0;
-  if (M <= kMaxDirect) {
+  if (split_reverb) {
+    // one launch: part 0 + the fixed-order reduction over it and the parts the first launch left, closing the step
+    stream_reverb_reduce_kernel<true><<<dim3(1, B), 256, 0, st>>>(F(L.partial), L.parts, P, M, B, K, final, tail_from, out, pre, F(L.ring),
+                                                                  F(L.residue), counters, ir, ir_len);
+    NWS_CHECK_LAUNCH();
+  } else if (M <= kMaxDirect) {
     // two launches: 125 x B workgroups of partial sums, then the fixed-order reduction that also closes the step
     stream_reverb_partial_kernel<<<dim3(L.parts, (M + 255) / 256, B), 256, 0, st>>>(F(L.ring), P, ir, ir_len, M, B, F(L.partial), counters);
     NWS_CHECK_LAUNCH();
-    stream_reverb_reduce_kernel<<<dim3((M + 255) / 256, B), 256, 0, st>>>(F(L.partial), L.parts, P, M, B, K, final, tail_from, out, pre,
-                                                                          F(L.ring), F(L.residue), counters);
+    stream_reverb_reduce_kernel<false><<<dim3((M + 255) / 256, B), 256, 0, st>>>(F(L.partial), L.parts, P, M, B, K, final, tail_from, out,
+                                                                                 pre, F(L.ring), F(L.residue), counters, ir, ir_len);
     NWS_CHECK_LAUNCH();
   } else {
     if (!plan || !reverb_tables || !reverb_spectrum || L.x_lin == 0) return NWS_ERR_BAD_ARG;

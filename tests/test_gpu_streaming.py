@@ -199,3 +199,23 @@ def test_stream_refresh_picks_up_a_weight_update_at_once(setup):
     assert not a._graphs                                   # dropped, to be re-captured on the new tables
     ya, yb = a.push(f0[:, :, 12:14], c[:, :, 12:14]), b.push(f0[:, :, 12:14], c[:, :, 12:14])
     assert torch.equal(ya, yb)
+
+
+def test_split_reverb_hop_is_bit_identical_with_the_three_launch_form(tmp_path):
+    """Hops of <= 256 samples sum the reverb's history parts as extra workgroups of the recurrence launch and part 0 inside the
+    closing kernel (csrc/stream.hip, NWS_STREAM_SPLIT_REVERB): same code, same order - the emitted samples of 40 graph-replayed
+    hops (final one included) must equal the three-launch form's bit for bit.  The switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "stream_hop_ab.py")
+    outs = []
+    for split in ("0", "1"):
+        path = str(tmp_path / f"hop_{split}.npy")
+        r = subprocess.run([sys.executable, tool, path, "3", "dump-only"], capture_output=True, text=True,
+                           env=dict(os.environ, NWS_STREAM_SPLIT_REVERB=split))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(path))
+    assert outs[0].shape == (3, 128 * 80) and np.isfinite(outs[0]).all() and rms(outs[0]) > 1e-3
+    assert np.array_equal(outs[0], outs[1])

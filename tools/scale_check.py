@@ -115,6 +115,9 @@ def main():
                 cells.append((1, gather, 1, name, d))
             name, d = run_cell(1, "copy", 1, steps, a.out, False, extra, tag="fake7", env_extra={"NWS_BENCH_FAKE_PEERS": "7"}, **kw)
             cells.append((1, "copy", 1, name, d))
+    def num(v, width):      # a single-GPU cell has no exchange: '-' rather than nan
+        return f"{v:{width}.3f}" if isinstance(v, (int, float)) and v == v else f"{'-':>{width}s}"
+
     print(f"{'cell':22s} {'ms/step':>9s} {'samples/s':>12s} {'efficiency':>10s} {'overlap':>8s} {'step/plain':>10s} {'rank spread':>11s} {'rccl world':>10s} "
           f"{'placement':>16s} selfcheck")
     best = {}
@@ -129,8 +132,8 @@ def main():
         pr = d.get("ms_per_step_per_rank") or [d["ms_per_step"]]
         pl = (d.get("config") or {}).get("placement") or {}
         where = f"{pl.get('mode', '-')}/{'ok' if pl.get('ok') else 'NOT OK'}/off{pl.get('queue_offset')}"
-        print(f"{name:22s} {d['ms_per_step']:9.4f} {d['value']:12.4g} {eff:10.3f} {ex.get('overlap_efficiency', float('nan')):8.3f} "
-              f"{ratio if ratio is not None else float('nan'):10.3f} {min(pr):5.3f}-{max(pr):5.3f} {str(ex.get('rccl_world_size', '-')):>10s} "
+        print(f"{name:22s} {d['ms_per_step']:9.4f} {d['value']:12.4g} {eff:10.3f} {num(ex.get('overlap_efficiency'), 8)} "
+              f"{num(ratio, 10)} {min(pr):5.3f}-{max(pr):5.3f} {str(ex.get('rccl_world_size', '-')):>10s} "
               f"{where:>16s} {sc.get('mismatching_all_ranks', sc.get('mismatching'))}")
         if n > 1 and (n not in best or d["value"] > best[n][1]):
             best[n] = (name, d["value"], eff)
