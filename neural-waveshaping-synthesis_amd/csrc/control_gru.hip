@@ -57,7 +57,7 @@ template <int DBG = 0>
 __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const float* __restrict__ control, int C, int T,
                                                              const float* __restrict__ h0, float* __restrict__ gru_out,
                                                              float* __restrict__ hT, const float* __restrict__ f0,
-                                                             double* __restrict__ carry, NwsStreamReverbSide side) {
+                                                             double* __restrict__ carry, NwsStreamSide side) {
   const int tid = threadIdx.x;
   __shared__ __attribute__((aligned(16))) float h_lds[2][kH];
   __shared__ __attribute__((aligned(16))) float x_lds[2][kXChunk];  // control[:, 0:2] of the current chunk of frames
@@ -70,12 +70,20 @@ __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const
     nws_phase_carry_block<4>(f0, nullptr, T, carry, blockIdx.x - gridDim.x / 2, tid, reinterpret_cast<double*>(&x_lds[0][0]));
     return;
   }
-  // streaming hop (nws_control_gru_stream): workgroups behind the B recurrences sum the reverb's history parts - 256 taps x
-  // 256 outputs each, earlier hops' reverb input only - beside the hop's critical path instead of on it (stream.hip)
-  if (side.ring != nullptr && blockIdx.x >= (unsigned)side.B) {
+  // streaming hop (nws_control_gru_stream): workgroups behind the B recurrences do what in the hop depends on nothing the hop
+  // computes - the per-utterance head (windows' first rows, phase carries), then the reverb's history parts (256 taps x 256
+  // outputs each, earlier hops' reverb input only) - beside the hop's critical path instead of on it (stream.hip, nws_common.h)
+  if ((side.ring != nullptr || side.f0_w != nullptr) && blockIdx.x >= (unsigned)side.B) {
+    int idx = blockIdx.x - side.B;
+    if (side.f0_w != nullptr) {
+      if (idx < side.B) {
+        nws_stream_head_block(side, idx, tid, reinterpret_cast<double*>(&x_lds[0][0]));
+        return;
+      }
+      idx -= side.B;
+    }
     __shared__ __attribute__((aligned(16))) float rv_xs[512];
     __shared__ __attribute__((aligned(16))) float rv_hs[256];
-    const int idx = blockIdx.x - side.B;
     const int sb = idx % side.B, p = 1 + idx / side.B;
     const long long pos = side.counters[0] + side.counters[2];
     const NwsPreSrc none{};
@@ -416,23 +424,32 @@ extern "C" int nws_control_gru_state(const NwsWeights* w, const float* control, 
                                      float* gru_out, float* hT, void* stream) {
   if (!w || !w->gru_w_ih || !w->gru_w_hh || !w->gru_b_ih || !w->gru_b_hh || !control || !gru_out) return NWS_ERR_BAD_ARG;
   if (B <= 0 || T <= 0 || C < 2) return NWS_ERR_BAD_ARG;
-  control_gru_kernel<0><<<B, 256, 0, (hipStream_t)stream>>>(*w, control, C, T, h0, gru_out, hT, nullptr, nullptr, NwsStreamReverbSide{});
+  control_gru_kernel<0><<<B, 256, 0, (hipStream_t)stream>>>(*w, control, C, T, h0, gru_out, hT, nullptr, nullptr, NwsStreamSide{});
   NWS_CHECK_LAUNCH();
   return NWS_OK;
 }
 
 // nws_control_gru_state + the reverb's history parts of a streaming hop as extra workgroups of the same launch (nws_common.h)
 extern "C" int nws_control_gru_stream(const NwsWeights* w, const float* control, int B, int C, int T, const float* h0,
-                                      float* gru_out, float* hT, const NwsStreamReverbSide* side, void* stream) {
+                                      float* gru_out, float* hT, const NwsStreamSide* side, void* stream) {
   if (!w || !w->gru_w_ih || !w->gru_w_hh || !w->gru_b_ih || !w->gru_b_hh || !control || !gru_out) return NWS_ERR_BAD_ARG;
   if (B <= 0 || T <= 0 || C < 2) return NWS_ERR_BAD_ARG;
-  NwsStreamReverbSide s{};
+  NwsStreamSide s{};
   int extra = 0;
-  if (side != nullptr && side->parts > 1) {
-    if (!side->ring || !side->ir || !side->partial || !side->counters || side->B != B || side->M <= 0 || side->M > 256)
-      return NWS_ERR_BAD_ARG;
+  if (side != nullptr) {
     s = *side;
-    extra = (side->parts - 1) * B;
+    if (s.B != B) return NWS_ERR_BAD_ARG;
+    if (s.f0_w != nullptr) {
+      if (!s.f0_new || !s.prev_f0 || !s.prev_film || !s.prev_fir || !s.S || !s.film_w || !s.fir_w || !s.carry || s.K != T)
+        return NWS_ERR_BAD_ARG;
+      extra += B;
+    }
+    if (s.ring != nullptr && s.parts > 1) {
+      if (!s.ir || !s.partial || !s.counters || s.M <= 0 || s.M > 256) return NWS_ERR_BAD_ARG;
+      extra += (s.parts - 1) * B;
+    } else {
+      s.ring = nullptr;
+    }
   }
   control_gru_kernel<0><<<B + extra, 256, 0, (hipStream_t)stream>>>(*w, control, C, T, h0, gru_out, hT, nullptr, nullptr, s);
   NWS_CHECK_LAUNCH();
@@ -444,7 +461,7 @@ extern "C" int nws_control_gru_carry(const NwsWeights* w, const float* control, 
   if (!w || !w->gru_w_ih || !w->gru_w_hh || !w->gru_b_ih || !w->gru_b_hh || !control || !gru_out || !f0 || !carry_out)
     return NWS_ERR_BAD_ARG;
   if (B <= 0 || T <= 0 || C < 2) return NWS_ERR_BAD_ARG;
-  control_gru_kernel<0><<<2 * B, 256, 0, (hipStream_t)stream>>>(*w, control, C, T, nullptr, gru_out, nullptr, f0, carry_out, NwsStreamReverbSide{});
+  control_gru_kernel<0><<<2 * B, 256, 0, (hipStream_t)stream>>>(*w, control, C, T, nullptr, gru_out, nullptr, f0, carry_out, NwsStreamSide{});
   NWS_CHECK_LAUNCH();
   return NWS_OK;
 }
@@ -452,7 +469,7 @@ extern "C" int nws_control_gru_carry(const NwsWeights* w, const float* control, 
 extern "C" int nws_debug_control_gru(int variant, const NwsWeights* w, const float* control, int B, int C, int T,
                                      float* gru_out, void* stream) {
   if (!w || !w->gru_w_hh || !control || !gru_out || B <= 0 || T <= 0 || C < 2) return NWS_ERR_BAD_ARG;
-#define NWS_GRU_DBG(V) control_gru_kernel<V><<<B, 256, 0, (hipStream_t)stream>>>(*w, control, C, T, nullptr, gru_out, nullptr, nullptr, nullptr, NwsStreamReverbSide{})
+#define NWS_GRU_DBG(V) control_gru_kernel<V><<<B, 256, 0, (hipStream_t)stream>>>(*w, control, C, T, nullptr, gru_out, nullptr, nullptr, nullptr, NwsStreamSide{})
   switch (variant) {
     case 0: NWS_GRU_DBG(0); break;
     case 1: NWS_GRU_DBG(1); break;

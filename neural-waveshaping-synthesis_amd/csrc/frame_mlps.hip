@@ -446,7 +446,15 @@ __device__ __forceinline__ void hidden_w8(MlpLds16& L, const f16x8* __restrict__
 template <bool TAPS>
 __global__ __launch_bounds__(512, 4) void frame_mlps16_kernel(NwsWeights w, const float* __restrict__ gru_out, int T,
                                                                 float* __restrict__ emb_out, float* __restrict__ film_out,
-                                                                float* __restrict__ H_out, float* __restrict__ fir_out) {
+                                                                float* __restrict__ H_out, float* __restrict__ fir_out,
+                                                                int out_T, int out_off, NwsStreamNoiseWin win) {
+  // out_T / out_off: the FiLM and FIR-tap rows of frame t go to row out_off + t of windows of out_T rows per utterance (T, 0: the
+  // plain (B, T, .) outputs).  Streaming hop (nws_frame_mlps_stream): one more workgroup behind the B utterances moves the shared
+  // noise window on and applies the previous hop's pending counters (nws_common.h)
+  if (win.nzwin != nullptr && blockIdx.y == gridDim.y - 1) {
+    nws_stream_noise_window_block<512>(win, threadIdx.x);
+    return;
+  }
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   MlpLds16& L = *reinterpret_cast<MlpLds16*>(smem_raw);
   char* const E = L.xt[0][0];
@@ -516,12 +524,12 @@ __global__ __launch_bounds__(512, 4) void frame_mlps16_kernel(NwsWeights w, cons
   load_frags<8>(A, F + frag_map(4).base, mt + 4, lane);
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] += acc[r];
-    store_tile_frame_major(patch, v, lane, film_out + ((size_t)b * T + t0) * NWS_FILM_CH + 32 * mt, NWS_FILM_CH, frames_valid);
+    store_tile_frame_major(patch, v, lane, film_out + ((size_t)b * out_T + out_off + t0) * NWS_FILM_CH + 32 * mt, NWS_FILM_CH, frames_valid);
     load_lane_params(v, w.newt_mlp_b[3], mt + 4, lane);
     mma_tile1<8>(A, X, lane, acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] += acc[r];
-    store_tile_frame_major(patch, v, lane, film_out + ((size_t)b * T + t0) * NWS_FILM_CH + 32 * (mt + 4), NWS_FILM_CH,
+    store_tile_frame_major(patch, v, lane, film_out + ((size_t)b * out_T + out_off + t0) * NWS_FILM_CH + 32 * (mt + 4), NWS_FILM_CH,
                            frames_valid);
   } else {
     // H (129 bands): M-tiles 0..3 from Y -> Z channels 0..127; wave 4 also M-tile 4 = row 128 (129..143 stay zero)
@@ -566,7 +574,7 @@ __global__ __launch_bounds__(512, 4) void frame_mlps16_kernel(NwsWeights w, cons
     mma_tile1<9>(A9, Z, lane, acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = acc[r];
-    store_tile_frame_major(patch, v, lane, fir_out + ((size_t)b * T + t0) * NWS_FIR_HALF + 32 * mt, NWS_FIR_HALF, frames_valid);
+    store_tile_frame_major(patch, v, lane, fir_out + ((size_t)b * out_T + out_off + t0) * NWS_FIR_HALF + 32 * mt, NWS_FIR_HALF, frames_valid);
   }
 }
 
@@ -1399,13 +1407,33 @@ int nws_frame_mlps(const NwsWeights* w, const float* gru_out, const float* fir_d
   const dim3 grid((T + kFT - 1) / kFT, B);
   if (w->mlp_frags != nullptr && !emb_out && !H_out)
     frame_mlps16_kernel<false><<<grid, 512, sizeof(MlpLds16), (hipStream_t)stream>>>(*w, gru_out, T, nullptr, film_out,
-                                                                                       nullptr, fir_out);
+                                                                                       nullptr, fir_out, T, 0, NwsStreamNoiseWin{});
   else if (w->mlp_frags != nullptr)
     frame_mlps16_kernel<true><<<grid, 512, sizeof(MlpLds16), (hipStream_t)stream>>>(*w, gru_out, T, emb_out, film_out,
-                                                                                      H_out, fir_out);
+                                                                                      H_out, fir_out, T, 0, NwsStreamNoiseWin{});
   else
     frame_mlps_kernel<<<grid, 256, sizeof(MlpLds), (hipStream_t)stream>>>(*w, gru_out, fir_design, T, emb_out, film_out,
                                                                           H_out, fir_out);
+  NWS_CHECK_LAUNCH();
+  return NWS_OK;
+}
+
+// Streaming hop (stream.hip): the 32-frame tile kernel on the T <= 32 new frames of every utterance; rows land in the windows the
+// oscillator / noise kernels read, one more workgroup runs the hop's shared head (nws_common.h)
+int nws_frame_mlps_stream(const NwsWeights* w, const float* gru_out, int B, int T, float* film_w, float* fir_w, int out_T,
+                          int out_off, const NwsStreamNoiseWin* win, void* stream) {
+  if (!w || !gru_out || !film_w || !fir_w || !win || !win->nzwin || !win->counters || B <= 0 || T <= 0 || out_off < 0 ||
+      out_off + T > out_T)
+    return NWS_ERR_BAD_ARG;
+  if (w->mlp_frags == nullptr || T > kFT || B > 65534) return NWS_ERR_UNSUPPORTED;
+  static unsigned long long attr_devices = 0;
+  if (nws_first_use_on_device(attr_devices)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_mlps16_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpLds16));
+    if (e != hipSuccess) return (int)e;
+  }
+  frame_mlps16_kernel<false><<<dim3(1, B + 1), 512, sizeof(MlpLds16), (hipStream_t)stream>>>(*w, gru_out, T, nullptr, film_w, nullptr,
+                                                                                              fir_w, out_T, out_off, *win);
   NWS_CHECK_LAUNCH();
   return NWS_OK;
 }

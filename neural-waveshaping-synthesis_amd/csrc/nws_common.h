@@ -302,18 +302,107 @@ __device__ __forceinline__ float nws_stream_reverb_partial(const float* __restri
   return nws_add_scalar(acc0, acc1);
 }
 
-// What the extra workgroups of the recurrence launch need (nws_control_gru_stream): parts 1 .. parts - 1 of every utterance.
-// The launch sits IN FRONT of the step's prep kernel, which is where the previous step's pending sample count is applied:
-// the position of this step's first sample is counters[0] + counters[2].
-struct NwsStreamReverbSide {
+// What the extra workgroups of the recurrence launch need (nws_control_gru_stream).  The launch sits IN FRONT of the
+// workgroup that applies the previous step's pending sample count (the step's second launch): the position of this step's first
+// sample is counters[0] + counters[2].
+// * parts 1 .. parts - 1 of the reverb of every utterance (ring != NULL; M <= 256);
+// * the per-utterance HEAD of the hop (f0_w != NULL): F0 window [previous frame | new frames], row 0 of the FiLM and FIR-tap windows
+//   from the previous hop's last frame (rows 1 .. K are written by the frame-MLP kernel itself), phase carries spliced with the
+//   carried phase sum.  Everything it reads is an input of the hop or state of the previous one.
+struct NwsStreamSide {
+  // reverb history
   const float* ring;
   const float* ir;
   float* partial;               // [part][b][M]
   const long long* counters;
   int ir_len, M, B, parts;
+  // head
+  const float* f0_new;          // (B, K)
+  float* prev_f0;
+  const float* prev_film;
+  const float* prev_fir;
+  double* S;
+  float* f0_w;
+  float* film_w;
+  float* fir_w;
+  double* carry;
+  int K, first, final;
 };
 
-// control_gru.hip: nws_control_gru_state with (side->parts - 1) * B extra workgroups (side may be NULL).  Internal to the library.
+// 256 threads; wave_tot: 4 doubles of LDS
+__device__ __forceinline__ void nws_stream_head_block(const NwsStreamSide& H, int b, int tid, double* wave_tot) {
+  const int K = H.K, Tw = H.first ? K : K + 1, off = H.first ? 0 : 1;
+  for (int i = tid; i < Tw; i += 256) H.f0_w[(size_t)b * Tw + i] = (i < off) ? H.prev_f0[b] : H.f0_new[(size_t)b * K + i - off];
+  if (off) {
+    for (int c = tid; c < NWS_FILM_CH; c += 256) H.film_w[(size_t)b * Tw * NWS_FILM_CH + c] = H.prev_film[(size_t)b * NWS_FILM_CH + c];
+    for (int c = tid; c < NWS_FIR_HALF; c += 256) H.fir_w[(size_t)b * Tw * NWS_FIR_HALF + c] = H.prev_fir[(size_t)b * NWS_FIR_HALF + c];
+  }
+  __syncthreads();   // the F0 window is complete (global writes of this block are visible to it) and prev_f0 has been consumed
+  if (tid == 0) H.prev_f0[b] = H.f0_new[(size_t)b * K + K - 1];
+  // exclusive float64 prefix sums of the window's upsampled F0 at 32-sample granularity (the lerp clamps at the window edges;
+  // those 64 + 64 samples are only emitted at the true ends of the stream)
+  nws_phase_carry_block<4>(H.f0_w, nullptr, Tw, H.carry, b, tid, wave_tot);
+  __syncthreads();
+  const int nch = 4 * Tw;
+  double* cb = H.carry + (size_t)b * nch;
+  if (!H.first) {
+    // sample 64 of the window is the first one not yet emitted: its running sum must continue the carried one.  Sums of
+    // fp32 values in fp64 are exact, so the spliced carries are bit-identical to the one-shot forward's
+    const double base = cb[2], s0 = H.S[b];
+    __syncthreads();
+    for (int c = tid; c < nch; c += 256) cb[c] = s0 + (cb[c] - base);
+    __syncthreads();
+  }
+  if (!H.final && tid == 0) H.S[b] = cb[nch - 2];    // through the last emitted sample (128 Tw - 64)
+}
+
+// The shared part of a hop's head, one workgroup of NT threads (an extra workgroup of the frame-MLP launch in the fused hop,
+// block B of stream_prep_kernel otherwise): applies the previous step's pending sample / frame counts - nobody else in the
+// launch reads the counters - and moves the noise window on.
+struct NwsStreamNoiseWin {
+  float* nzwin;
+  const float* noise_new;
+  const float* noise_all;
+  long long* counters;
+  int nz_shift, nz_keep, n_new, noise_all_len, first, K;
+};
+template <int NT>
+__device__ __forceinline__ void nws_stream_noise_window_block(const NwsStreamNoiseWin& Z, int tid) {
+  const int Tw = Z.first ? Z.K : Z.K + 1;
+  const long long F = Z.counters[1] + Z.counters[3];
+  __syncthreads();   // every thread has read the old values
+  if (tid == 0) {
+    Z.counters[0] += Z.counters[2];
+    Z.counters[1] = F;
+    Z.counters[2] = 0;
+    Z.counters[3] = 0;
+  }
+  if (Z.noise_all != nullptr) {
+    // injected stream (parity runs): the window starts at absolute sample max(0, 128 (A0 - 1)), A0 = first frame of the window
+    const long long A0 = Z.first ? 0 : F - 1;
+    const long long start = A0 <= 0 ? 0 : 128 * (A0 - 1);
+    const int want = 128 * (Tw + 1) + 1;
+    for (int i = tid; i < want; i += NT) Z.nzwin[i] = start + i < Z.noise_all_len ? Z.noise_all[start + i] : 0.0f;
+  } else {
+    // drawn stream: keep the last nz_keep samples (shifted down by nz_shift), append the n_new fresh draws
+    for (int i0 = 0; i0 < Z.nz_keep; i0 += NT) {
+      const int i = i0 + tid;
+      const float v = i < Z.nz_keep ? Z.nzwin[i + Z.nz_shift] : 0.0f;
+      __syncthreads();
+      if (i < Z.nz_keep) Z.nzwin[i] = v;
+      __syncthreads();
+    }
+    for (int i = tid; i < Z.n_new; i += NT) Z.nzwin[Z.nz_keep + i] = Z.noise_new[i];
+  }
+}
+
+// control_gru.hip: nws_control_gru_state with the extra workgroups `side` asks for (NULL: none).  Internal to the library.
 extern "C" __attribute__((visibility("hidden"))) int nws_control_gru_stream(const NwsWeights* w, const float* control, int B, int C,
                                                                             int T, const float* h0, float* gru_out, float* hT,
-                                                                            const NwsStreamReverbSide* side, void* stream);
+                                                                            const NwsStreamSide* side, void* stream);
+// frame_mlps.hip: the 32-frame tile kernel on T <= 32 new frames per utterance, FiLM / FIR-tap rows written as rows out_off .. of
+// windows of out_T rows per utterance, + one extra workgroup running nws_stream_noise_window_block.  NWS_ERR_UNSUPPORTED if the
+// fragment tables are missing or T > 32.  Internal to the library.
+extern "C" __attribute__((visibility("hidden"))) int nws_frame_mlps_stream(const NwsWeights* w, const float* gru_out, int B, int T,
+                                                                           float* film_w, float* fir_w, int out_T, int out_off,
+                                                                           const NwsStreamNoiseWin* win, void* stream);

@@ -90,31 +90,8 @@ __global__ __launch_bounds__(256) void stream_prep_kernel(const float* __restric
   if (b == B) {
     // positions advance here, at the head of the NEXT step: the previous step's last kernel left its sample / frame counts as
     // pending (its other workgroups were still reading the position).  Nobody else in this launch reads the counters.
-    const long long F = counters[1] + counters[3];
-    __syncthreads();   // every thread has read the old values
-    if (tid == 0) {
-      counters[0] += counters[2];
-      counters[1] = F;
-      counters[2] = 0;
-      counters[3] = 0;
-    }
-    if (noise_all != nullptr) {
-      // injected stream (parity runs): the window starts at absolute sample max(0, 128 (A0 - 1)), A0 = first frame of the window
-      const long long A0 = first ? 0 : F - 1;
-      const long long start = A0 <= 0 ? 0 : 128 * (A0 - 1);
-      const int want = 128 * (Tw + 1) + 1;
-      for (int i = tid; i < want; i += 256) nzwin[i] = start + i < noise_all_len ? noise_all[start + i] : 0.0f;
-    } else {
-      // drawn stream: keep the last nz_keep samples (shifted down by nz_shift), append the n_new fresh draws
-      for (int i0 = 0; i0 < nz_keep; i0 += 256) {
-        const int i = i0 + tid;
-        const float v = i < nz_keep ? nzwin[i + nz_shift] : 0.0f;
-        __syncthreads();
-        if (i < nz_keep) nzwin[i] = v;
-        __syncthreads();
-      }
-      for (int i = tid; i < n_new; i += 256) nzwin[nz_keep + i] = noise_new[i];
-    }
+    const NwsStreamNoiseWin Z{nzwin, noise_new, noise_all, counters, nz_shift, nz_keep, n_new, noise_all_len, first, K};
+    nws_stream_noise_window_block<256>(Z, tid);
     return;
   }
   // window = [previous frame] + new frames
@@ -184,13 +161,29 @@ __global__ __launch_bounds__(256) void stream_reverb_partial_kernel(const float*
 // INLINE0 (hops of <= 256 samples: one block per utterance): parts 1 .. parts - 1 were summed by the extra workgroups of the
 // hop's FIRST launch (control_gru.hip) - they read earlier hops' reverb input only; part 0, the one that reaches this hop's own
 // samples, is summed here by the same code in the same order, so the result is bit-identical with the three-launch form
+struct StreamTail {
+  const float* film_w;
+  const float* fir_w;
+  const float* h_next;
+  float* prev_film;
+  float* prev_fir;
+  float* h;
+  int Tw;
+};
 template <bool INLINE0>
 __global__ __launch_bounds__(256) void stream_reverb_reduce_kernel(const float* __restrict__ partial, int parts, PreSrc P, int M, int B,
                                                                    int K, int final, int tail_from, float* __restrict__ out,
                                                                    float* __restrict__ pre_out, float* __restrict__ ring,
                                                                    float* __restrict__ residue, long long* __restrict__ counters,
-                                                                   const float* __restrict__ ir, int ir_len) {
+                                                                   const float* __restrict__ ir, int ir_len, StreamTail tail) {
   const int b = blockIdx.y;
+  if (INLINE0 && tail.film_w != nullptr) {
+    // fused hop (no prep kernel): what the next hop's head needs of this one - the last frame's FiLM row and FIR taps, the GRU state
+    const int c = threadIdx.x;
+    tail.prev_film[(size_t)b * NWS_FILM_CH + c] = tail.film_w[((size_t)b * tail.Tw + tail.Tw - 1) * NWS_FILM_CH + c];
+    if (c < NWS_FIR_HALF) tail.prev_fir[(size_t)b * NWS_FIR_HALF + c] = tail.fir_w[((size_t)b * tail.Tw + tail.Tw - 1) * NWS_FIR_HALF + c];
+    if (c < NWS_HIDDEN) tail.h[(size_t)b * NWS_HIDDEN + c] = tail.h_next[(size_t)b * NWS_HIDDEN + c];
+  }
   const int j = blockIdx.x * 256 + threadIdx.x;
   float part0 = 0.0f;
   if (INLINE0) {
@@ -331,24 +324,63 @@ int nws_stream_step(const NwsWeights* w, const float* fir_design, const NwsRever
     return e == nullptr || e[0] != '0';
   }();
   const bool split_reverb = split_env && M <= 256 && L.parts >= 2;
-  const NwsStreamReverbSide side{F(L.ring), ir, F(L.partial), counters, ir_len, M, B, L.parts};
-  rc = nws_control_gru_stream(w, control, B, C, K, first ? nullptr : F(L.h), F(L.gru_out), F(L.h_next), split_reverb ? &side : nullptr,
-                              stream);
-  if (rc != NWS_OK) return rc;
-  rc = nws_frame_mlps(w, F(L.gru_out), fir_design, B, K, nullptr, F(L.film_new), nullptr, F(L.fir_new), stream);
-  if (rc != NWS_OK) return rc;
-  // 3. windows, spliced carries, state hand-over, noise window
+  // ... and then nothing is left for a prep launch either (NWS_STREAM_FUSE_HEAD=0 keeps it): the per-utterance head (F0 window, first
+  // rows of the FiLM / tap windows, spliced carries) depends on nothing the hop computes - more workgroups of the recurrence launch;
+  // the frame-MLP kernel writes its rows straight into the windows and carries one workgroup for the shared noise window and the
+  // pending counters; the closing kernel hands the last frame and the GRU state to the next hop.  Five launches.
+  static const bool head_env = [] {
+    const char* e = getenv("NWS_STREAM_FUSE_HEAD");
+    return e == nullptr || e[0] != '0';
+  }();
+  const bool fuse_head = head_env && split_reverb && K <= 32 && w->mlp_frags != nullptr;
   const long long nz_start = nws_stream_noise_start(first, frames_seen);
   const long long have = first ? 0 : 128 * (frames_seen - 1) + 129;       // absolute end of what the window holds now
   const int n_new = noise_new ? nws_stream_noise_draws(K, first, frames_seen) : 0;
   const int nz_keep = first ? 0 : (int)(have - nz_start);
   const int nz_shift = first ? 0 : (int)(nz_start - nz_prev_start);
   if (nz_shift < 0 || nz_keep < 0) return NWS_ERR_BAD_ARG;
-  stream_prep_kernel<<<B + 1, 256, 0, st>>>(f0, F(L.film_new), F(L.fir_new), K, first, final, B, F(L.prev_f0), F(L.prev_film),
-                                           F(L.prev_fir), reinterpret_cast<double*>(base + L.S), F(L.h), F(L.h_next), F(L.f0_w),
-                                           F(L.film_w), F(L.fir_w), reinterpret_cast<double*>(base + L.carry), F(L.nzwin), noise_new,
-                                           nz_shift, nz_keep, n_new, noise_all, noise_all_len, counters);
-  NWS_CHECK_LAUNCH();
+  NwsStreamSide side{};
+  side.B = B;
+  if (split_reverb) {
+    side.ring = F(L.ring);
+    side.ir = ir;
+    side.partial = F(L.partial);
+    side.counters = counters;
+    side.ir_len = ir_len;
+    side.M = M;
+    side.parts = L.parts;
+  }
+  if (fuse_head) {
+    side.f0_new = f0;
+    side.prev_f0 = F(L.prev_f0);
+    side.prev_film = F(L.prev_film);
+    side.prev_fir = F(L.prev_fir);
+    side.S = reinterpret_cast<double*>(base + L.S);
+    side.f0_w = F(L.f0_w);
+    side.film_w = F(L.film_w);
+    side.fir_w = F(L.fir_w);
+    side.carry = reinterpret_cast<double*>(base + L.carry);
+    side.K = K;
+    side.first = first;
+    side.final = final;
+  }
+  rc = nws_control_gru_stream(w, control, B, C, K, first ? nullptr : F(L.h), F(L.gru_out), F(L.h_next), split_reverb ? &side : nullptr,
+                              stream);
+  if (rc != NWS_OK) return rc;
+  if (fuse_head) {
+    const NwsStreamNoiseWin Z{F(L.nzwin), noise_new, noise_all, counters, nz_shift, nz_keep, n_new, noise_all_len, first, K};
+    rc = nws_frame_mlps_stream(w, F(L.gru_out), B, K, F(L.film_w), F(L.fir_w), Tw, first ? 0 : 1, &Z, stream);
+    if (rc != NWS_OK) return rc;
+  } else {
+    rc = nws_frame_mlps(w, F(L.gru_out), fir_design, B, K, nullptr, F(L.film_new), nullptr, F(L.fir_new), stream);
+    if (rc != NWS_OK) return rc;
+    // 3. windows, spliced carries, state hand-over, noise window
+    stream_prep_kernel<<<B + 1, 256, 0, st>>>(f0, F(L.film_new), F(L.fir_new), K, first, final, B, F(L.prev_f0), F(L.prev_film),
+                                             F(L.prev_fir), reinterpret_cast<double*>(base + L.S), F(L.h), F(L.h_next), F(L.f0_w),
+                                             F(L.film_w), F(L.fir_w), reinterpret_cast<double*>(base + L.carry), F(L.nzwin), noise_new,
+                                             nz_shift, nz_keep, n_new, noise_all, noise_all_len, counters);
+    NWS_CHECK_LAUNCH();
+  }
   // 4. oscillator + waveshapers on the window   5. noise branch on the same window
   rc = nws_exciter_newt(w, F(L.f0_w), nullptr, reinterpret_cast<double*>(base + L.carry), phase_u, rand_phase, F(L.film_w), B, Tw,
                         sample_rate, nullptr, F(L.newt_w), stream);
@@ -369,15 +401,18 @@ int nws_stream_step(const NwsWeights* w, const float* fir_design, const NwsRever
   const int tail_from = noise_off + M - R0;
   if (split_reverb) {
     // one launch: part 0 + the fixed-order reduction over it and the parts the first launch left, closing the step
+    StreamTail tail{};
+    if (fuse_head) tail = StreamTail{F(L.film_w), F(L.fir_w), F(L.h_next), F(L.prev_film), F(L.prev_fir), F(L.h), Tw};
     stream_reverb_reduce_kernel<true><<<dim3(1, B), 256, 0, st>>>(F(L.partial), L.parts, P, M, B, K, final, tail_from, out, pre, F(L.ring),
-                                                                  F(L.residue), counters, ir, ir_len);
+                                                                  F(L.residue), counters, ir, ir_len, tail);
     NWS_CHECK_LAUNCH();
   } else if (M <= kMaxDirect) {
     // two launches: 125 x B workgroups of partial sums, then the fixed-order reduction that also closes the step
     stream_reverb_partial_kernel<<<dim3(L.parts, (M + 255) / 256, B), 256, 0, st>>>(F(L.ring), P, ir, ir_len, M, B, F(L.partial), counters);
     NWS_CHECK_LAUNCH();
     stream_reverb_reduce_kernel<false><<<dim3((M + 255) / 256, B), 256, 0, st>>>(F(L.partial), L.parts, P, M, B, K, final, tail_from, out,
-                                                                                 pre, F(L.ring), F(L.residue), counters, ir, ir_len);
+                                                                                 pre, F(L.ring), F(L.residue), counters, ir, ir_len,
+                                                                                 StreamTail{});
     NWS_CHECK_LAUNCH();
   } else {
     if (!plan || !reverb_tables || !reverb_spectrum || L.x_lin == 0) return NWS_ERR_BAD_ARG;
