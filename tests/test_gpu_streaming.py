@@ -201,10 +201,11 @@ def test_stream_refresh_picks_up_a_weight_update_at_once(setup):
     assert torch.equal(ya, yb)
 
 
-def test_split_reverb_hop_is_bit_identical_with_the_three_launch_form(tmp_path):
-    """Hops of <= 256 samples sum the reverb's history parts as extra workgroups of the recurrence launch and part 0 inside the
-    closing kernel (csrc/stream.hip, NWS_STREAM_SPLIT_REVERB): same code, same order - the emitted samples of 40 graph-replayed
-    hops (final one included) must equal the three-launch form's bit for bit.  The switch is read once per process."""
+def test_fused_hop_is_bit_identical_with_the_seven_launch_form(tmp_path):
+    """Hops of <= 256 samples run in five launches (csrc/stream.hip): the reverb's history parts and the per-utterance head as extra
+    workgroups of the recurrence launch, frame-MLP rows straight into the windows, reverb part 0 + hand-over inside the closing
+    kernel.  Same code, same order of sums: the emitted samples of 40 graph-replayed hops (final one included) must equal the
+    seven-launch form's (NWS_STREAM_SPLIT_REVERB=0) bit for bit.  The switches are read once per process."""
     import os
     import subprocess
     import sys
