@@ -1,5 +1,6 @@
 export TMPDIR=/tmp
-mkdir -p gpurun_out/s4
-timeout 300 python -m pytest tests/test_gpu_streaming.py -x -q -p no:cacheprovider 2>&1 | tail -3
-NWS_STREAM_FUSE_HEAD=0 timeout 300 python -m pytest tests/test_gpu_streaming.py -x -q -p no:cacheprovider 2>&1 | tail -2
-bash tools/stream_hop_ab.sh 2>&1 | tee gpurun_out/s4/stream_hop_ab.txt
+for B in 1; do
+NWS_AB_EAGER=1 NWS_AB_LABEL=default python tools/stream_hop_ab.py /tmp/x.npy $B 2>&1 | grep "p50"
+NWS_BACKEND=ctypes NWS_AB_EAGER=1 NWS_AB_LABEL=ctypes python tools/stream_hop_ab.py /tmp/x.npy $B 2>&1 | grep "p50"
+done
+timeout 900 python -m pytest tests/test_gpu_distributed.py tests/test_gpu_coexec.py -x -q -p no:cacheprovider 2>&1 | grep -E "passed|failed"

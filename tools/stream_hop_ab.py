@@ -42,17 +42,30 @@ def main():
         f0_in.copy_(f0h[:, 0])
         c_in.copy_(ch)
         torch.cuda.synchronize()
-        for mode in ("hop", "push"):
-            lat = []
+        import time
+        modes = ("hop", "push") + (("eager",) if os.environ.get("NWS_AB_EAGER") else ())
+        g, f0_g, c_g, nz_g, out_g, pre_g = s._graphs[(K, 2)]
+        for mode in modes:
+            lat, host = [], []
             for _ in range(1000):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                s.hop(K) if mode == "hop" else s.push(f0h, ch)
+                t0 = time.perf_counter()
+                if mode == "hop":
+                    s.hop(K)
+                elif mode == "push":
+                    s.push(f0h, ch)
+                else:          # the captured hop's own buffers, launched kernel by kernel: what the graph saves or costs on the host
+                    nz_g.uniform_()
+                    s._step(f0_g, c_g, False, False, nz_g, out_g, pre_g)
+                    s._advance(K, 128 * K, False, False)
+                host.append((time.perf_counter() - t0) * 1e6)
                 e1.record()
                 e1.synchronize()
                 lat.append(e0.elapsed_time(e1) * 1e3)
             lat = np.array(lat)
-            print(f"{os.environ.get('NWS_AB_LABEL', '?'):>14s} B={B} {mode:4s}: p50 {np.percentile(lat, 50):6.1f} us  p99 {np.percentile(lat, 99):6.1f} us")
+            print(f"{os.environ.get('NWS_AB_LABEL', '?'):>14s} B={B} {mode:5s}: p50 {np.percentile(lat, 50):6.1f} us  p99 {np.percentile(lat, 99):6.1f} us"
+                  f"   (host call p50 {np.percentile(host, 50):5.1f} us)")
 
 
 if __name__ == "__main__":
