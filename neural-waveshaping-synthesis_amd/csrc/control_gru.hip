@@ -26,6 +26,7 @@
 // are issued twice per SIMD) 0.285 ms; K-quarters interleaved at 16 B (the four addresses of a read in one 64 B line) 0.238
 // ms; 4 K-slices + LDS partial-sum exchange + libm gates 0.457 ms (round 1).
 #include "nws_common.h"
+#include "mlp_few.h"
 
 namespace {
 
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const
   // streaming hop (nws_control_gru_stream): workgroups behind the B recurrences do what in the hop depends on nothing the hop
   // computes - the per-utterance head (windows' first rows, phase carries), then the reverb's history parts (256 taps x 256
   // outputs each, earlier hops' reverb input only) - beside the hop's critical path instead of on it (stream.hip, nws_common.h)
-  if ((side.ring != nullptr || side.f0_w != nullptr) && blockIdx.x >= (unsigned)side.B) {
+  if (DBG == 0 && (side.ring != nullptr || side.f0_w != nullptr) && blockIdx.x >= (unsigned)side.B) {
     int idx = blockIdx.x - side.B;
     if (side.f0_w != nullptr) {
       if (idx < side.B) {
@@ -81,6 +82,37 @@ __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const
         return;
       }
       idx -= side.B;
+    }
+    if (side.gru_flag != nullptr) {
+      // frame MLPs of the hop's new frames: (path, utterance) = (idx & 1, idx >> 1).  Dispatched behind ALL recurrence workgroups
+      // (lower block ids), so the wait below cannot keep one of them from starting; it is bounded anyway (a wrong hop instead of
+      // a hung queue; counters[5] says so)
+      if (idx < 2 * side.B) {
+        __shared__ __attribute__((aligned(16))) NwsFewLds FL;
+        const int mb = idx >> 1;
+        const long long target = side.counters[1] + side.counters[3] + side.K;
+        nws_mlp_few_path<2>(FL, w, side.gru_out, side.K, mb, idx & 1, side.film_w, side.fir_w, side.out_T, side.out_off, tid, [&] {
+          if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(&side.gru_flag[mb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != target) {
+              if (++spins > (1 << 18)) {
+                side.counters_rw[5] = 1;
+                break;
+              }
+              __builtin_amdgcn_s_sleep(4);
+            }
+          }
+          __syncthreads();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // gru_out as the recurrence workgroup left it
+        });
+        return;
+      }
+      idx -= 2 * side.B;
+      if (idx == 0) {
+        nws_stream_noise_window_block<256, false>(side.win, tid);
+        return;
+      }
+      idx -= 1;
     }
     __shared__ __attribute__((aligned(16))) float rv_xs[512];
     __shared__ __attribute__((aligned(16))) float rv_hs[256];
@@ -229,6 +261,12 @@ __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const
     if (b == 0 && tid < 48 && T >= 208) reinterpret_cast<unsigned long long*>(gru_out)[tid] = ticks[tid];
   }
   if (hT != nullptr && writer) hT[(size_t)b * kH + unit] = h_prev;
+  if (DBG == 0 && side.gru_flag != nullptr) {
+    // every gru_out row of this utterance is in memory: release the frame-MLP workgroups waiting for it in this launch
+    __syncthreads();
+    if (tid == 0)
+      __hip_atomic_store(&side.gru_flag[b], side.counters[1] + side.counters[3] + side.K, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -443,6 +481,11 @@ extern "C" int nws_control_gru_stream(const NwsWeights* w, const float* control,
       if (!s.f0_new || !s.prev_f0 || !s.prev_film || !s.prev_fir || !s.S || !s.film_w || !s.fir_w || !s.carry || s.K != T)
         return NWS_ERR_BAD_ARG;
       extra += B;
+    }
+    if (s.gru_flag != nullptr) {
+      if (s.f0_w == nullptr || !s.gru_out || !s.counters || !s.counters_rw || !s.win.nzwin || !w->mlp_frags || s.K > 2 || s.gru_out != gru_out)
+        return NWS_ERR_BAD_ARG;
+      extra += 2 * B + 1;
     }
     if (s.ring != nullptr && s.parts > 1) {
       if (!s.ir || !s.partial || !s.counters || s.M <= 0 || s.M > 256) return NWS_ERR_BAD_ARG;

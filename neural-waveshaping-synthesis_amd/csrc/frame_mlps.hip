@@ -20,6 +20,7 @@
 #include <cstring>
 
 #include "nws_common.h"
+#include "mlp_few.h"
 
 namespace {
 
@@ -1275,6 +1276,20 @@ __global__ void fir_design_kernel(const float* __restrict__ window, float* __res
   D[n * kDK + k] = v;
 }
 
+// A handful of frames per utterance (streaming hop): matrix-vector form, one workgroup per (path, utterance) - mlp_few.h.
+// Streaming: one more pair of workgroups behind the B utterances; the first of them runs the hop's shared head (nws_common.h).
+template <int NF>
+__global__ __launch_bounds__(256) void frame_mlps_few_kernel(NwsWeights w, const float* __restrict__ gru_out, int T,
+                                                             float* __restrict__ film_out, float* __restrict__ fir_out, int out_T,
+                                                             int out_off, NwsStreamNoiseWin win) {
+  if (win.nzwin != nullptr && blockIdx.y == gridDim.y - 1) {
+    if (blockIdx.x == 0) nws_stream_noise_window_block<256>(win, threadIdx.x);
+    return;
+  }
+  __shared__ __attribute__((aligned(16))) NwsFewLds L;
+  nws_mlp_few_path<NF>(L, w, gru_out, T, blockIdx.y, blockIdx.x, film_out, fir_out, out_T, out_off, threadIdx.x, [] {});
+}
+
 }  // namespace
 
 extern "C" {
@@ -1311,6 +1326,15 @@ int nws_debug_frame_mlps_kernel(int mode) {
   g_mlp_kernel_mode = mode & 15;
   g_mlp_dbg = mode >> 4;     // bits 8..10: timing ablation
   return NWS_OK;
+}
+
+// NWS_MLP_FEW=0: utterances of one or two frames take the 32-frame tile kernel like longer ones (measurements, bit-identity tests)
+static bool few_frames_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("NWS_MLP_FEW");
+    return e == nullptr || e[0] != '0';
+  }();
+  return on;
 }
 
 int nws_frame_mlps(const NwsWeights* w, const float* gru_out, const float* fir_design, int B, int T, float* emb_out,
@@ -1404,6 +1428,13 @@ int nws_frame_mlps(const NwsWeights* w, const float* gru_out, const float* fir_d
     NWS_CHECK_LAUNCH();
     return NWS_OK;
   }
+  // one or two frames per utterance (256-sample streaming buffers, scripts/time_buffer_sizes.py): the matrix-vector form of mlp_few.h
+  // (four frames through the NF = 4 instantiation measured no faster than the tile kernel: 65.5 against 64.8 us per 512-sample buffer)
+  if (w->mlp_frags != nullptr && !emb_out && !H_out && T <= 2 && mode == 0 && few_frames_enabled()) {
+    frame_mlps_few_kernel<2><<<dim3(2, B), 256, 0, (hipStream_t)stream>>>(*w, gru_out, T, film_out, fir_out, T, 0, NwsStreamNoiseWin{});
+    NWS_CHECK_LAUNCH();
+    return NWS_OK;
+  }
   const dim3 grid((T + kFT - 1) / kFT, B);
   if (w->mlp_frags != nullptr && !emb_out && !H_out)
     frame_mlps16_kernel<false><<<grid, 512, sizeof(MlpLds16), (hipStream_t)stream>>>(*w, gru_out, T, nullptr, film_out,
@@ -1431,6 +1462,12 @@ int nws_frame_mlps_stream(const NwsWeights* w, const float* gru_out, int B, int 
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_mlps16_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MlpLds16));
     if (e != hipSuccess) return (int)e;
+  }
+  // one or two frames: the matrix-vector form (NWS_MLP_FEW=0 keeps the tile kernel: measurements, bit-identity tests)
+  if (few_frames_enabled() && T <= 2) {
+    frame_mlps_few_kernel<2><<<dim3(2, B + 1), 256, 0, (hipStream_t)stream>>>(*w, gru_out, T, film_w, fir_w, out_T, out_off, *win);
+    NWS_CHECK_LAUNCH();
+    return NWS_OK;
   }
   frame_mlps16_kernel<false><<<dim3(1, B + 1), 512, sizeof(MlpLds16), (hipStream_t)stream>>>(*w, gru_out, T, nullptr, film_w, nullptr,
                                                                                               fir_w, out_T, out_off, *win);

@@ -302,6 +302,48 @@ __device__ __forceinline__ float nws_stream_reverb_partial(const float* __restri
   return nws_add_scalar(acc0, acc1);
 }
 
+// The shared part of a hop's head, one workgroup of NT threads (an extra workgroup of the frame-MLP launch in the fused hop,
+// block B of stream_prep_kernel otherwise): applies the previous step's pending sample / frame counts - nobody else in the
+// launch reads the counters - and moves the noise window on.
+struct NwsStreamNoiseWin {
+  float* nzwin;
+  const float* noise_new;
+  const float* noise_all;
+  long long* counters;
+  int nz_shift, nz_keep, n_new, noise_all_len, first, K;
+};
+template <int NT, bool ADVANCE = true>
+__device__ __forceinline__ void nws_stream_noise_window_block(const NwsStreamNoiseWin& Z, int tid) {
+  const int Tw = Z.first ? Z.K : Z.K + 1;
+  const long long F = Z.counters[1] + Z.counters[3];
+  __syncthreads();   // every thread has read the old values
+  // (!ADVANCE - the four-launch hop: this workgroup shares its launch with readers of the pending form; the closing kernel's last
+  // workgroup applies the counts)
+  if (ADVANCE && tid == 0) {
+    Z.counters[0] += Z.counters[2];
+    Z.counters[1] = F;
+    Z.counters[2] = 0;
+    Z.counters[3] = 0;
+  }
+  if (Z.noise_all != nullptr) {
+    // injected stream (parity runs): the window starts at absolute sample max(0, 128 (A0 - 1)), A0 = first frame of the window
+    const long long A0 = Z.first ? 0 : F - 1;
+    const long long start = A0 <= 0 ? 0 : 128 * (A0 - 1);
+    const int want = 128 * (Tw + 1) + 1;
+    for (int i = tid; i < want; i += NT) Z.nzwin[i] = start + i < Z.noise_all_len ? Z.noise_all[start + i] : 0.0f;
+  } else {
+    // drawn stream: keep the last nz_keep samples (shifted down by nz_shift), append the n_new fresh draws
+    for (int i0 = 0; i0 < Z.nz_keep; i0 += NT) {
+      const int i = i0 + tid;
+      const float v = i < Z.nz_keep ? Z.nzwin[i + Z.nz_shift] : 0.0f;
+      __syncthreads();
+      if (i < Z.nz_keep) Z.nzwin[i] = v;
+      __syncthreads();
+    }
+    for (int i = tid; i < Z.n_new; i += NT) Z.nzwin[Z.nz_keep + i] = Z.noise_new[i];
+  }
+}
+
 // What the extra workgroups of the recurrence launch need (nws_control_gru_stream).  The launch sits IN FRONT of the
 // workgroup that applies the previous step's pending sample count (the step's second launch): the position of this step's first
 // sample is counters[0] + counters[2].
@@ -327,6 +369,15 @@ struct NwsStreamSide {
   float* fir_w;
   double* carry;
   int K, first, final;
+  // frame MLPs of the K <= 2 new frames inside this launch (gru_flag != NULL): two workgroups per utterance (mlp_few.h) fetch
+  // their first weight fragments, then wait for the recurrence workgroup of their utterance, which leaves
+  // gru_flag[b] = frames seen through this hop (counters[1] + counters[3] + K: unique per hop) behind its last gru_out row;
+  // + one workgroup for the shared noise window (the pending counters stay: see the closing kernel of stream.hip)
+  long long* gru_flag;          // (B)
+  long long* counters_rw;       // the same counters, writable: [5] = 1 if a frame-MLP workgroup gave up waiting
+  const float* gru_out;         // (B, K, 128)
+  int out_T, out_off;           // rows per utterance of film_w / fir_w, row of the first new frame
+  NwsStreamNoiseWin win;
 };
 
 // 256 threads; wave_tot: 4 doubles of LDS
@@ -354,46 +405,6 @@ __device__ __forceinline__ void nws_stream_head_block(const NwsStreamSide& H, in
     __syncthreads();
   }
   if (!H.final && tid == 0) H.S[b] = cb[nch - 2];    // through the last emitted sample (128 Tw - 64)
-}
-
-// The shared part of a hop's head, one workgroup of NT threads (an extra workgroup of the frame-MLP launch in the fused hop,
-// block B of stream_prep_kernel otherwise): applies the previous step's pending sample / frame counts - nobody else in the
-// launch reads the counters - and moves the noise window on.
-struct NwsStreamNoiseWin {
-  float* nzwin;
-  const float* noise_new;
-  const float* noise_all;
-  long long* counters;
-  int nz_shift, nz_keep, n_new, noise_all_len, first, K;
-};
-template <int NT>
-__device__ __forceinline__ void nws_stream_noise_window_block(const NwsStreamNoiseWin& Z, int tid) {
-  const int Tw = Z.first ? Z.K : Z.K + 1;
-  const long long F = Z.counters[1] + Z.counters[3];
-  __syncthreads();   // every thread has read the old values
-  if (tid == 0) {
-    Z.counters[0] += Z.counters[2];
-    Z.counters[1] = F;
-    Z.counters[2] = 0;
-    Z.counters[3] = 0;
-  }
-  if (Z.noise_all != nullptr) {
-    // injected stream (parity runs): the window starts at absolute sample max(0, 128 (A0 - 1)), A0 = first frame of the window
-    const long long A0 = Z.first ? 0 : F - 1;
-    const long long start = A0 <= 0 ? 0 : 128 * (A0 - 1);
-    const int want = 128 * (Tw + 1) + 1;
-    for (int i = tid; i < want; i += NT) Z.nzwin[i] = start + i < Z.noise_all_len ? Z.noise_all[start + i] : 0.0f;
-  } else {
-    // drawn stream: keep the last nz_keep samples (shifted down by nz_shift), append the n_new fresh draws
-    for (int i0 = 0; i0 < Z.nz_keep; i0 += NT) {
-      const int i = i0 + tid;
-      const float v = i < Z.nz_keep ? Z.nzwin[i + Z.nz_shift] : 0.0f;
-      __syncthreads();
-      if (i < Z.nz_keep) Z.nzwin[i] = v;
-      __syncthreads();
-    }
-    for (int i = tid; i < Z.n_new; i += NT) Z.nzwin[Z.nz_keep + i] = Z.noise_new[i];
-  }
 }
 
 // control_gru.hip: nws_control_gru_state with the extra workgroups `side` asks for (NULL: none).  Internal to the library.

@@ -24,7 +24,7 @@ constexpr int kMaxDirect = 2048;      // samples per step the time-domain reverb
 size_t al(size_t b) { return (b + 255) & ~size_t(255); }
 
 struct Layout {
-  size_t h, h_next, prev_f0, prev_film, prev_fir, S, residue, ring, counters, nzwin;            // state
+  size_t h, h_next, prev_f0, prev_film, prev_fir, S, residue, ring, counters, gru_flag, nzwin;  // state
   size_t gru_out, film_new, fir_new, f0_w, film_w, fir_w, carry, newt_w, noise_w, pre, partial, x_lin, y_lin, rv_ws;   // scratch
   size_t rv_ws_bytes, total;
   int parts;
@@ -48,6 +48,7 @@ Layout layout(int B, int max_frames, int ir_len, size_t fft_ws_bytes) {
   L.residue = take((size_t)B * 64 * 4);
   L.ring = take((size_t)B * kRing * 4);
   L.counters = take(64);
+  L.gru_flag = take((size_t)B * 8);
   L.nzwin = take((Nw + 128 + 8) * 4);
   L.gru_out = take((size_t)B * K * NWS_HIDDEN * 4);
   L.film_new = take((size_t)B * K * NWS_FILM_CH * 4);
@@ -169,6 +170,10 @@ struct StreamTail {
   float* prev_fir;
   float* h;
   int Tw;
+  // four-launch hop: nobody has applied the previous step's pending counts (the workgroup that does so in the five-launch hop
+  // shares its launch with readers of the pending form there): positions are read as counters[0] + counters[2], and the LAST
+  // workgroup of this kernel to finish leaves the counters with nothing pending
+  int apply_counters;
 };
 template <bool INLINE0>
 __global__ __launch_bounds__(256) void stream_reverb_reduce_kernel(const float* __restrict__ partial, int parts, PreSrc P, int M, int B,
@@ -185,11 +190,13 @@ __global__ __launch_bounds__(256) void stream_reverb_reduce_kernel(const float* 
     if (c < NWS_HIDDEN) tail.h[(size_t)b * NWS_HIDDEN + c] = tail.h_next[(size_t)b * NWS_HIDDEN + c];
   }
   const int j = blockIdx.x * 256 + threadIdx.x;
+  const bool apply = INLINE0 && tail.apply_counters != 0;
+  const long long pos = counters[0] + (apply ? counters[2] : 0);
   float part0 = 0.0f;
   if (INLINE0) {
     __shared__ __attribute__((aligned(16))) float xs[512];
     __shared__ __attribute__((aligned(16))) float hs[256];
-    part0 = nws_stream_reverb_partial<false>(ring, P, ir, ir_len, M, b, 0, 0, counters[0], threadIdx.x, xs, hs);
+    part0 = nws_stream_reverb_partial<false>(ring, P, ir, ir_len, M, b, 0, 0, pos, threadIdx.x, xs, hs);
   }
   if (j < M) {
     const float dry = pre_value(P, b, j);
@@ -207,10 +214,28 @@ __global__ __launch_bounds__(256) void stream_reverb_reduce_kernel(const float* 
     for (; p < parts; ++p) acc += (INLINE0 && p == 0) ? part0 : partial[((size_t)p * B + b) * M + j];
     out[(size_t)b * M + j] = dry + acc;
     pre_out[(size_t)b * M + j] = dry;
-    ring[(size_t)b * kRing + ((counters[0] + j) & (kRing - 1))] = dry;
+    ring[(size_t)b * kRing + ((pos + j) & (kRing - 1))] = dry;
   }
   // the noise residue of the next chunk: thread j < 64 of the first block is the only one that read residue[b][j] above
   if (!final && blockIdx.x == 0 && threadIdx.x < 64) residue[(size_t)b * 64 + threadIdx.x] = P.noise_w[(size_t)b * P.Nw + tail_from + threadIdx.x];
+  if (apply) {
+    // every workgroup has read the position (above, into `pos`) before it counts itself done; the one that completes the count
+    // is the only one left that touches the counters
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(&counters[4]), 1ull);
+      if (done == (unsigned long long)(gridDim.x * gridDim.y) - 1) {
+        __threadfence();
+        counters[0] = pos + M;
+        counters[1] = counters[1] + counters[3] + K;
+        counters[2] = 0;
+        counters[3] = 0;
+        counters[4] = 0;
+      }
+    }
+    return;
+  }
   if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {   // applied by the next step's prep kernel
     counters[2] = M;
     counters[3] = K;
@@ -333,6 +358,14 @@ int nws_stream_step(const NwsWeights* w, const float* fir_design, const NwsRever
     return e == nullptr || e[0] != '0';
   }();
   const bool fuse_head = head_env && split_reverb && K <= 32 && w->mlp_frags != nullptr;
+  // ... and with one or two new frames the frame MLPs join the recurrence launch as well (two workgroups per utterance that fetch
+  // their first weights while the recurrence runs and wait for its rows; NWS_STREAM_FUSE_MLP=0 keeps their launch).  Four launches.
+  static const bool mlp_env = [] {
+    const char* e = getenv("NWS_STREAM_FUSE_MLP");
+    const char* f = getenv("NWS_MLP_FEW");
+    return (e == nullptr || e[0] != '0') && (f == nullptr || f[0] != '0');
+  }();
+  const bool fuse_mlp = mlp_env && fuse_head && K <= 2;
   const long long nz_start = nws_stream_noise_start(first, frames_seen);
   const long long have = first ? 0 : 128 * (frames_seen - 1) + 129;       // absolute end of what the window holds now
   const int n_new = noise_new ? nws_stream_noise_draws(K, first, frames_seen) : 0;
@@ -364,10 +397,21 @@ int nws_stream_step(const NwsWeights* w, const float* fir_design, const NwsRever
     side.first = first;
     side.final = final;
   }
+  if (fuse_mlp) {
+    side.gru_flag = reinterpret_cast<long long*>(base + L.gru_flag);
+    side.counters = counters;
+    side.counters_rw = counters;
+    side.gru_out = F(L.gru_out);
+    side.out_T = Tw;
+    side.out_off = first ? 0 : 1;
+    side.win = NwsStreamNoiseWin{F(L.nzwin), noise_new, noise_all, counters, nz_shift, nz_keep, n_new, noise_all_len, first, K};
+  }
   rc = nws_control_gru_stream(w, control, B, C, K, first ? nullptr : F(L.h), F(L.gru_out), F(L.h_next), split_reverb ? &side : nullptr,
                               stream);
   if (rc != NWS_OK) return rc;
-  if (fuse_head) {
+  if (fuse_mlp) {
+    // (nothing: the frame MLPs, the noise window and the windows' rows were part of the first launch)
+  } else if (fuse_head) {
     const NwsStreamNoiseWin Z{F(L.nzwin), noise_new, noise_all, counters, nz_shift, nz_keep, n_new, noise_all_len, first, K};
     rc = nws_frame_mlps_stream(w, F(L.gru_out), B, K, F(L.film_w), F(L.fir_w), Tw, first ? 0 : 1, &Z, stream);
     if (rc != NWS_OK) return rc;
@@ -402,7 +446,7 @@ int nws_stream_step(const NwsWeights* w, const float* fir_design, const NwsRever
   if (split_reverb) {
     // one launch: part 0 + the fixed-order reduction over it and the parts the first launch left, closing the step
     StreamTail tail{};
-    if (fuse_head) tail = StreamTail{F(L.film_w), F(L.fir_w), F(L.h_next), F(L.prev_film), F(L.prev_fir), F(L.h), Tw};
+    if (fuse_head) tail = StreamTail{F(L.film_w), F(L.fir_w), F(L.h_next), F(L.prev_film), F(L.prev_fir), F(L.h), Tw, fuse_mlp ? 1 : 0};
     stream_reverb_reduce_kernel<true><<<dim3(1, B), 256, 0, st>>>(F(L.partial), L.parts, P, M, B, K, final, tail_from, out, pre, F(L.ring),
                                                                   F(L.residue), counters, ir, ir_len, tail);
     NWS_CHECK_LAUNCH();

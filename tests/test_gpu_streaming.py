@@ -202,8 +202,8 @@ def test_stream_refresh_picks_up_a_weight_update_at_once(setup):
 
 
 def test_fused_hop_is_bit_identical_with_the_seven_launch_form(tmp_path):
-    """Hops of <= 256 samples run in five launches (csrc/stream.hip): the reverb's history parts and the per-utterance head as extra
-    workgroups of the recurrence launch, frame-MLP rows straight into the windows, reverb part 0 + hand-over inside the closing
+    """Hops of <= 256 samples run in four launches (csrc/stream.hip): the reverb's history parts, the per-utterance head and the
+    frame MLPs of the new frames as extra workgroups of the recurrence launch, reverb part 0 + hand-over inside the closing
     kernel.  Same code, same order of sums: the emitted samples of 40 graph-replayed hops (final one included) must equal the
     seven-launch form's (NWS_STREAM_SPLIT_REVERB=0) bit for bit.  The switches are read once per process."""
     import os
@@ -211,12 +211,19 @@ def test_fused_hop_is_bit_identical_with_the_seven_launch_form(tmp_path):
     import sys
 
     tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "stream_hop_ab.py")
-    outs = []
-    for split in ("0", "1"):
-        path = str(tmp_path / f"hop_{split}.npy")
-        r = subprocess.run([sys.executable, tool, path, "3", "dump-only"], capture_output=True, text=True,
-                           env=dict(os.environ, NWS_STREAM_SPLIT_REVERB=split))
+    outs = {}
+    # launch structures with the SAME frame-MLP arithmetic must agree bit for bit: seven / five launches with the 32-frame tile
+    # kernel; five launches / the default four with the matrix-vector form of csrc/mlp_few.h for the hop's two frames (exact fp32
+    # products of the same 22-bit weights: equal to the tile kernel's results to fp32 rounding)
+    variants = {"seven_tiles": {"NWS_STREAM_SPLIT_REVERB": "0", "NWS_MLP_FEW": "0"}, "five_tiles": {"NWS_MLP_FEW": "0"},
+                "five_few": {"NWS_STREAM_FUSE_MLP": "0"}, "default": {}}
+    for name, env in variants.items():
+        path = str(tmp_path / f"hop_{name}.npy")
+        r = subprocess.run([sys.executable, tool, path, "3", "dump-only"], capture_output=True, text=True, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(np.load(path))
-    assert outs[0].shape == (3, 128 * 80) and np.isfinite(outs[0]).all() and rms(outs[0]) > 1e-3
-    assert np.array_equal(outs[0], outs[1])
+        outs[name] = np.load(path)
+    a = outs["seven_tiles"]
+    assert a.shape == (3, 128 * 80) and np.isfinite(a).all() and rms(a) > 1e-3
+    assert np.array_equal(a, outs["five_tiles"])
+    assert np.array_equal(outs["five_few"], outs["default"])
+    assert rms(outs["default"] - a) <= 1e-5 * rms(a), rms(outs["default"] - a)      # measured 3.4e-6 (1e-7 absolute; the parity bar is 1e-4)
