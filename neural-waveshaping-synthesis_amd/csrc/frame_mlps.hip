@@ -1281,13 +1281,13 @@ __global__ void fir_design_kernel(const float* __restrict__ window, float* __res
 template <int NF>
 __global__ __launch_bounds__(256) void frame_mlps_few_kernel(NwsWeights w, const float* __restrict__ gru_out, int T,
                                                              float* __restrict__ film_out, float* __restrict__ fir_out, int out_T,
-                                                             int out_off, NwsStreamNoiseWin win) {
+                                                             int out_off, NwsStreamNoiseWin win, long long* probe) {
   if (win.nzwin != nullptr && blockIdx.y == gridDim.y - 1) {
     if (blockIdx.x == 0) nws_stream_noise_window_block<256>(win, threadIdx.x);
     return;
   }
   __shared__ __attribute__((aligned(16))) NwsFewLds L;
-  nws_mlp_few_path<NF>(L, w, gru_out, T, blockIdx.y, blockIdx.x, film_out, fir_out, out_T, out_off, threadIdx.x, [] {});
+  nws_mlp_few_path<NF>(L, w, gru_out, T, blockIdx.y, blockIdx.x, film_out, fir_out, out_T, out_off, threadIdx.x, [] {}, probe);
 }
 
 }  // namespace
@@ -1431,7 +1431,8 @@ int nws_frame_mlps(const NwsWeights* w, const float* gru_out, const float* fir_d
   // one or two frames per utterance (256-sample streaming buffers, scripts/time_buffer_sizes.py): the matrix-vector form of mlp_few.h
   // (four frames through the NF = 4 instantiation measured no faster than the tile kernel: 65.5 against 64.8 us per 512-sample buffer)
   if (w->mlp_frags != nullptr && !emb_out && !H_out && T <= 2 && mode == 0 && few_frames_enabled()) {
-    frame_mlps_few_kernel<2><<<dim3(2, B), 256, 0, (hipStream_t)stream>>>(*w, gru_out, T, film_out, fir_out, T, 0, NwsStreamNoiseWin{});
+    frame_mlps_few_kernel<2><<<dim3(2, B), 256, 0, (hipStream_t)stream>>>(*w, gru_out, T, film_out, fir_out, T, 0, NwsStreamNoiseWin{},
+                                                                          static_cast<long long*>(g_mlp_probe));
     NWS_CHECK_LAUNCH();
     return NWS_OK;
   }
@@ -1465,7 +1466,7 @@ int nws_frame_mlps_stream(const NwsWeights* w, const float* gru_out, int B, int 
   }
   // one or two frames: the matrix-vector form (NWS_MLP_FEW=0 keeps the tile kernel: measurements, bit-identity tests)
   if (few_frames_enabled() && T <= 2) {
-    frame_mlps_few_kernel<2><<<dim3(2, B + 1), 256, 0, (hipStream_t)stream>>>(*w, gru_out, T, film_w, fir_w, out_T, out_off, *win);
+    frame_mlps_few_kernel<2><<<dim3(2, B + 1), 256, 0, (hipStream_t)stream>>>(*w, gru_out, T, film_w, fir_w, out_T, out_off, *win, nullptr);
     NWS_CHECK_LAUNCH();
     return NWS_OK;
   }

@@ -11,6 +11,13 @@
 // packed FMA per weight and frame pair).  Exact fp32 products of 22-bit weights: the class of the two-term MFMA form, not
 // bit-identical with it (tests/test_gpu_streaming.py compares both forms with the same CPU reference).
 // newt.mlp and h_generator are independent after the embedding: one workgroup each (both compute proj).
+// Where its ~10 us go (tools/mlp_few_timeline.py, cycles of one workgroup): a hidden layer 3 700 = ~1 000 for requesting the next
+// layer's 64 KB of fragments (four waves through one CU's 64 B / clock), ~1 600 for the product (32 ds_read_b128 per lane and product:
+// the four waves' 128 KB of activation reads are the LDS pipe's 1 000 cycles - lanes of a half read the same address, the
+// bandwidth is per lane all the same), ~1 100 LayerNorm (two dependent 32-lane reductions, two barriers).  A rolled loop over the
+// layers (a quarter of the code) measured SLOWER (26-29 K against 19-22 K cycles: moving the prefetched fragments into the loop's
+// registers waits for them) - it is not instruction fetch.  A K-split over the waves (every wave all four M-tiles of a quarter of K: a
+// quarter of the LDS reads, one more exchange per layer) is what is left; not built.
 #pragma once
 
 #include "nws_common.h"
@@ -159,7 +166,14 @@ __device__ __forceinline__ void nws_few_hidden(NwsFewLds& L, const NwsFewFrag<8>
 template <int NF, typename Wait>
 __device__ __forceinline__ void nws_mlp_few_path(NwsFewLds& L, const NwsWeights& w, const float* __restrict__ gru_out, int T, int b,
                                                  int path, float* __restrict__ film_w, float* __restrict__ fir_w, int out_T,
-                                                 int out_off, int tid, Wait&& wait_for_input) {
+                                                 int out_off, int tid, Wait&& wait_for_input, long long* probe = nullptr) {
+  // probe (measurements: tools/mlp_few_timeline.py): s_memtime of thread 0 of utterance 0 at the phase boundaries, 16 slots per path
+  int pslot = 0;
+  auto tick = [&] {
+    if (probe != nullptr && b == 0 && tid == 0) probe[16 * path + pslot] = (long long)__builtin_readcyclecounter();
+    ++pslot;
+  };
+  tick();
   const nws_f16x8* F = reinterpret_cast<const nws_f16x8*>(w.mlp_frags);
   const int li = tid & 63, mt = tid >> 6, row = li & 31, half = li >> 5;
   // this lane's biases and LayerNorm gains of every layer FIRST: a value loaded behind a layer's fragment requests is the youngest
@@ -177,6 +191,7 @@ __device__ __forceinline__ void nws_mlp_few_path(NwsFewLds& L, const NwsWeights&
   NwsFewFrag<8> A, An;
   nws_few_load<8>(A, F, nws_few_frag_base(0), mt, li);                      // proj
   nws_few_load<8>(An, F, nws_few_frag_base(path ? 5 : 1), mt, li);          // first hidden layer
+  tick();
   wait_for_input();
   // gru_out rows -> xa[k][f]; zero the K padding of both buffers (rows 128 .. 143: the FIR design contracts over 144)
   for (int e = tid; e < NWS_HIDDEN * NF; e += 256) {
@@ -188,6 +203,7 @@ __device__ __forceinline__ void nws_mlp_few_path(NwsFewLds& L, const NwsWeights&
     L.xb[NWS_HIDDEN * NF + e] = 0.0f;
   }
   __syncthreads();
+  tick();
   {
     // emb = proj(gru_out) -> xb (no LayerNorm)
     const int o = 32 * mt + row;
@@ -200,17 +216,21 @@ __device__ __forceinline__ void nws_mlp_few_path(NwsFewLds& L, const NwsWeights&
     }
     __syncthreads();
   }
+  tick();
   const int id0 = path ? 5 : 1;
   // three hidden layers: xb -> xa -> xb -> xa, each with the next layer's fragments in flight
   A = An;
   nws_few_load<8>(An, F, nws_few_frag_base(id0 + 1), mt, li);
   nws_few_hidden<NF>(L, A, L.xb, L.xa, b_h[0], g_h[0], t_h[0], mt, row, half);
+  tick();
   A = An;
   nws_few_load<8>(An, F, nws_few_frag_base(id0 + 2), mt, li);
   nws_few_hidden<NF>(L, A, L.xa, L.xb, b_h[1], g_h[1], t_h[1], mt, row, half);
+  tick();
   A = An;
   nws_few_load<8>(An, F, nws_few_frag_base(id0 + 3), mt, li);                // output layer, M-tile mt
   nws_few_hidden<NF>(L, A, L.xb, L.xa, b_h[2], g_h[2], t_h[2], mt, row, half);
+  tick();
   A = An;
   if (path == 0) {
     // FiLM rows: 256 channels = M-tiles mt and mt + 4 from xa
@@ -227,6 +247,7 @@ __device__ __forceinline__ void nws_mlp_few_path(NwsFewLds& L, const NwsWeights&
           if (f < T) film_w[((size_t)b * out_T + out_off + f) * NWS_FILM_CH + o] = ((f & 1) ? acc.p[f >> 1].y : acc.p[f >> 1].x) + bo;
       }
     }
+    tick();
     return;
   }
   // H (129 bands): M-tiles 0 .. 3 from xa -> xb rows 0 .. 127; wave 0 also M-tile 4 = row 128 (rows 129 .. 143 stay zero)
@@ -252,6 +273,7 @@ __device__ __forceinline__ void nws_mlp_few_path(NwsFewLds& L, const NwsWeights&
     }
   }
   __syncthreads();
+  tick();
   {
     // fir = D[128 .. 255] H (upper half-taps), K = 144 padded
     const int o = 32 * mt + row;
@@ -263,4 +285,5 @@ __device__ __forceinline__ void nws_mlp_few_path(NwsFewLds& L, const NwsWeights&
         if (f < T) fir_w[((size_t)b * out_T + out_off + f) * NWS_FIR_HALF + o] = (f & 1) ? acc.p[f >> 1].y : acc.p[f >> 1].x;
     }
   }
+  tick();
 }

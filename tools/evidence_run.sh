@@ -37,6 +37,9 @@ bash tools/fake_peers_ab.sh > /dev/null 2>&1; cp gpurun_out/fake_peers_ab.txt gp
 python tools/cu_pressure.py > gpurun_out/ev/cu_pressure.txt 2>&1
 python tools/film_dma_ab.py > gpurun_out/ev/film_dma_ab.txt 2>&1
 python tools/mlp_paths_ab.py > gpurun_out/ev/mlp_paths_ab.txt 2>&1
+# round 6, last session: the streaming hop's launch structures (bit-identity + p50 per form), the few-frame MLP kernel's cycle timeline
+bash tools/stream_hop_ab.sh 2>&1 | grep -E "p50|outputs" > gpurun_out/ev/stream_hop_ab.txt
+python tools/mlp_few_timeline.py 2>&1 | grep -E "^rep [345]" > gpurun_out/ev/mlp_few_timeline.txt
 bash tools/collect_profiles.sh ${ROUND:-r06} > gpurun_out/ev/collect.log 2>&1
 ls gpurun_out/prof_${ROUND:-r06} | head -30
 du -sh gpurun_out

@@ -15,6 +15,6 @@ grep -E "passed|failed" gpurun_out/ev/pytest_gpu.txt | tail -1 > "$D/pytest_gpu_
 cat gpurun_out/ev/buffer_fast.txt gpurun_out/ev/buffer_exact.txt gpurun_out/ev/streaming_stateful.txt > "$D/buffer_sizes_summary.txt"
 cp gpurun_out/ev/streaming.jsonl "$D/streaming_stateful.jsonl"
 python tools/buffer_sizes_digest.py gpurun_out/ev/buffer_fast.txt gpurun_out/ev/buffer_exact.txt > "$D/buffer_sizes.csv"
-for f in reverb_lengths mlp_variants mlp_timeline generic_path generic_kernels world1_ab scale_check_dry_run range_proven_ab queue_pipe_map_final placement_ab fake_peers_ab cu_pressure; do
+for f in reverb_lengths mlp_variants mlp_timeline generic_path generic_kernels world1_ab scale_check_dry_run range_proven_ab queue_pipe_map_final placement_ab fake_peers_ab cu_pressure film_dma_ab mlp_paths_ab stream_hop_ab mlp_few_timeline; do
   [ -f gpurun_out/ev/$f.txt ] && grep -v "amdgpu.ids" gpurun_out/ev/$f.txt > "$D/$f.txt"
 done
