@@ -85,25 +85,29 @@ __global__ __launch_bounds__(256, 1) void control_gru_kernel(NwsWeights w, const
     }
     if (side.gru_flag != nullptr) {
       // frame MLPs of the hop's new frames: (path, utterance) = (idx & 1, idx >> 1).  Dispatched behind ALL recurrence workgroups
-      // (lower block ids), so the wait below cannot keep one of them from starting; it is bounded anyway (a wrong hop instead of
-      // a hung queue; counters[5] says so)
+      // (lower block ids), so the wait below cannot keep one of them from starting; it is bounded anyway (a hop of NaNs instead of
+      // a hung queue; counters[5] says so too)
       if (idx < 2 * side.B) {
         __shared__ __attribute__((aligned(16))) NwsFewLds FL;
         const int mb = idx >> 1;
         const long long target = side.counters[1] + side.counters[3] + side.K;
+        __shared__ int gave_up;
         nws_mlp_few_path<2>(FL, w, side.gru_out, side.K, mb, idx & 1, side.film_w, side.fir_w, side.out_T, side.out_off, tid, [&] {
           if (tid == 0) {
-            int spins = 0;
+            int spins = 0, lost = 0;
             while (__hip_atomic_load(&side.gru_flag[mb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != target) {
-              if (++spins > (1 << 18)) {
+              if (++spins > (1 << 18)) {      // ~0.3 s: the recurrence of a hop takes microseconds
                 side.counters_rw[5] = 1;
+                lost = 1;
                 break;
               }
               __builtin_amdgcn_s_sleep(4);
             }
+            gave_up = lost;
           }
           __syncthreads();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // gru_out as the recurrence workgroup left it
+          return gave_up == 0;
         });
         return;
       }

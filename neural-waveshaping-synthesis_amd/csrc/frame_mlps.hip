@@ -1287,7 +1287,7 @@ __global__ __launch_bounds__(256) void frame_mlps_few_kernel(NwsWeights w, const
     return;
   }
   __shared__ __attribute__((aligned(16))) NwsFewLds L;
-  nws_mlp_few_path<NF>(L, w, gru_out, T, blockIdx.y, blockIdx.x, film_out, fir_out, out_T, out_off, threadIdx.x, [] {}, probe);
+  nws_mlp_few_path<NF>(L, w, gru_out, T, blockIdx.y, blockIdx.x, film_out, fir_out, out_T, out_off, threadIdx.x, [] { return true; }, probe);
 }
 
 }  // namespace

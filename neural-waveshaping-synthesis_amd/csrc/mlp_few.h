@@ -161,8 +161,8 @@ __device__ __forceinline__ void nws_few_hidden(NwsFewLds& L, const NwsFewFrag<8>
 
 // path 0: proj -> newt.mlp -> FiLM rows;  path 1: proj -> h_generator -> H -> FIR half-taps.  256 threads; T <= NF frames of
 // utterance b; rows go to row out_off + t of windows of out_T rows per utterance.
-// `wait_for_input()` runs behind the first two layers' fragment requests and in front of the first read of gru_out (a no-op for a
-// launch of its own; the role inside the recurrence launch waits for its utterance's recurrence there).
+// `wait_for_input()` runs behind the first two layers' fragment requests and in front of the first read of gru_out (returns true at
+// once for a launch of its own; the role inside the recurrence launch waits for its utterance's recurrence there, false = gave up).
 template <int NF, typename Wait>
 __device__ __forceinline__ void nws_mlp_few_path(NwsFewLds& L, const NwsWeights& w, const float* __restrict__ gru_out, int T, int b,
                                                  int path, float* __restrict__ film_w, float* __restrict__ fir_w, int out_T,
@@ -192,11 +192,12 @@ __device__ __forceinline__ void nws_mlp_few_path(NwsFewLds& L, const NwsWeights&
   nws_few_load<8>(A, F, nws_few_frag_base(0), mt, li);                      // proj
   nws_few_load<8>(An, F, nws_few_frag_base(path ? 5 : 1), mt, li);          // first hidden layer
   tick();
-  wait_for_input();
+  // (false: the input never arrived - the role's bounded wait gave up.  The rows of this hop are then NaN, loudly, not stale)
+  const bool have_input = wait_for_input();
   // gru_out rows -> xa[k][f]; zero the K padding of both buffers (rows 128 .. 143: the FIR design contracts over 144)
   for (int e = tid; e < NWS_HIDDEN * NF; e += 256) {
     const int k = e / NF, f = e - k * NF;
-    L.xa[e] = f < T ? gru_out[((size_t)b * T + f) * NWS_HIDDEN + k] : 0.0f;
+    L.xa[e] = !have_input ? __builtin_nanf("") : f < T ? gru_out[((size_t)b * T + f) * NWS_HIDDEN + k] : 0.0f;
   }
   for (int e = tid; e < (kFewK - NWS_HIDDEN) * NF; e += 256) {
     L.xa[NWS_HIDDEN * NF + e] = 0.0f;
