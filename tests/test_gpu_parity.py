@@ -212,6 +212,31 @@ def test_frame_mlp_kernels_against_the_stage_taps(models, oracle, mode):
         L.nws_debug_frame_mlps_kernel(0)
 
 
+@pytest.mark.parametrize("B,T", [(1, 2), (3, 2), (5, 1), (17, 2)])
+def test_frame_mlps_of_one_or_two_frames_against_the_tile_kernel(models, B, T):
+    """Utterances of one or two frames (a streaming hop, a 256-sample buffer) take the matrix-vector form of csrc/mlp_few.h: one
+    workgroup of four waves per (utterance, path), the same fp16 fragment pairs as the MFMA kernels (hi + lo = the weight to 22
+    bits) against fp32 activations.  Forced back onto the 32-frame tile kernel (nws_debug_frame_mlps_kernel(1)) the same inputs
+    must give the same FiLM rows and FIR half-taps to fp32 rounding; three frames take the tile kernel either way."""
+    from nws_amd import _lib
+    m, _ = models
+    m._engine.weights()
+    L = _lib.lib()
+    gen = torch.Generator().manual_seed(100 * B + T)
+    gru = torch.tanh(torch.randn(B, T, 128, generator=gen)).cuda()
+    try:
+        _, film, _, fir = m._engine.frame_mlps(gru)
+        assert L.nws_debug_frame_mlps_kernel(1) == 0
+        _, film_t, _, fir_t = m._engine.frame_mlps(gru)
+    finally:
+        L.nws_debug_frame_mlps_kernel(0)
+    assert film.shape == (B, T, 256) and fir.shape == (B, T, 128) and torch.isfinite(film).all() and torch.isfinite(fir).all()
+    e_film, e_fir = maxabs(film.cpu().numpy(), film_t.cpu().numpy()), maxabs(fir.cpu().numpy(), fir_t.cpu().numpy())
+    record(f"frame_mlps_few_B{B}_T{T}", film=e_film, fir=e_fir, film_max=float(film_t.abs().max()), fir_max=float(fir_t.abs().max()))
+    assert e_film <= 2e-5 * max(1.0, float(film_t.abs().max())) and e_fir <= 2e-6 * max(1.0, float(fir_t.abs().max()) * 50), (e_film, e_fir)
+    assert not torch.equal(film, film_t) or B * T == 0          # it IS another kernel (same bits would mean the switch did nothing)
+
+
 def test_forward_pipeline_matches_plain_forward(models, oracle):
     """ForwardPipeline (control half on side streams, batched GRU, ring of workspaces) must return what model() returns for
     the same inputs and draws, batch after batch, including a shape change in mid-stream; one batch is also held against
