@@ -1,6 +1,7 @@
 // Stateful streaming step (the counterpart of the reference's stateless scripts/time_buffer_sizes.py:50-72):
 // one call = K new control frames of B parallel streams in, 128 K audio samples out, ALL state device-resident behind fixed
-// pointers, so that a steady-state hop is a fixed sequence of eight launches that a hipGraph replays.
+// pointers, so that a steady-state hop is a fixed sequence of launches that a hipGraph replays (four for hops of <= 256 samples:
+// see nws_stream_step; seven for longer chunks).
 //
 // What is carried (LABBOOK.md "7"): the GRU state h; the previous chunk's last frame (F0, FiLM row, FIR half-taps) so
 // that every kernel of the one-shot forward runs unchanged on the window [previous frame | K new frames]; the float64 phase

@@ -5,8 +5,10 @@ oscillator phase and the reverb.  `NewtStream` carries that state so that the co
 equals the reference's ONE-SHOT forward over the whole signal up to the reverb input (`pre_reverb`), and applies the
 learned reverb as a linear convolution of the stream instead of the one-shot path's wrap-around.
 
-One `push` = ONE C-ABI call (`nws_stream_step` / `torch.ops.newt_hip.stream_step`): eight launches of the one-shot kernels
-plus four small streaming kernels on a window = [last frame of the previous chunk] + [K new frames]; every piece of state
+One `push` = ONE C-ABI call (`nws_stream_step` / `torch.ops.newt_hip.stream_step`): the one-shot kernels plus small streaming
+kernels on a window = [last frame of the previous chunk] + [K new frames] - four launches for a hop of <= 256 samples (whatever
+depends on nothing the hop computes, and the frame MLPs of its one or two frames, ride on the recurrence launch: DESIGN.md 3.8),
+seven for longer chunks; every piece of state
 (GRU h, previous frame, float64 phase sum, noise residue and window, reverb-input ring, position counters) lives in one
 device blob behind fixed pointers.  Nothing is computed by torch.  Because the pointers and launch arguments of a
 steady-state hop (same K as the previous push, not first, not final) never change, such hops are captured ONCE into a
