@@ -21,16 +21,20 @@ def main():
     model = nws.NeuralWaveshaping.load_from_checkpoint(os.path.join(ROOT, "tests", "golden", "weights_vn.npz")).cuda().eval()
     model.newt = nws.FastNEWT(model.newt)
     g = torch.Generator(device="cpu").manual_seed(7)
-    K, hops = 2, 40
-    f0 = (220 + 20 * torch.rand(B, 1, K * hops, generator=g)).cuda()
-    control = torch.randn(B, 2, K * hops, generator=g).cuda()
-    noise = torch.rand(128 * K * hops - 1, generator=g).cuda()
+    # NWS_AB_CHUNKS="2,1,7,2,2,3" replaces the 40 hops of two frames by that chunk sequence (differential runs of the launch structures)
+    chunks = [int(c) for c in os.environ["NWS_AB_CHUNKS"].split(",")] if os.environ.get("NWS_AB_CHUNKS") else [2] * 40
+    K, total = 2, sum(chunks)
+    f0 = (220 + 20 * torch.rand(B, 1, total, generator=g)).cuda()
+    control = torch.randn(B, 2, total, generator=g).cuda()
+    noise = torch.rand(128 * total - 1, generator=g).cuda()
     phase_u = torch.rand(1, 101, 1, generator=g).cuda()
     outs = []
     with torch.no_grad():
         s = model.stream(B, phase_u=phase_u, noise=noise, graph=True)
-        for i in range(hops):
-            outs.append(s.push(f0[:, :, K * i:K * i + K], control[:, :, K * i:K * i + K], final=(i == hops - 1)).cpu().numpy())
+        at = 0
+        for i, k in enumerate(chunks):
+            outs.append(s.push(f0[:, :, at:at + k], control[:, :, at:at + k], final=(i == len(chunks) - 1)).cpu().numpy())
+            at += k
         np.save(out_path, np.concatenate(outs, axis=1))
         if dump_only:
             return
